@@ -1,0 +1,96 @@
+"""ctypes binding of include/ggl_mpops.h.
+
+The product loads exactly one library: ``gammagl_amd/lib/libggl_mpops_hip.so`` (hand-written HIP for
+gfx950, built in-tree by ``gammagl_amd/csrc/Makefile``).  If it is missing or does not load, importing
+the ops fails loudly — there is no CPU or pure-PyTorch fallback anywhere in this package.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
+
+GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
+ABI_VERSION = 1
+
+
+class SegPlanC(ctypes.Structure):
+    """struct ggl_segplan (include/ggl_mpops.h)."""
+
+    _fields_ = [
+        ("rowptr", c_void_p), ("perm", c_void_p), ("long_rows", c_void_p), ("chunk_ptr", c_void_p),
+        ("n_long", c_int64), ("n_chunks", c_int64), ("chunk", c_int64), ("partial", c_void_p),
+        ("N", c_int64), ("E", c_int64),
+    ]
+
+
+_P = POINTER(SegPlanC)
+_V = c_void_p
+
+# name -> (restype, argtypes): every symbol include/ggl_mpops.h declares
+SIGNATURES = {
+    "ggl_abi_version": (c_int, []),
+    "ggl_last_error": (c_char_p, []),
+    "ggl_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "ggl_plan_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ggl_plan_build": (c_int, [_V, c_int64, c_int64, _V, _V, _V, c_size_t, _V, POINTER(c_int32),
+                               POINTER(c_int64)]),
+    "ggl_plan_long_workspace_bytes": (c_size_t, [c_int64]),
+    "ggl_plan_long_count": (c_int, [_V, c_int64, c_int64, _V, c_size_t, _V, POINTER(c_int64),
+                                    POINTER(c_int64)]),
+    "ggl_plan_long_fill": (c_int, [_V, c_int64, c_int64, c_int64, _V, _V, _V, c_size_t, _V]),
+    "ggl_partial_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int]),
+    "ggl_fill_i64": (c_int, [_V, c_int64, c_int64, _V]),
+    "ggl_gather_i64_to_i32": (c_int, [_V, _V, c_int64, _V, _V]),
+    "ggl_gather_rows_f32": (c_int, [_V, _V, c_int64, c_int64, _V, _V]),
+    "ggl_segment_sum": (c_int, [c_int, _V, _P, c_int64, _V, _V]),
+    "ggl_segment_mean": (c_int, [c_int, _V, _P, c_int64, _V, _V]),
+    "ggl_segment_max": (c_int, [c_int, _V, _P, c_int64, _V, _V, c_int64, _V]),
+    "ggl_segment_sum_bwd": (c_int, [c_int, _V, _V, c_int64, c_int64, _V, _V]),
+    "ggl_segment_mean_bwd": (c_int, [c_int, _V, _V, _V, c_int64, c_int64, _V, _V]),
+    "ggl_segment_max_bwd": (c_int, [c_int, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
+    "ggl_spmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V]),
+    "ggl_spmm_mean": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V]),
+    "ggl_spmm_max": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V, _V]),
+    "ggl_spmm_mean_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
+    "ggl_spmm_max_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
+    "ggl_bspmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, _V]),
+    "ggl_bspmm_grad_w": (c_int, [_V, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
+    "ggl_gat_fused_fwd": (c_int, [_P, _V, _V, _V, _V, c_float, c_int64, c_int64, _V, _V, _V, _V]),
+    "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,
+                                      _V, _V, _V, _V]),
+    "ggl_gat_fused_bwd_src": (c_int, [_P, _V, _V, _V, _V, _V, c_int64, c_int64, _V, _V, _V]),
+    "ggl_set_option": (c_int, [c_char_p, c_int64]),
+    "ggl_get_option": (c_int64, [c_char_p]),
+    "ggl_time_spmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V, c_int, POINTER(c_float)]),
+}
+
+
+def bind(path):
+    """dlopen `path` and attach the prototypes of every symbol the header declares."""
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.ggl_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {got}, expected {ABI_VERSION}")
+    return lib
+
+
+_hip = None
+
+
+def hip_lib():
+    """The HIP library (singleton).  Raises ImportError when it has not been built."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise ImportError(
+                f"{HIP_LIB_PATH} not found: build it with `make -C gammagl_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()').  gammagl_amd has no "
+                "CPU / PyTorch fallback.")
+        _hip = bind(HIP_LIB_PATH)
+    return _hip

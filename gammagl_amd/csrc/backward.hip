@@ -1,0 +1,173 @@
+// gammagl_amd/csrc/backward.hip — edge-parallel kernels: the backward passes of the segment ops and
+// bspmm's per-edge weight gradient.  These have no reduction across edges, so they are plain
+// coalesced row copies / per-edge dot products.
+//   ggl_segment_sum_bwd  : SegmentSum::backward  (src/segment_sum.cpp:43-54)   gin[e] = gout[ids[e]]
+//   ggl_segment_mean_bwd : SegmentMean::backward (src/segment_mean.cpp:44-63)  ... / bincount[ids[e]]
+//   ggl_segment_max_bwd  : SegmentMax::backward  (src/segment_max.cpp:48-61)   scatter by argmax
+//   ggl_bspmm_grad_w     : bspmm_sum_cpu_backward's grad_weight (cpu/bspmm_sum_cpu.cpp:102-107)
+#include "common.hpp"
+
+namespace ggl {
+
+// One lane group of L = 2^logL lanes per destination row e; VEC elements per lane per step.
+// MEAN divides by the segment's element count (int64 -> storage float type, then a rounded divide).
+template <typename T, int VEC, bool MEAN>
+__global__ __launch_bounds__(kBlock) void row_gather_kernel(const typename TT<T>::S *src,
+                                                            const int64_t *ids,
+                                                            const int64_t *rowptr, int64_t E,
+                                                            int64_t K, int logL,
+                                                            typename TT<T>::S *dst) {
+  using S = typename TT<T>::S;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int L = 1 << logL;
+  const int64_t e = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * (kWave >> logL) + (lane >> logL);
+  if (e >= E) return;
+  const int li = lane & (L - 1);
+  const int64_t s = ids[e];
+  typename TT<T>::A cnt = TT<T>::zero();
+  // torch promotes the int64 bincount to the gradient dtype before dividing (segment_mean.cpp:61)
+  if (MEAN) cnt = TT<T>::load(TT<T>::store((typename TT<T>::A)(rowptr[s + 1] - rowptr[s])));
+  for (int64_t kk = (int64_t)li * VEC; kk < K; kk += (int64_t)L * VEC) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      if (kk + i < K) {
+        S v = src[s * K + kk + i];
+        if (MEAN) v = TT<T>::store(TT<T>::div(TT<T>::load(v), cnt));
+        dst[e * K + kk + i] = v;
+      }
+    }
+  }
+}
+
+// gin pre-zeroed; one thread per (s,k): gin[arg[s,k], k] = gout[s,k] when 0 <= arg < E
+template <typename S>
+__global__ __launch_bounds__(kBlock) void max_scatter_kernel(const S *gout, const int64_t *arg,
+                                                             int64_t total, int64_t K, int64_t E,
+                                                             S *gin) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t a = arg[i];
+    if (a >= 0 && a < E) gin[a * K + (i % K)] = gout[i];
+  }
+}
+
+// gw[e,h] = sum_c x[src,h,c] * g[dst,h,c]   (serial over c, rounded multiply then rounded add)
+__global__ __launch_bounds__(kBlock) void bspmm_grad_w_kernel(const int64_t *index, const float *x,
+                                                              const float *g, int64_t E, int64_t H,
+                                                              int64_t C, float *gw) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E * H; i += stride) {
+    const int64_t e = i / H, h = i - e * H;
+    const float *xr = x + (index[e] * H + h) * C;
+    const float *gr = g + (index[e + E] * H + h) * C;
+    float acc = 0.0f;
+    for (int64_t c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(xr[c], gr[c]));
+    gw[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_i64_kernel(int64_t *p, int64_t n, int64_t v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+static inline int64_t grid_for(int64_t n) {
+  int64_t g = ceil_div(n, kBlock);
+  if (g > 2048) g = 2048;
+  return g < 1 ? 1 : g;
+}
+
+static inline int group_log2(int64_t K) {
+  int l = 0;
+  while (l < 6 && ((int64_t)1 << l) < K) ++l;
+  return l;
+}
+
+template <typename T, bool MEAN>
+static int launch_gather(const void *gout, const int64_t *ids, const int64_t *rowptr, int64_t E,
+                         int64_t K, void *gin, hipStream_t s) {
+  using S = typename TT<T>::S;
+  if (E == 0 || K == 0) return GGL_OK;
+  const int logL = group_log2(K);
+  const int64_t rows_per_block = kWavesPerBlock * (kWave >> logL);
+  GGL_LAUNCH((row_gather_kernel<T, 1, MEAN>), ceil_div(E, rows_per_block), kBlock, s,
+             static_cast<const S *>(gout), ids, rowptr, E, K, logL, static_cast<S *>(gin));
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+}  // namespace ggl
+
+using namespace ggl;
+
+extern "C" int ggl_fill_i64(int64_t *p, int64_t n, int64_t v, void *stream) {
+  if (n <= 0) return GGL_OK;
+  GGL_REQUIRE(p != nullptr, GGL_EINVAL, "p is NULL");
+  GGL_LAUNCH((fill_i64_kernel), grid_for(n), kBlock, as_stream(stream), p, n, v);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+extern "C" int ggl_segment_sum_bwd(int dtype, const void *gout, const int64_t *ids, int64_t E,
+                                   int64_t K, void *gin, void *stream) {
+  GGL_REQUIRE(E >= 0 && K >= 0, GGL_EINVAL, "negative size");
+  GGL_REQUIRE((gout && ids && gin) || E * K == 0, GGL_EINVAL, "NULL pointer");
+  hipStream_t s = as_stream(stream);
+  switch (dtype_size(dtype)) {  // a pure row copy: only the element width matters
+    case 1: return launch_gather<uint8_t, false>(gout, ids, nullptr, E, K, gin, s);
+    case 2: return launch_gather<int16_t, false>(gout, ids, nullptr, E, K, gin, s);
+    case 4: return launch_gather<int32_t, false>(gout, ids, nullptr, E, K, gin, s);
+    case 8: return launch_gather<int64_t, false>(gout, ids, nullptr, E, K, gin, s);
+    default: set_error("unsupported dtype code %d", dtype); return GGL_EDTYPE;
+  }
+}
+
+extern "C" int ggl_segment_mean_bwd(int dtype, const void *gout, const int64_t *ids,
+                                    const int64_t *rowptr, int64_t E, int64_t K, void *gin,
+                                    void *stream) {
+  GGL_REQUIRE(E >= 0 && K >= 0, GGL_EINVAL, "negative size");
+  GGL_REQUIRE((gout && ids && gin && rowptr) || E * K == 0, GGL_EINVAL, "NULL pointer");
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case GGL_F32: return launch_gather<float, true>(gout, ids, rowptr, E, K, gin, s);
+    case GGL_F64: return launch_gather<double, true>(gout, ids, rowptr, E, K, gin, s);
+    case GGL_F16: return launch_gather<f16_t, true>(gout, ids, rowptr, E, K, gin, s);
+    case GGL_BF16: return launch_gather<bf16_t, true>(gout, ids, rowptr, E, K, gin, s);
+    default: set_error("mean backward needs a floating dtype (got code %d)", dtype); return GGL_EDTYPE;
+  }
+}
+
+extern "C" int ggl_segment_max_bwd(int dtype, const void *gout, const int64_t *arg, int64_t E,
+                                   int64_t N, int64_t K, void *gin, void *stream) {
+  GGL_REQUIRE(E >= 0 && K >= 0 && N >= 0, GGL_EINVAL, "negative size");
+  const size_t es = dtype_size(dtype);
+  GGL_REQUIRE(es != 0, GGL_EDTYPE, "unsupported dtype code %d", dtype);
+  hipStream_t s = as_stream(stream);
+  if (E * K > 0) {
+    GGL_REQUIRE(gin != nullptr, GGL_EINVAL, "gin is NULL");
+    GGL_HIP_CHECK(hipMemsetAsync(gin, 0, (size_t)E * K * es, s));
+  }
+  const int64_t total = N * K;
+  if (total == 0 || E == 0) return GGL_OK;
+  GGL_REQUIRE(gout && arg, GGL_EINVAL, "gout/arg is NULL");
+  switch (es) {
+    case 1: GGL_LAUNCH((max_scatter_kernel<uint8_t>), grid_for(total), kBlock, s, (const uint8_t *)gout, arg, total, K, E, (uint8_t *)gin); break;
+    case 2: GGL_LAUNCH((max_scatter_kernel<uint16_t>), grid_for(total), kBlock, s, (const uint16_t *)gout, arg, total, K, E, (uint16_t *)gin); break;
+    case 4: GGL_LAUNCH((max_scatter_kernel<uint32_t>), grid_for(total), kBlock, s, (const uint32_t *)gout, arg, total, K, E, (uint32_t *)gin); break;
+    default: GGL_LAUNCH((max_scatter_kernel<uint64_t>), grid_for(total), kBlock, s, (const uint64_t *)gout, arg, total, K, E, (uint64_t *)gin); break;
+  }
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+extern "C" int ggl_bspmm_grad_w(const int64_t *index, const float *x, const float *g, int64_t E,
+                                int64_t H, int64_t C, float *gw, void *stream) {
+  GGL_REQUIRE(E >= 0 && H > 0 && C > 0, GGL_EINVAL, "bad sizes");
+  if (E == 0) return GGL_OK;
+  GGL_REQUIRE(index && x && g && gw, GGL_EINVAL, "NULL pointer");
+  GGL_LAUNCH((bspmm_grad_w_kernel), grid_for(E * H), kBlock, as_stream(stream), index, x, g, E, H, C,
+             gw);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}

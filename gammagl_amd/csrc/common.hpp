@@ -1,0 +1,193 @@
+// gammagl_amd/csrc/common.hpp — shared host/device helpers for libggl_mpops_hip.so (gfx950 only).
+#pragma once
+#ifdef GGL_EMULATE
+// Host build of the SAME kernel sources, one "thread" at a time (tests/emul/).  Test
+// infrastructure for the GPU-less container: never built into, nor loaded by, the product.
+#include "../../tests/emul/emul_shim.hpp"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+
+#include <cfloat>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/ggl_mpops.h"
+
+namespace ggl {
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kBlock = 256;      // 4 waves: one per SIMD of a CU
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+enum Op { OP_SUM = 0, OP_MEAN = 1, OP_MAX = 2 };
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define GGL_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::ggl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                       __LINE__);                                                        \
+      return GGL_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+#define GGL_REQUIRE(cond, code, ...)                                                     \
+  do {                                                                                   \
+    if (!(cond)) {                                                                       \
+      ::ggl::set_error(__VA_ARGS__);                                                     \
+      return (code);                                                                     \
+    }                                                                                    \
+  } while (0)
+#define GGL_LAUNCH_CHECK() GGL_HIP_CHECK(hipGetLastError())
+
+// kernel launch: KERN is a parenthesised kernel name, e.g. (k<float, 4>)
+#ifdef GGL_EMULATE
+#define GGL_LAUNCH(KERN, GRID, BLOCK, STREAM, ...) \
+  ::ggl_emul::launch((GRID), (BLOCK), [&]() { KERN(__VA_ARGS__); })
+#else
+#define GGL_LAUNCH(KERN, GRID, BLOCK, STREAM, ...) \
+  hipLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3((unsigned)(BLOCK)), 0, (STREAM), __VA_ARGS__)
+#endif
+
+struct Options {
+  int64_t unroll = 4;        // neighbour loads in flight per lane in the f32 fast path (4 or 8)
+  int64_t xcd_swizzle = 1;   // give each XCD a contiguous range of row blocks (private L2 locality)
+  int64_t force_generic = 0; // route f32 through the VEC=1 generic kernel (A/B aid)
+  int64_t rows_per_block_log2 = -1;  // reserved
+};
+Options &options();
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- dtype semantics: "accumulate in the storage dtype" (segment_sum_cpu.cpp:56) ---------------
+// S = storage type in memory, A = register type.  add() rounds to storage precision after every
+// step, exactly like c10::Half / c10::BFloat16 operator+= (float add, then round-to-nearest-even).
+struct bf16_t { uint16_t bits; };
+struct f16_t { uint16_t bits; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t x = __float_as_uint(f);
+  if ((x & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;  // c10::BFloat16: NaN -> 0x7FC0
+  return (uint16_t)((x + (((x >> 16) & 1u) + 0x7fffu)) >> 16);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t b) {
+  _Float16 h;
+  __builtin_memcpy(&h, &b, 2);
+  return (float)h;
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+  _Float16 h = (_Float16)f;  // v_cvt_f16_f32, round-to-nearest-even
+  uint16_t b;
+  __builtin_memcpy(&b, &h, 2);
+  return b;
+}
+
+template <typename T> struct TT;
+
+#define GGL_INT_TT(T, LOW)                                                               \
+  template <> struct TT<T> {                                                             \
+    using S = T;                                                                         \
+    using A = T;                                                                         \
+    static __device__ __forceinline__ A load(S v) { return v; }                          \
+    static __device__ __forceinline__ S store(A v) { return v; }                         \
+    static __device__ __forceinline__ A add(A a, A b) {                                  \
+      using U = typename std::make_unsigned<T>::type;                                    \
+      return (T)(U)((U)a + (U)b);                                                        \
+    }                                                                                    \
+    static __device__ __forceinline__ bool less(A a, A b) { return a < b; }              \
+    static __device__ __forceinline__ A lowest() { return (T)(LOW); }                    \
+    static __device__ __forceinline__ A zero() { return (T)0; }                          \
+    static __device__ __forceinline__ A count(int64_t c) { return (T)c; }                \
+    static __device__ __forceinline__ bool gt1(A c) { return c > (T)1; }                 \
+    static __device__ __forceinline__ A div(A a, A c) { return (T)(a / c); }             \
+  };
+GGL_INT_TT(uint8_t, 0)
+GGL_INT_TT(int8_t, INT8_MIN)
+GGL_INT_TT(int16_t, INT16_MIN)
+GGL_INT_TT(int32_t, INT32_MIN)
+GGL_INT_TT(int64_t, INT64_MIN)
+
+template <> struct TT<float> {
+  using S = float;
+  using A = float;
+  static __device__ __forceinline__ A load(S v) { return v; }
+  static __device__ __forceinline__ S store(A v) { return v; }
+  static __device__ __forceinline__ A add(A a, A b) { return __fadd_rn(a, b); }
+  static __device__ __forceinline__ bool less(A a, A b) { return a < b; }
+  static __device__ __forceinline__ A lowest() { return -FLT_MAX; }
+  static __device__ __forceinline__ A zero() { return 0.0f; }
+  // the reference counts in x's dtype with += 1 (segment_mean_cpu.cpp:44,52): a float counter
+  // stops growing at 2^24
+  static __device__ __forceinline__ A count(int64_t c) { return (float)(c < 16777216 ? c : 16777216); }
+  static __device__ __forceinline__ bool gt1(A c) { return c > 1.0f; }
+  static __device__ __forceinline__ A div(A a, A c) { return __fdiv_rn(a, c); }
+};
+template <> struct TT<double> {
+  using S = double;
+  using A = double;
+  static __device__ __forceinline__ A load(S v) { return v; }
+  static __device__ __forceinline__ S store(A v) { return v; }
+  static __device__ __forceinline__ A add(A a, A b) { return __dadd_rn(a, b); }
+  static __device__ __forceinline__ bool less(A a, A b) { return a < b; }
+  static __device__ __forceinline__ A lowest() { return -DBL_MAX; }
+  static __device__ __forceinline__ A zero() { return 0.0; }
+  static __device__ __forceinline__ A count(int64_t c) { return (double)c; }
+  static __device__ __forceinline__ bool gt1(A c) { return c > 1.0; }
+  static __device__ __forceinline__ A div(A a, A c) { return __ddiv_rn(a, c); }
+};
+template <> struct TT<f16_t> {
+  using S = uint16_t;
+  using A = float;  // always holds a value exactly representable in f16
+  static __device__ __forceinline__ A load(S v) { return f16_to_f32(v); }
+  static __device__ __forceinline__ S store(A v) { return f32_to_f16(v); }
+  static __device__ __forceinline__ A add(A a, A b) { return f16_to_f32(f32_to_f16(__fadd_rn(a, b))); }
+  static __device__ __forceinline__ bool less(A a, A b) { return a < b; }
+  static __device__ __forceinline__ A lowest() { return -65504.0f; }
+  static __device__ __forceinline__ A zero() { return 0.0f; }
+  static __device__ __forceinline__ A count(int64_t c) { return (float)(c < 2048 ? c : 2048); }
+  static __device__ __forceinline__ bool gt1(A c) { return c > 1.0f; }
+  static __device__ __forceinline__ A div(A a, A c) { return f16_to_f32(f32_to_f16(__fdiv_rn(a, c))); }
+};
+template <> struct TT<bf16_t> {
+  using S = uint16_t;
+  using A = float;  // always holds a value exactly representable in bf16
+  static __device__ __forceinline__ A load(S v) { return bf16_to_f32(v); }
+  static __device__ __forceinline__ S store(A v) { return f32_to_bf16(v); }
+  static __device__ __forceinline__ A add(A a, A b) { return bf16_to_f32(f32_to_bf16(__fadd_rn(a, b))); }
+  static __device__ __forceinline__ bool less(A a, A b) { return a < b; }
+  static __device__ __forceinline__ A lowest() { return bf16_to_f32(0xFF7Fu); }
+  static __device__ __forceinline__ A zero() { return 0.0f; }
+  static __device__ __forceinline__ A count(int64_t c) { return (float)(c < 256 ? c : 256); }
+  static __device__ __forceinline__ bool gt1(A c) { return c > 1.0f; }
+  static __device__ __forceinline__ A div(A a, A c) { return bf16_to_f32(f32_to_bf16(__fdiv_rn(a, c))); }
+};
+
+static inline size_t dtype_size(int dtype) {
+  switch (dtype) {
+    case GGL_U8: case GGL_I8: return 1;
+    case GGL_I16: case GGL_F16: case GGL_BF16: return 2;
+    case GGL_I32: case GGL_F32: return 4;
+    case GGL_I64: case GGL_F64: return 8;
+    default: return 0;
+  }
+}
+
+// block id -> logical block id so that each XCD (block b runs on XCD b % 8, observed) owns a
+// contiguous range of row blocks: neighbouring rows of a locality-ordered graph then share one
+// private 4 MiB L2.  Pure performance: any mapping is correct.  (guide §5.5 T1)
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb, int swizzle) {
+  if (!swizzle) return b;
+  const int64_t per = nb >> 3;
+  const int64_t main_blocks = per << 3;
+  if (b >= main_blocks) return b;  // ragged tail keeps identity
+  return (b & 7) * per + (b >> 3);
+}
+
+}  // namespace ggl

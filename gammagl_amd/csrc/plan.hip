@@ -1,0 +1,397 @@
+// gammagl_amd/csrc/plan.hip — COO ids -> destination-sorted plan (perm, rowptr, long-row lists), plus
+// the library's small housekeeping entry points (errors, options, device info).
+//
+// This is the step the reference does implicitly on every call by scattering with atomics
+// (cuda/segment_sum_cuda.cu:19-31) — and, on the CUDA path, with two device->host syncs per call
+// (segment_sum_cuda.cu:51-53).  Here it happens once per edge list: a stable LSD radix sort of
+// (id, e) pairs (rocPRIM), a binary search per segment for rowptr, and a two-level ordered
+// compaction of the rows longer than `chunk`.  The hot kernels (reduce.hip) never sort, never
+// sync and never use atomics.
+#include "common.hpp"
+
+#include <cstdarg>
+
+#ifndef GGL_EMULATE
+#include <rocprim/rocprim.hpp>
+#else
+#include <algorithm>
+#include <numeric>
+#include <vector>
+#endif
+
+namespace ggl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static int64_t env_i64(const char *name, int64_t dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? atoll(v) : dflt;
+}
+
+Options &options() {
+  static Options o = [] {
+    Options t;
+    t.unroll = env_i64("GGL_UNROLL", t.unroll);
+    t.xcd_swizzle = env_i64("GGL_XCD_SWIZZLE", t.xcd_swizzle);
+    t.force_generic = env_i64("GGL_FORCE_GENERIC", t.force_generic);
+    return t;
+  }();
+  return o;
+}
+
+// flags[0] = some id out of [0, N); flags[1] = ids not non-decreasing
+__global__ __launch_bounds__(kBlock) void check_ids_kernel(const int64_t *ids, int64_t E, int64_t N,
+                                                           int32_t *flags) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+    const int64_t v = ids[i];
+    if (v < 0 || v >= N) flags[0] = 1;  // benign race: every writer stores the same value
+    if (i > 0 && ids[i - 1] > v) flags[1] = 1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void keys_iota_kernel(const int64_t *ids, int64_t E,
+                                                           uint32_t *keys, int32_t *vals) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+    if (keys) keys[i] = (uint32_t)ids[i];
+    vals[i] = (int32_t)i;
+  }
+}
+
+// rowptr[s] = first position p with key[p] >= s   (keys sorted ascending), s = 0..N
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void rowptr_kernel(const KeyT *keys, int64_t E, int64_t N,
+                                                        int64_t *rowptr) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= N; s += stride) {
+    int64_t lo = 0, hi = E;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)keys[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    rowptr[s] = lo;
+  }
+}
+
+// ---- two-level ordered scan over rows (no atomics, no LDS) --------------------------------------
+constexpr int64_t kSpan = 2048;  // rows per scanning thread
+
+// per span: number of long rows, number of chunks, longest row
+__global__ __launch_bounds__(kBlock) void span_count_kernel(const int64_t *rowptr, int64_t N,
+                                                            int64_t chunk, int64_t nspans,
+                                                            int64_t *span_long, int64_t *span_chunks,
+                                                            int64_t *span_maxlen) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nspans) return;
+  const int64_t r0 = t * kSpan, r1 = (r0 + kSpan < N) ? r0 + kSpan : N;
+  int64_t nl = 0, nc = 0, mx = 0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const int64_t len = rowptr[r + 1] - rowptr[r];
+    if (len > mx) mx = len;
+    if (len > chunk) {
+      ++nl;
+      nc += (len + chunk - 1) / chunk;
+    }
+  }
+  span_long[t] = nl;
+  span_chunks[t] = nc;
+  span_maxlen[t] = mx;
+}
+
+// one thread: exclusive scan of the span counts in place; totals[0..2] = n_long, n_chunks, max_len
+__global__ void span_scan_kernel(int64_t nspans, int64_t *span_long, int64_t *span_chunks,
+                                 const int64_t *span_maxlen, int64_t *totals) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int64_t al = 0, ac = 0, mx = 0;
+  for (int64_t t = 0; t < nspans; ++t) {
+    const int64_t l = span_long[t], c = span_chunks[t];
+    span_long[t] = al;
+    span_chunks[t] = ac;
+    al += l;
+    ac += c;
+    if (span_maxlen[t] > mx) mx = span_maxlen[t];
+  }
+  totals[0] = al;
+  totals[1] = ac;
+  totals[2] = mx;
+}
+
+__global__ __launch_bounds__(kBlock) void span_fill_kernel(const int64_t *rowptr, int64_t N,
+                                                           int64_t chunk, int64_t nspans,
+                                                           const int64_t *span_long,
+                                                           const int64_t *span_chunks,
+                                                           int32_t *long_rows, int64_t *chunk_ptr,
+                                                           int64_t n_long, int64_t n_chunks) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) chunk_ptr[n_long] = n_chunks;
+  if (t >= nspans) return;
+  const int64_t r0 = t * kSpan, r1 = (r0 + kSpan < N) ? r0 + kSpan : N;
+  int64_t slot = span_long[t], cacc = span_chunks[t];
+  for (int64_t r = r0; r < r1; ++r) {
+    const int64_t len = rowptr[r + 1] - rowptr[r];
+    if (len > chunk) {
+      long_rows[slot] = (int32_t)r;
+      chunk_ptr[slot] = cacc;
+      ++slot;
+      cacc += (len + chunk - 1) / chunk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_i64_i32_kernel(const int64_t *src,
+                                                                const int32_t *perm, int64_t E,
+                                                                int32_t *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride)
+    out[i] = (int32_t)src[perm ? (int64_t)perm[i] : i];
+}
+
+__global__ __launch_bounds__(kBlock) void gather_rows_f32_kernel(const float *src,
+                                                                 const int32_t *perm, int64_t total,
+                                                                 int64_t H, float *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t p = i / H, h = i - p * H;
+    out[i] = src[(perm ? (int64_t)perm[p] : p) * H + h];
+  }
+}
+
+static inline int64_t grid_for(int64_t n) {
+  int64_t g = ceil_div(n, kBlock);
+  const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks: grid-stride the rest (guide G11)
+  if (g > cap) g = cap;
+  return g < 1 ? 1 : g;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static inline int key_bits(int64_t N) {
+  int b = 1;
+  while (b < 32 && ((int64_t)1 << b) < N) ++b;
+  return b;
+}
+
+#ifndef GGL_EMULATE
+static size_t sort_temp_bytes(int64_t E, int bits) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                  (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)E, 0u,
+                                  (unsigned)bits, (hipStream_t)0);
+  return tmp;
+}
+#endif
+
+}  // namespace ggl
+
+using namespace ggl;
+
+extern "C" int ggl_abi_version(void) { return GGL_ABI_VERSION; }
+extern "C" const char *ggl_last_error(void) { return g_err; }
+
+extern "C" int ggl_device_info(int *cus_host, int *wave_host, char *arch_host, int arch_len) {
+#ifdef GGL_EMULATE
+  if (cus_host) *cus_host = 1;
+  if (wave_host) *wave_host = 64;
+  if (arch_host && arch_len > 0) snprintf(arch_host, (size_t)arch_len, "emulated");
+  return GGL_OK;
+#else
+  int dev = 0;
+  GGL_HIP_CHECK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  GGL_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  if (cus_host) *cus_host = prop.multiProcessorCount;
+  if (wave_host) *wave_host = prop.warpSize;
+  if (arch_host && arch_len > 0) snprintf(arch_host, (size_t)arch_len, "%s", prop.gcnArchName);
+  return GGL_OK;
+#endif
+}
+
+extern "C" int ggl_set_option(const char *name, int64_t value) {
+  Options &o = options();
+  if (!strcmp(name, "unroll")) o.unroll = value;
+  else if (!strcmp(name, "xcd_swizzle")) o.xcd_swizzle = value;
+  else if (!strcmp(name, "force_generic")) o.force_generic = value;
+  else { set_error("unknown option %s", name); return GGL_EINVAL; }
+  return GGL_OK;
+}
+
+extern "C" int64_t ggl_get_option(const char *name) {
+  Options &o = options();
+  if (!strcmp(name, "unroll")) return o.unroll;
+  if (!strcmp(name, "xcd_swizzle")) return o.xcd_swizzle;
+  if (!strcmp(name, "force_generic")) return o.force_generic;
+  return -1;
+}
+
+extern "C" size_t ggl_plan_workspace_bytes(int64_t E, int64_t N) {
+  if (E < 0 || N < 0) return 0;
+  size_t b = 256;                                        // flags
+  b += 2 * align_up((size_t)E * 4, 256);                 // keys in / out
+  b += align_up((size_t)E * 4, 256);                     // vals in
+#ifndef GGL_EMULATE
+  b += align_up(sort_temp_bytes(E > 0 ? E : 1, key_bits(N)), 256);
+#endif
+  b += 3 * align_up((size_t)(ceil_div(N > 0 ? N : 1, kSpan)) * 8, 256) + 256;  // max_len scan
+  return b;
+}
+
+extern "C" size_t ggl_plan_long_workspace_bytes(int64_t N) {
+  return 3 * align_up((size_t)(ceil_div(N > 0 ? N : 1, kSpan)) * 8, 256) + 256;
+}
+
+static int run_span_scan(const int64_t *rowptr, int64_t N, int64_t chunk, char *ws, hipStream_t s,
+                         int64_t **span_long, int64_t **span_chunks, int64_t totals_host[3]) {
+  const int64_t nspans = ceil_div(N > 0 ? N : 1, kSpan);
+  const size_t seg = align_up((size_t)nspans * 8, 256);
+  int64_t *sl = reinterpret_cast<int64_t *>(ws);
+  int64_t *sc = reinterpret_cast<int64_t *>(ws + seg);
+  int64_t *sm = reinterpret_cast<int64_t *>(ws + 2 * seg);
+  int64_t *tot = reinterpret_cast<int64_t *>(ws + 3 * seg);
+  GGL_LAUNCH((span_count_kernel), ceil_div(nspans, kBlock), kBlock, s, rowptr, N, chunk, nspans, sl,
+             sc, sm);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((span_scan_kernel), 1, 64, s, nspans, sl, sc, sm, tot);
+  GGL_LAUNCH_CHECK();
+  GGL_HIP_CHECK(hipMemcpyAsync(totals_host, tot, 24, hipMemcpyDeviceToHost, s));
+  GGL_HIP_CHECK(hipStreamSynchronize(s));
+  *span_long = sl;
+  *span_chunks = sc;
+  return GGL_OK;
+}
+
+extern "C" int ggl_plan_build(const int64_t *ids, int64_t E, int64_t N, int32_t *perm,
+                              int64_t *rowptr, void *workspace, size_t workspace_bytes,
+                              void *stream, int32_t *is_sorted_host, int64_t *max_len_host) {
+  GGL_REQUIRE(E >= 0 && N >= 0, GGL_EINVAL, "negative size");
+  GGL_REQUIRE(E < ((int64_t)1 << 31), GGL_EINVAL, "E >= 2^31 elements per plan is not supported");
+  GGL_REQUIRE(N < ((int64_t)1 << 31), GGL_EINVAL, "N >= 2^31 segments is not supported");
+  GGL_REQUIRE(rowptr != nullptr, GGL_EINVAL, "rowptr is NULL");
+  GGL_REQUIRE((ids && perm) || E == 0, GGL_EINVAL, "ids/perm is NULL");
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_plan_workspace_bytes(E, N), GGL_EWORKSPACE,
+              "plan workspace too small: need %zu bytes", ggl_plan_workspace_bytes(E, N));
+  hipStream_t s = as_stream(stream);
+  char *ws = static_cast<char *>(workspace);
+  int32_t *flags = reinterpret_cast<int32_t *>(ws);
+  size_t off = 256;
+  uint32_t *keys_in = reinterpret_cast<uint32_t *>(ws + off);
+  off += align_up((size_t)E * 4, 256);
+  uint32_t *keys_out = reinterpret_cast<uint32_t *>(ws + off);
+  off += align_up((size_t)E * 4, 256);
+  int32_t *vals_in = reinterpret_cast<int32_t *>(ws + off);
+  off += align_up((size_t)E * 4, 256);
+
+  int32_t flags_host[2] = {0, 0};
+  GGL_HIP_CHECK(hipMemsetAsync(flags, 0, 256, s));
+  if (E > 0) {
+    GGL_LAUNCH((check_ids_kernel), grid_for(E), kBlock, s, ids, E, N, flags);
+    GGL_LAUNCH_CHECK();
+  }
+  GGL_HIP_CHECK(hipMemcpyAsync(flags_host, flags, 8, hipMemcpyDeviceToHost, s));
+  GGL_HIP_CHECK(hipStreamSynchronize(s));
+  GGL_REQUIRE(flags_host[0] == 0, GGL_EINDEX, "segment id out of range [0, %lld)", (long long)N);
+  const bool sorted = flags_host[1] == 0;
+  if (is_sorted_host) *is_sorted_host = sorted ? 1 : 0;
+
+  if (sorted) {
+    if (E > 0) {
+      GGL_LAUNCH((keys_iota_kernel), grid_for(E), kBlock, s, ids, E, (uint32_t *)nullptr, perm);
+      GGL_LAUNCH_CHECK();
+    }
+    GGL_LAUNCH((rowptr_kernel<int64_t>), grid_for(N + 1), kBlock, s, ids, E, N, rowptr);
+    GGL_LAUNCH_CHECK();
+  } else {
+    GGL_LAUNCH((keys_iota_kernel), grid_for(E), kBlock, s, ids, E, keys_in, vals_in);
+    GGL_LAUNCH_CHECK();
+#ifndef GGL_EMULATE
+    const int bits = key_bits(N);
+    size_t tmp = sort_temp_bytes(E, bits);
+    void *tmp_ptr = ws + off;
+    off += align_up(tmp, 256);
+    GGL_HIP_CHECK(rocprim::radix_sort_pairs(tmp_ptr, tmp, (const uint32_t *)keys_in, keys_out,
+                                            (const int32_t *)vals_in, perm, (size_t)E, 0u,
+                                            (unsigned)bits, s));
+#else
+    std::vector<int32_t> order((size_t)E);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return keys_in[a] < keys_in[b]; });
+    for (int64_t i = 0; i < E; ++i) {
+      perm[i] = order[(size_t)i];
+      keys_out[i] = keys_in[order[(size_t)i]];
+    }
+#endif
+    GGL_LAUNCH((rowptr_kernel<uint32_t>), grid_for(N + 1), kBlock, s, (const uint32_t *)keys_out, E,
+               N, rowptr);
+    GGL_LAUNCH_CHECK();
+  }
+  // longest row (host fact used to size the long-row machinery)
+  int64_t *sl, *sc, totals[3] = {0, 0, 0};
+  char *scan_ws = ws + ggl_plan_workspace_bytes(E, N) - ggl_plan_long_workspace_bytes(N);
+  int rc = run_span_scan(rowptr, N, (int64_t)1 << 62, scan_ws, s, &sl, &sc, totals);
+  if (rc) return rc;
+  if (max_len_host) *max_len_host = totals[2];
+  return GGL_OK;
+}
+
+extern "C" int ggl_plan_long_count(const int64_t *rowptr, int64_t N, int64_t chunk, void *workspace,
+                                   size_t workspace_bytes, void *stream, int64_t *n_long_host,
+                                   int64_t *n_chunks_host) {
+  GGL_REQUIRE(rowptr && chunk > 0 && N >= 0, GGL_EINVAL, "bad arguments");
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_plan_long_workspace_bytes(N), GGL_EWORKSPACE,
+              "long-row workspace too small");
+  int64_t *sl, *sc, totals[3] = {0, 0, 0};
+  int rc = run_span_scan(rowptr, N, chunk, static_cast<char *>(workspace), as_stream(stream), &sl,
+                         &sc, totals);
+  if (rc) return rc;
+  if (n_long_host) *n_long_host = totals[0];
+  if (n_chunks_host) *n_chunks_host = totals[1];
+  return GGL_OK;
+}
+
+extern "C" int ggl_plan_long_fill(const int64_t *rowptr, int64_t N, int64_t chunk, int64_t n_long,
+                                  int32_t *long_rows, int64_t *chunk_ptr, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  GGL_REQUIRE(rowptr && chunk > 0 && N >= 0 && n_long >= 0, GGL_EINVAL, "bad arguments");
+  GGL_REQUIRE(chunk_ptr && (long_rows || n_long == 0), GGL_EINVAL, "long_rows/chunk_ptr is NULL");
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_plan_long_workspace_bytes(N), GGL_EWORKSPACE,
+              "long-row workspace too small");
+  hipStream_t s = as_stream(stream);
+  int64_t *sl, *sc, totals[3] = {0, 0, 0};
+  int rc = run_span_scan(rowptr, N, chunk, static_cast<char *>(workspace), s, &sl, &sc, totals);
+  if (rc) return rc;
+  GGL_REQUIRE(totals[0] == n_long, GGL_EINVAL, "n_long mismatch: plan has %lld long rows",
+              (long long)totals[0]);
+  const int64_t nspans = ceil_div(N > 0 ? N : 1, kSpan);
+  GGL_LAUNCH((span_fill_kernel), ceil_div(nspans, kBlock), kBlock, s, rowptr, N, chunk, nspans,
+             (const int64_t *)sl, (const int64_t *)sc, long_rows, chunk_ptr, n_long, totals[1]);
+  GGL_LAUNCH_CHECK();
+  GGL_HIP_CHECK(hipStreamSynchronize(s));
+  return GGL_OK;
+}
+
+extern "C" int ggl_gather_i64_to_i32(const int64_t *src, const int32_t *perm, int64_t E,
+                                     int32_t *out, void *stream) {
+  GGL_REQUIRE(E >= 0 && ((src && out) || E == 0), GGL_EINVAL, "bad arguments");
+  if (E == 0) return GGL_OK;
+  GGL_LAUNCH((gather_i64_i32_kernel), grid_for(E), kBlock, as_stream(stream), src, perm, E, out);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+extern "C" int ggl_gather_rows_f32(const float *src, const int32_t *perm, int64_t E, int64_t H,
+                                   float *out, void *stream) {
+  GGL_REQUIRE(E >= 0 && H > 0 && ((src && out) || E == 0), GGL_EINVAL, "bad arguments");
+  if (E == 0) return GGL_OK;
+  GGL_LAUNCH((gather_rows_f32_kernel), grid_for(E * H), kBlock, as_stream(stream), src, perm, E * H,
+             H, out);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}

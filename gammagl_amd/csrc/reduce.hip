@@ -1,0 +1,559 @@
+// gammagl_amd/csrc/reduce.hip — the row-reduction kernels behind every aggregate on the path:
+//   ggl_segment_{sum,mean,max}          (supersede cpu/segment_*_cpu.cpp, cuda/segment_*_cuda.cu)
+//   ggl_spmm_{sum,mean,max}[_bwd]       (supersede cpu/spmm_*_cpu.cpp, cuda/spmm_sum_cuda.cu)
+//   ggl_bspmm_sum                       (supersedes cpu/bspmm_sum_cpu.cpp)
+//
+// One design for all of them (MI355X-first, not a port of the reference's one-thread-per-(edge,k)
+// atomicAdd scatter):
+//   * rows of the destination-sorted plan are the unit of work; a group of L = 2^logL lanes
+//     (L = 64 -> one wavefront per row) owns a row and strides the feature axis, VEC contiguous
+//     elements per lane (float4 = 16 B/lane -> 1 KiB per wave-load for K = 256);
+//   * the lane group walks the row's elements in ascending original order with U loads in
+//     flight, accumulating in order in registers: no atomics, no LDS, no cross-lane traffic,
+//     one coalesced store per output row.  Summation order == the reference's serial CPU order,
+//     so short rows are bit-identical to it and the argmax tie-break ("first edge wins") is exact;
+//   * for L = 64 the row id, rowptr, column indices and edge weights are wave-uniform: they are
+//     read through the scalar path (s_load) and broadcast for free, the vector memory pipe only
+//     carries feature rows;
+//   * rows longer than plan->chunk are cut into chunks reduced by independent wavefronts into a
+//     partial buffer and combined in chunk order (deterministic; bounds the tail a power-law hub
+//     would otherwise put on one wavefront);
+//   * block b -> row block remap keeps each XCD's private L2 on a contiguous row range.
+// Roofline: HBM.  Algorithmic bytes per edge = 4K (feature row) + 4 (col) + 4 (weight);
+// per output row = 4K + 8.
+#include "common.hpp"
+
+namespace ggl {
+
+enum Mode {
+  MODE_SEG = 0,        // value = x[e,:],                    e = perm ? perm[p] : p
+  MODE_SPMM = 1,       // value = w * x[col[p],:]
+  MODE_BSPMM = 2,      // value = w[.,h] * x[col[p],h,:],    h = k / C
+  MODE_MEANBWD = 3,    // value = g[col[p],:] / count[col[p]] * w       (spmm_mean_cpu.cpp:95-101)
+  MODE_MAXBWD = 4      // value = w * g[col[p],k] if argsrc[col[p],k] == row (spmm_max_cpu.cpp:88-93)
+};
+
+struct ReduceArgs {
+  const void *x;
+  const int32_t *perm;
+  const int32_t *col;
+  const float *w;
+  int w_by_pos;
+  const int64_t *rowptr;
+  int64_t N, K, E;
+  void *out;
+  int64_t *arg;
+  int64_t arg_fill;
+  int64_t chunk;
+  int logL;
+  int swizzle;
+  int64_t nblocks;
+  int64_t H, C;
+  const int64_t *aux_rowptr;
+  const int64_t *aux_arg;
+  const int32_t *long_rows;
+  const int64_t *chunk_ptr;
+  int64_t n_long, n_chunks;
+  void *partial;
+  int64_t *partial_arg;
+};
+
+// ---- VEC-wide loads / stores of storage elements ------------------------------------------------
+template <typename S, int VEC> struct VecIO {
+  static __device__ __forceinline__ void load(const S *p, S (&v)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = p[i];
+  }
+  static __device__ __forceinline__ void store(S *p, const S (&v)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = v[i];
+  }
+};
+template <> struct VecIO<float, 4> {
+  static __device__ __forceinline__ void load(const float *p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);  // global_load_dwordx4
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float *p, const float (&v)[4]) {
+    float4 t;
+    t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+    *reinterpret_cast<float4 *>(p) = t;
+  }
+};
+
+// ---- reduce sorted positions [beg, end) of `row` for the VEC features starting at kk -------------
+template <typename T, int VEC, int OP, int MODE, int U>
+__device__ __forceinline__ void reduce_range(const ReduceArgs &a, int64_t row, int64_t beg,
+                                             int64_t end, int64_t kk,
+                                             typename TT<T>::A (&acc)[VEC], int64_t (&arg)[VEC]) {
+  using S = typename TT<T>::S;
+  using A = typename TT<T>::A;
+  const S *xs = static_cast<const S *>(a.x);
+  const int64_t K = a.K;
+  const int64_t head = (MODE == MODE_BSPMM) ? kk / a.C : 0;
+
+  auto element = [&](int64_t p, int64_t &xrow, float &wv, int64_t &who) {
+    if (MODE == MODE_SEG) {
+      const int64_t e = a.perm ? (int64_t)a.perm[p] : p;
+      xrow = e;
+      who = e;
+      wv = 1.0f;
+    } else {
+      const int64_t c = (int64_t)a.col[p];
+      xrow = c;
+      who = c;
+      if (a.w) {
+        const int64_t wi = (a.w_by_pos || !a.perm) ? p : (int64_t)a.perm[p];
+        wv = (MODE == MODE_BSPMM) ? a.w[wi * a.H + head] : a.w[wi];
+      } else {
+        wv = 1.0f;
+      }
+    }
+  };
+
+  auto accumulate = [&](const S (&raw)[VEC], int64_t xrow, float wv, int64_t who) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      A v = TT<T>::load(raw[i]);
+      if (MODE == MODE_SPMM || MODE == MODE_BSPMM) {
+        if (a.w) v = (A)__fmul_rn(wv, (float)v);
+      } else if (MODE == MODE_MEANBWD) {
+        const int64_t cnt = a.aux_rowptr[xrow + 1] - a.aux_rowptr[xrow];
+        v = (A)__fdiv_rn((float)v, (float)cnt);
+        if (a.w) v = (A)__fmul_rn((float)v, wv);
+      } else if (MODE == MODE_MAXBWD) {
+        if (a.aux_arg[xrow * K + kk + i] != row) continue;
+        if (a.w) v = (A)__fmul_rn(wv, (float)v);
+      }
+      if (OP == OP_MAX) {
+        if (TT<T>::less(acc[i], v)) {
+          acc[i] = v;
+          arg[i] = who;
+        }
+      } else {
+        acc[i] = TT<T>::add(acc[i], v);
+      }
+    }
+  };
+
+  int64_t p = beg;
+  for (; p + U <= end; p += U) {
+    int64_t xrow[U], who[U];
+    float wv[U];
+    S raw[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) element(p + u, xrow[u], wv[u], who[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) VecIO<S, VEC>::load(xs + xrow[u] * K + kk, raw[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) accumulate(raw[u], xrow[u], wv[u], who[u]);
+  }
+  for (; p < end; ++p) {
+    int64_t xrow, who;
+    float wv;
+    S raw[VEC];
+    element(p, xrow, wv, who);
+    VecIO<S, VEC>::load(xs + xrow * K + kk, raw);
+    accumulate(raw, xrow, wv, who);
+  }
+}
+
+template <typename T, int VEC, int OP>
+__device__ __forceinline__ void init_acc(typename TT<T>::A (&acc)[VEC], int64_t (&arg)[VEC],
+                                         int64_t arg_fill) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    acc[i] = (OP == OP_MAX) ? TT<T>::lowest() : TT<T>::zero();
+    arg[i] = arg_fill;
+  }
+}
+
+// mean / store epilogue of a finished row
+template <typename T, int VEC, int OP, int MODE>
+__device__ __forceinline__ void finish_row(const ReduceArgs &a, int64_t row, int64_t len,
+                                           int64_t kk, typename TT<T>::A (&acc)[VEC],
+                                           const int64_t (&arg)[VEC]) {
+  using S = typename TT<T>::S;
+  if (OP == OP_MEAN) {
+    if (MODE == MODE_SEG) {
+      // segment_mean_cpu.cpp:67-76: count lives in x's dtype; divide only where count > 1
+      const typename TT<T>::A c = TT<T>::count(len);
+      if (TT<T>::gt1(c)) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = TT<T>::div(acc[i], c);
+      }
+    } else {
+      // spmm_mean_cpu.cpp:51-58: int64 count cast to float; divide where count > 0
+      if (len > 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = (typename TT<T>::A)__fdiv_rn((float)acc[i], (float)len);
+      }
+    }
+  }
+  S o[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
+  VecIO<S, VEC>::store(static_cast<S *>(a.out) + row * a.K + kk, o);
+  if (OP == OP_MAX) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a.arg[row * a.K + kk + i] = arg[i];
+  }
+}
+
+// ---- main kernel: every row with len <= chunk ---------------------------------------------------
+template <typename T, int VEC, int OP, int MODE, bool UNIFORM, int U>
+__global__ __launch_bounds__(kBlock) void row_reduce_kernel(const ReduceArgs a) {
+  using A = typename TT<T>::A;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int64_t blk = xcd_remap((int64_t)blockIdx.x, a.nblocks, a.swizzle);
+  const int L = 1 << a.logL;
+  int64_t row;
+  int li;
+  if (UNIFORM) {  // one wavefront per row: everything about the row is wave-uniform (scalar path)
+    row = blk * kWavesPerBlock + wave;
+    row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(row >> 32)) << 32) |
+          (uint32_t)__builtin_amdgcn_readfirstlane((int)(row & 0xffffffff));
+    li = lane;
+  } else {
+    const int rows_per_wave = kWave >> a.logL;
+    row = (blk * kWavesPerBlock + wave) * rows_per_wave + (lane >> a.logL);
+    li = lane & (L - 1);
+  }
+  if (row >= a.N) return;
+  const int64_t beg = a.rowptr[row], end = a.rowptr[row + 1];
+  const int64_t len = end - beg;
+  if (len > a.chunk) return;  // long row: handled by long_chunk_kernel + long_final_kernel
+  for (int64_t kk = (int64_t)li * VEC; kk < a.K; kk += (int64_t)L * VEC) {
+    A acc[VEC];
+    int64_t arg[VEC];
+    init_acc<T, VEC, OP>(acc, arg, a.arg_fill);
+    reduce_range<T, VEC, OP, MODE, U>(a, row, beg, end, kk, acc, arg);
+    finish_row<T, VEC, OP, MODE>(a, row, len, kk, acc, arg);
+  }
+}
+
+// ---- long rows: one wavefront per chunk, then an ordered combine --------------------------------
+template <typename T, int VEC, int OP, int MODE, int U>
+__global__ __launch_bounds__(kBlock) void long_chunk_kernel(const ReduceArgs a) {
+  using S = typename TT<T>::S;
+  using A = typename TT<T>::A;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  int64_t cid = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (cid >= a.n_chunks) return;
+  // owning long row: last j with chunk_ptr[j] <= cid
+  int64_t lo = 0, hi = a.n_long - 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (a.chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
+  }
+  const int64_t row = a.long_rows[lo];
+  const int64_t local = cid - a.chunk_ptr[lo];
+  const int64_t rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
+  const int64_t beg = rbeg + local * a.chunk;
+  const int64_t end = (beg + a.chunk < rend) ? beg + a.chunk : rend;
+  for (int64_t kk = (int64_t)lane * VEC; kk < a.K; kk += (int64_t)kWave * VEC) {
+    A acc[VEC];
+    int64_t arg[VEC];
+    init_acc<T, VEC, OP>(acc, arg, a.arg_fill);
+    reduce_range<T, VEC, OP, MODE, U>(a, row, beg, end, kk, acc, arg);
+    S o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
+    VecIO<S, VEC>::store(static_cast<S *>(a.partial) + cid * a.K + kk, o);
+    if (OP == OP_MAX) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) a.partial_arg[cid * a.K + kk + i] = arg[i];
+    }
+  }
+}
+
+template <typename T, int OP, int MODE>
+__global__ __launch_bounds__(kBlock) void long_final_kernel(const ReduceArgs a) {
+  using S = typename TT<T>::S;
+  using A = typename TT<T>::A;
+  const int64_t j = blockIdx.x;  // one block per long row
+  const int64_t row = a.long_rows[j];
+  const int64_t c0 = a.chunk_ptr[j], c1 = a.chunk_ptr[j + 1];
+  const int64_t len = a.rowptr[row + 1] - a.rowptr[row];
+  const S *part = static_cast<const S *>(a.partial);
+  for (int64_t k = threadIdx.x; k < a.K; k += kBlock) {
+    A acc[1];
+    int64_t arg[1];
+    init_acc<T, 1, OP>(acc, arg, a.arg_fill);
+    for (int64_t c = c0; c < c1; ++c) {
+      const A v = TT<T>::load(part[c * a.K + k]);
+      if (OP == OP_MAX) {
+        if (TT<T>::less(acc[0], v)) {  // strict <: the earliest chunk (smallest e) keeps ties
+          acc[0] = v;
+          arg[0] = a.partial_arg[c * a.K + k];
+        }
+      } else {
+        acc[0] = TT<T>::add(acc[0], v);
+      }
+    }
+    finish_row<T, 1, OP, MODE>(a, row, len, k, acc, arg);
+  }
+}
+
+// ---- host-side dispatch -------------------------------------------------------------------------
+static inline int pow2_ceil_log2(int64_t v) {
+  int l = 0;
+  while (((int64_t)1 << l) < v) ++l;
+  return l;
+}
+
+template <typename T, int VEC, int OP, int MODE>
+static int launch_typed(ReduceArgs a, hipStream_t stream) {
+  const int64_t kv = ceil_div(a.K, VEC);
+  a.logL = pow2_ceil_log2(kv < kWave ? kv : kWave);
+  if (a.logL > 6) a.logL = 6;
+  const bool uniform = (a.logL == 6) && std::is_same<T, float>::value;
+  const int rows_per_block = kWavesPerBlock * (kWave >> a.logL);
+  a.nblocks = ceil_div(a.N, rows_per_block);
+  a.swizzle = (int)options().xcd_swizzle;
+  GGL_REQUIRE(a.nblocks < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+  if (a.N > 0 && a.K > 0) {
+    if (uniform) {
+      if (options().unroll >= 8)
+        GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, true, 8>), a.nblocks, kBlock, stream, a);
+      else
+        GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, true, 4>), a.nblocks, kBlock, stream, a);
+    } else {
+      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, false, 4>), a.nblocks, kBlock, stream, a);
+    }
+    GGL_LAUNCH_CHECK();
+    if (a.n_long > 0) {
+      GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
+      GGL_LAUNCH((long_chunk_kernel<T, VEC, OP, MODE, 4>), ceil_div(a.n_chunks, kWavesPerBlock),
+                 kBlock, stream, a);
+      GGL_LAUNCH_CHECK();
+      GGL_LAUNCH((long_final_kernel<T, OP, MODE>), a.n_long, kBlock, stream, a);
+      GGL_LAUNCH_CHECK();
+    }
+  }
+  return GGL_OK;
+}
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int OP, int MODE>
+static int launch_f32(ReduceArgs a, hipStream_t stream) {
+  const bool vec4 = !options().force_generic && (a.K % 4 == 0) && aligned16(a.x) &&
+                    aligned16(a.out) && (!a.partial || aligned16(a.partial)) &&
+                    (MODE != MODE_BSPMM || a.C % 4 == 0);
+  if (vec4) return launch_typed<float, 4, OP, MODE>(a, stream);
+  return launch_typed<float, 1, OP, MODE>(a, stream);
+}
+
+template <int OP>
+static int launch_seg(int dtype, ReduceArgs a, hipStream_t stream) {
+  switch (dtype) {
+    case GGL_F32: return launch_f32<OP, MODE_SEG>(a, stream);
+    case GGL_F64: return launch_typed<double, 1, OP, MODE_SEG>(a, stream);
+    case GGL_F16: return launch_typed<f16_t, 1, OP, MODE_SEG>(a, stream);
+    case GGL_BF16: return launch_typed<bf16_t, 1, OP, MODE_SEG>(a, stream);
+    case GGL_U8: return launch_typed<uint8_t, 1, OP, MODE_SEG>(a, stream);
+    case GGL_I8: return launch_typed<int8_t, 1, OP, MODE_SEG>(a, stream);
+    case GGL_I16: return launch_typed<int16_t, 1, OP, MODE_SEG>(a, stream);
+    case GGL_I32: return launch_typed<int32_t, 1, OP, MODE_SEG>(a, stream);
+    case GGL_I64: return launch_typed<int64_t, 1, OP, MODE_SEG>(a, stream);
+    default: set_error("unsupported dtype code %d", dtype); return GGL_EDTYPE;
+  }
+}
+
+static int fill_plan(ReduceArgs &a, const ggl_segplan_t *plan, int dtype, int64_t K, bool with_arg) {
+  GGL_REQUIRE(plan != nullptr && plan->rowptr != nullptr, GGL_EINVAL, "plan / rowptr is NULL");
+  GGL_REQUIRE(plan->chunk > 0, GGL_EINVAL, "plan->chunk must be > 0");
+  GGL_REQUIRE(K >= 0 && plan->N >= 0 && plan->E >= 0, GGL_EINVAL, "negative size");
+  a.rowptr = plan->rowptr;
+  a.perm = plan->perm;
+  a.N = plan->N;
+  a.E = plan->E;
+  a.K = K;
+  a.chunk = plan->chunk;
+  a.long_rows = plan->long_rows;
+  a.chunk_ptr = plan->chunk_ptr;
+  a.n_long = plan->n_long;
+  a.n_chunks = plan->n_chunks;
+  a.partial = plan->partial;
+  a.partial_arg = nullptr;
+  if (plan->n_long > 0) {
+    GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
+                "plan has long rows but long_rows/chunk_ptr/partial is NULL");
+    if (with_arg) {
+      size_t off = (size_t)plan->n_chunks * (size_t)K * dtype_size(dtype);
+      off = (off + 15) & ~(size_t)15;
+      a.partial_arg = reinterpret_cast<int64_t *>(static_cast<char *>(plan->partial) + off);
+    }
+  }
+  return GGL_OK;
+}
+
+}  // namespace ggl
+
+using namespace ggl;
+
+extern "C" size_t ggl_partial_bytes(int dtype, int64_t n_chunks, int64_t K, int with_arg) {
+  if (n_chunks <= 0 || K <= 0) return 0;
+  size_t b = (size_t)n_chunks * (size_t)K * dtype_size(dtype);
+  b = (b + 15) & ~(size_t)15;
+  if (with_arg) b += (size_t)n_chunks * (size_t)K * 8;
+  return b;
+}
+
+// ---- segment ops ---------------------------------------------------------------------------------
+extern "C" int ggl_segment_sum(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K,
+                               void *out, void *stream) {
+  ReduceArgs a{};
+  int rc = fill_plan(a, plan, dtype, K, false);
+  if (rc) return rc;
+  GGL_REQUIRE((x || plan->E * K == 0) && (out || plan->N * K == 0), GGL_EINVAL, "x/out is NULL");
+  a.x = x;
+  a.out = out;
+  return launch_seg<OP_SUM>(dtype, a, as_stream(stream));
+}
+
+extern "C" int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K,
+                                void *out, void *stream) {
+  ReduceArgs a{};
+  int rc = fill_plan(a, plan, dtype, K, false);
+  if (rc) return rc;
+  GGL_REQUIRE((x || plan->E * K == 0) && (out || plan->N * K == 0), GGL_EINVAL, "x/out is NULL");
+  a.x = x;
+  a.out = out;
+  return launch_seg<OP_MEAN>(dtype, a, as_stream(stream));
+}
+
+extern "C" int ggl_segment_max(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K,
+                               void *out, int64_t *arg, int64_t arg_fill, void *stream) {
+  ReduceArgs a{};
+  int rc = fill_plan(a, plan, dtype, K, true);
+  if (rc) return rc;
+  GGL_REQUIRE((x || plan->E * K == 0) && ((out && arg) || plan->N * K == 0), GGL_EINVAL,
+              "x/out/arg is NULL");
+  a.x = x;
+  a.out = out;
+  a.arg = arg;
+  a.arg_fill = arg_fill;
+  if (plan->E * K == 0) {
+    // segment_max_cpu.cpp:28-30: an empty x returns zeros (the lowest() fill comes later), arg = fill
+    if (plan->N * K > 0) {
+      GGL_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)plan->N * K * dtype_size(dtype), as_stream(stream)));
+      return ggl_fill_i64(arg, plan->N * K, arg_fill, stream);
+    }
+    return GGL_OK;
+  }
+  return launch_seg<OP_MAX>(dtype, a, as_stream(stream));
+}
+
+// ---- gspmm ---------------------------------------------------------------------------------------
+static int spmm_common(ReduceArgs &a, const ggl_segplan_t *plan, const int32_t *col, const float *w,
+                       int w_by_pos, const float *x, int64_t K, float *out, bool with_arg) {
+  int rc = fill_plan(a, plan, GGL_F32, K, with_arg);
+  if (rc) return rc;
+  GGL_REQUIRE(col || plan->E == 0, GGL_EINVAL, "col is NULL");
+  GGL_REQUIRE((x || plan->E * K == 0) && (out || plan->N * K == 0), GGL_EINVAL, "x/out is NULL");
+  a.x = x;
+  a.col = col;
+  a.w = w;
+  a.w_by_pos = w_by_pos;
+  a.out = out;
+  return GGL_OK;
+}
+
+extern "C" int ggl_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w,
+                            int w_by_pos, const float *x, int64_t K, float *out, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
+  if (rc) return rc;
+  return launch_f32<OP_SUM, MODE_SPMM>(a, as_stream(stream));
+}
+
+extern "C" int ggl_spmm_mean(const ggl_segplan_t *plan, const int32_t *col, const float *w,
+                             int w_by_pos, const float *x, int64_t K, float *out, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
+  if (rc) return rc;
+  return launch_f32<OP_MEAN, MODE_SPMM>(a, as_stream(stream));
+}
+
+extern "C" int ggl_spmm_max(const ggl_segplan_t *plan, const int32_t *col, const float *w,
+                            int w_by_pos, const float *x, int64_t K, float *out, int64_t *argsrc,
+                            void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, true);
+  if (rc) return rc;
+  GGL_REQUIRE(argsrc || plan->N * K == 0, GGL_EINVAL, "argsrc is NULL");
+  a.arg = argsrc;
+  a.arg_fill = 0;  // spmm_max_cpu.cpp:20: max_indices = zeros
+  return launch_f32<OP_MAX, MODE_SPMM>(a, as_stream(stream));
+}
+
+extern "C" int ggl_spmm_mean_bwd(const ggl_segplan_t *planT, const int32_t *colT, const float *w,
+                                 int w_by_pos, const float *g, const int64_t *fwd_rowptr, int64_t K,
+                                 float *gx, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, planT, colT, w, w_by_pos, g, K, gx, false);
+  if (rc) return rc;
+  GGL_REQUIRE(fwd_rowptr != nullptr, GGL_EINVAL, "fwd_rowptr is NULL");
+  a.aux_rowptr = fwd_rowptr;
+  return launch_f32<OP_SUM, MODE_MEANBWD>(a, as_stream(stream));
+}
+
+extern "C" int ggl_spmm_max_bwd(const ggl_segplan_t *planT, const int32_t *colT, const float *w,
+                                int w_by_pos, const float *g, const int64_t *argsrc, int64_t K,
+                                float *gx, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, planT, colT, w, w_by_pos, g, K, gx, false);
+  if (rc) return rc;
+  GGL_REQUIRE(argsrc || planT->E * K == 0, GGL_EINVAL, "argsrc is NULL");
+  a.aux_arg = argsrc;
+  return launch_f32<OP_SUM, MODE_MAXBWD>(a, as_stream(stream));
+}
+
+// ---- bspmm ---------------------------------------------------------------------------------------
+extern "C" int ggl_bspmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w,
+                             int w_by_pos, const float *x, int64_t H, int64_t C, float *out,
+                             void *stream) {
+  ReduceArgs a{};
+  GGL_REQUIRE(H > 0 && C > 0, GGL_EINVAL, "H and C must be positive");
+  int rc = spmm_common(a, plan, col, w, w_by_pos, x, H * C, out, false);
+  if (rc) return rc;
+  a.H = H;
+  a.C = C;
+  return launch_f32<OP_SUM, MODE_BSPMM>(a, as_stream(stream));
+}
+
+// ---- timing aid for bench.py's roofline leg ------------------------------------------------------
+extern "C" int ggl_time_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w,
+                                 int w_by_pos, const float *x, int64_t K, float *out, void *stream,
+                                 int reps, float *ms_host) {
+#ifdef GGL_EMULATE
+  (void)plan; (void)col; (void)w; (void)w_by_pos; (void)x; (void)K; (void)out; (void)stream; (void)reps;
+  *ms_host = 0.0f;
+  return GGL_OK;
+#else
+  GGL_REQUIRE(reps > 0 && ms_host, GGL_EINVAL, "reps must be > 0");
+  hipStream_t s = as_stream(stream);
+  hipEvent_t e0, e1;
+  GGL_HIP_CHECK(hipEventCreate(&e0));
+  GGL_HIP_CHECK(hipEventCreate(&e1));
+  int rc = ggl_spmm_sum(plan, col, w, w_by_pos, x, K, out, stream);  // warm
+  if (rc) return rc;
+  GGL_HIP_CHECK(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; ++i) {
+    rc = ggl_spmm_sum(plan, col, w, w_by_pos, x, K, out, stream);
+    if (rc) return rc;
+  }
+  GGL_HIP_CHECK(hipEventRecord(e1, s));
+  GGL_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  GGL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_host = ms / (float)reps;
+  GGL_HIP_CHECK(hipEventDestroy(e0));
+  GGL_HIP_CHECK(hipEventDestroy(e1));
+  return GGL_OK;
+#endif
+}

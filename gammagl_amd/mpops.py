@@ -1,0 +1,100 @@
+"""Drop-in for ``gammagl/mpops/torch.py`` (the op surface ``from gammagl.mpops import *`` exposes).
+
+Same names, argument meaning and return types as the reference module
+(gammagl/mpops/torch.py:43,99,159,209,240,271,302,354), including the module globals ``use_ext``
+(read by MessagePassing.message_aggregate, layers/conv/message_passing.py:99) and ``torch`` (which
+leaks through the star-import and is used at message_passing.py:101).  Differences, on purpose:
+
+* the work runs in hand-written HIP kernels on MI355X (no CPU path; CPU tensors raise);
+* native errors are NOT swallowed: the reference's segment wrappers catch every exception and
+  silently re-run a pure-torch fallback (torch.py:83-86,139-142,199-202) that disagrees with the
+  C++ extension on empty max segments and integer dtypes; here an error is an error;
+* results follow the reference's C++ CPU extension (the implementation its own known-answer tests
+  pass on): empty max segments hold numeric_limits<T>::lowest(), integer mean truncates, ties go to
+  the first edge.
+"""
+import torch  # noqa: F401  (re-exported on purpose, see above)
+
+from . import engine as _engine
+
+use_ext = True
+
+__all__ = ["unsorted_segment_sum", "unsorted_segment_mean", "unsorted_segment_max", "segment_sum",
+           "segment_mean", "segment_max", "gspmm", "bspmm", "use_ext", "torch"]
+
+
+def _num_segments(segment_ids, num_segments):
+    if num_segments is None:  # torch.py:74-75 — the one host sync the reference API forces
+        num_segments = int(segment_ids.max().item()) + 1
+    return int(num_segments)
+
+
+def _ids(segment_ids, x):
+    # the reference extension wants int64 (segment_sum_cpu.cpp:36); its Python fallback casts
+    # anything else with .to(torch.long) (torch.py:11) — so the surface accepts any integer dtype
+    if segment_ids.dtype != torch.int64:
+        segment_ids = segment_ids.to(torch.int64)
+    if segment_ids.device != x.device:
+        segment_ids = segment_ids.to(x.device)
+    return segment_ids
+
+
+def unsorted_segment_sum(x, segment_ids, num_segments=None):
+    """out[s] = sum of x[e] over e with segment_ids[e] == s (torch.py:43-86)."""
+    assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
+    n = _num_segments(segment_ids, num_segments)
+    return _engine().c_segment_sum(x, _ids(segment_ids, x), n)
+
+
+def unsorted_segment_mean(x, segment_ids, num_segments=None):
+    """Mean along segments; empty segments give 0 (torch.py:99-142)."""
+    assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
+    n = _num_segments(segment_ids, num_segments)
+    return _engine().c_segment_mean(x, _ids(segment_ids, x), n)
+
+
+def unsorted_segment_max(x, segment_ids, num_segments=None):
+    """Max along segments (torch.py:159-202); empty segments hold lowest() as in the C++ extension."""
+    n = _num_segments(segment_ids, num_segments)
+    assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
+    return _engine().c_segment_max(x, _ids(segment_ids, x), n)
+
+
+def segment_max(x, segment_ids, num_segments=None):
+    return unsorted_segment_max(x, segment_ids, num_segments)  # torch.py:209-237
+
+
+def segment_mean(x, segment_ids, num_segments=None):
+    return unsorted_segment_mean(x, segment_ids, num_segments)  # torch.py:240-268
+
+
+def segment_sum(x, segment_ids, num_segments=None):
+    return unsorted_segment_sum(x, segment_ids, num_segments)  # torch.py:271-299
+
+
+def gspmm(index, weight=None, x=None, reduce='sum'):
+    """Generalized SpMM: out[dst] = reduce_e weight[e] * x[src] (torch.py:302-351)."""
+    eng = _engine()
+    if weight is None:
+        # torch.py:332-333 builds ones([E]) f32; w * x == x exactly, so the kernel skips the multiply
+        weight = None
+    if reduce == 'sum':
+        return eng.c_spmm_sum(index, weight, x)
+    elif reduce == 'mean':
+        return eng.c_spmm_mean(index, weight, x)
+    elif reduce == 'max':
+        return eng.c_spmm_max(index, weight, x)
+    else:
+        raise Exception("Unsupported reduce type, please choose from ['sum', 'mean', 'max'].")
+
+
+def bspmm(index, weight=None, x=None, reduce='sum'):
+    """Multi-head SpMM: out[dst,h,:] = sum_e weight[e,h] * x[src,h,:] (torch.py:354-365)."""
+    if weight is None:
+        # torch.py:355-356 builds a 1-D ones([E]) that the C++ kernel then indexes as [E,H] (an
+        # out-of-bounds read for H > 1); the only meaningful reading is "all heads weigh 1"
+        weight = torch.ones((index.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
+    if reduce == 'sum':
+        return _engine().c_bspmm_sum(index, weight, x)
+    else:
+        raise Exception("Unsupported reduce type, please choose from ['sum'].")

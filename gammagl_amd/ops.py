@@ -1,0 +1,595 @@
+"""Host side of the MI355X message-passing backend: plans, plan caches and autograd glue over the
+C ABI (include/ggl_mpops.h).
+
+This is the part of the reference that lives in ``gammagl/mpops/torch_ext/src/*.cpp`` — the seven
+``torch::autograd::Function``s and their device dispatch (src/segment_sum.cpp:35-54,
+src/segment_mean.cpp:36-63, src/segment_max.cpp:37-61, src/gspmm.cpp:26-260) — restated for a
+backend whose kernels work on a destination-sorted plan instead of atomics:
+
+* ``SegPlan``   : perm / rowptr / long-row lists for one id vector (built once, cached by the
+                  identity + version counter of the id tensor's storage; no per-call host sync).
+* ``GraphPlan`` : the pair of SegPlans (by destination, by source) for one ``edge_index`` plus the
+                  int32 column arrays — CSR for the forward SpMM, CSC for its backward.
+* ``Engine``    : the ops.  PyTorch is plumbing here (device memory, streams, autograd graph).
+
+``Engine`` takes the ctypes library as a constructor argument; the product singleton
+(``gammagl_amd.engine()``) is always built on the HIP library and refuses non-GPU tensors.
+"""
+import ctypes
+import math
+import os
+from collections import OrderedDict
+
+import torch
+from torch.multiprocessing.reductions import StorageWeakRef
+
+from . import _lib
+from ._lib import SegPlanC
+
+_DTYPE_CODE = {
+    torch.uint8: 0, torch.int8: 1, torch.int16: 2, torch.int32: 3, torch.int64: 4,
+    torch.float16: 5, torch.bfloat16: 6, torch.float32: 7, torch.float64: 8,
+}
+_FLOAT_DTYPES = (torch.float16, torch.bfloat16, torch.float32, torch.float64)
+
+DEFAULT_CHUNK = int(os.environ.get("GGL_LONG_ROW", "4096"))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class SegPlan:
+    """Destination-sorted view of one id vector (struct ggl_segplan + the tensors that own it)."""
+
+    __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
+                 "chunk_ptr", "n_long", "n_chunks", "device")
+
+    def c_struct(self, partial=None, perm_override=None):
+        perm = self.perm if perm_override is None else perm_override
+        return SegPlanC(
+            rowptr=self.rowptr.data_ptr(), perm=(perm.data_ptr() if perm is not None else None),
+            long_rows=(self.long_rows.data_ptr() if self.n_long else None),
+            chunk_ptr=(self.chunk_ptr.data_ptr() if self.n_long else None),
+            n_long=self.n_long, n_chunks=self.n_chunks, chunk=self.chunk,
+            partial=(partial.data_ptr() if partial is not None else None), N=self.N, E=self.E)
+
+    def counts(self):
+        return self.rowptr[1:] - self.rowptr[:-1]
+
+
+class GraphPlan:
+    """CSR (rows = destination) and, lazily, CSC (rows = source) plans of one edge_index."""
+
+    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT")
+
+    def __init__(self, engine, index, n_dst, n_src):
+        self.engine = engine
+        self.index = index
+        self.N_dst, self.N_src = int(n_dst), int(n_src)
+        self.E = int(index.shape[1])
+        self.fwd = engine.build_plan(index[1], self.N_dst)
+        engine._check_range(index[0], self.N_src)
+        self.col = engine.gather_i32(index[0], self.fwd.perm)
+        self._bwd = self._colT = self._posT = None
+
+    @property
+    def bwd(self):
+        if self._bwd is None:
+            self._bwd = self.engine.build_plan(self.index[0], self.N_src)
+            self._colT = self.engine.gather_i32(self.index[1], self._bwd.perm)
+        return self._bwd
+
+    @property
+    def colT(self):
+        self.bwd  # noqa: B018
+        return self._colT
+
+    @property
+    def posT(self):
+        """transposed sorted position -> forward sorted position (int32 [E])."""
+        if self._posT is None:
+            E, dev = self.E, self.index.device
+            ar = torch.arange(E, device=dev, dtype=torch.int32)
+            pf = self.fwd.perm if self.fwd.perm is not None else ar
+            pt = self.bwd.perm if self.bwd.perm is not None else ar
+            inv = torch.empty(E, device=dev, dtype=torch.int32)
+            inv[pf.long()] = ar
+            self._posT = inv[pt.long()].contiguous()
+        return self._posT
+
+
+class _PlanCache:
+    """LRU keyed on the identity of the id tensor's storage + its version counter."""
+
+    def __init__(self, cap=16):
+        self.cap = cap
+        self.d = OrderedDict()
+
+    @staticmethod
+    def key(t, extra):
+        st = t.untyped_storage()
+        return (st._cdata, t.storage_offset(), tuple(t.shape), tuple(t.stride()), t._version,
+                t.dtype, str(t.device)) + tuple(extra)
+
+    def get(self, t, extra):
+        k = self.key(t, extra)
+        hit = self.d.get(k)
+        if hit is not None:
+            ref, val = hit
+            if not ref.expired():
+                self.d.move_to_end(k)
+                return val
+            del self.d[k]
+        return None
+
+    def put(self, t, extra, val):
+        k = self.key(t, extra)
+        self.d[k] = (StorageWeakRef(t.untyped_storage()), val)
+        while len(self.d) > self.cap:
+            self.d.popitem(last=False)
+
+    def clear(self):
+        self.d.clear()
+
+
+class Engine:
+    def __init__(self, lib, require_cuda=True):
+        self.lib = lib
+        self.require_cuda = require_cuda
+        self.seg_cache = _PlanCache()
+        self.graph_cache = _PlanCache()
+        self.stats = {"plans_built": 0, "plan_hits": 0}
+        self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk
+        self._make_functions()
+
+    # ---- plumbing ----------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc == _lib.GGL_OK:
+            return
+        msg = (self.lib.ggl_last_error() or b"").decode("utf-8", "replace")
+        if rc == _lib.GGL_EINDEX:
+            raise IndexError(msg)
+        raise RuntimeError(f"ggl_mpops error {rc}: {msg}")
+
+    def _dev(self, *tensors):
+        dev = None
+        for t in tensors:
+            if t is None:
+                continue
+            if self.require_cuda and not t.is_cuda:
+                raise RuntimeError(
+                    "gammagl_amd runs on MI355X only: got a tensor on %s (there is no CPU path; "
+                    "move the tensors to 'cuda')" % t.device)
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise RuntimeError("Tensor device inconsistent error.")  # segment_sum.cpp:31
+        return dev
+
+    @staticmethod
+    def _stream(dev):
+        if dev is not None and dev.type == "cuda":
+            return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        return None
+
+    @staticmethod
+    def _code(t):
+        try:
+            return _DTYPE_CODE[t.dtype]
+        except KeyError:
+            raise RuntimeError(f"unsupported dtype {t.dtype}") from None
+
+    # ---- plans -------------------------------------------------------------------------------
+    def _check_range(self, ids, n):
+        if ids.numel() == 0:
+            return
+        # one-off (per plan) validation of the gathered side of an edge list
+        lo, hi = torch.aminmax(ids)
+        if int(lo) < 0 or int(hi) >= n:
+            raise IndexError(f"node id out of range [0, {n})")
+
+    def build_plan(self, ids, N, chunk=None):
+        """Sort `ids` (int64 [E]) into a SegPlan.  Synchronous; run once per edge list."""
+        dev = self._dev(ids)
+        ids = ids.contiguous()
+        if ids.dtype != torch.int64:
+            ids = ids.to(torch.int64)
+        E, N = int(ids.shape[0]), int(N)
+        chunk = int(chunk or self.chunk)
+        st = self._stream(dev)
+        p = SegPlan()
+        p.N, p.E, p.chunk, p.device = N, E, chunk, dev
+        p.rowptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        wsb = self.lib.ggl_plan_workspace_bytes(E, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        is_sorted, max_len = ctypes.c_int32(0), ctypes.c_int64(0)
+        self._check(self.lib.ggl_plan_build(_ptr(ids), E, N, _ptr(perm), _ptr(p.rowptr), _ptr(ws),
+                                            wsb, st, ctypes.byref(is_sorted), ctypes.byref(max_len)))
+        p.is_sorted, p.max_len = bool(is_sorted.value), int(max_len.value)
+        p.perm = None if p.is_sorted else perm[:E]
+        p.n_long = p.n_chunks = 0
+        p.long_rows = p.chunk_ptr = None
+        if p.max_len > chunk:
+            lwb = self.lib.ggl_plan_long_workspace_bytes(N)
+            lws = torch.empty(lwb, dtype=torch.uint8, device=dev)
+            nl, nc = ctypes.c_int64(0), ctypes.c_int64(0)
+            self._check(self.lib.ggl_plan_long_count(_ptr(p.rowptr), N, chunk, _ptr(lws), lwb, st,
+                                                     ctypes.byref(nl), ctypes.byref(nc)))
+            p.n_long, p.n_chunks = int(nl.value), int(nc.value)
+            p.long_rows = torch.empty(p.n_long, dtype=torch.int32, device=dev)
+            p.chunk_ptr = torch.empty(p.n_long + 1, dtype=torch.int64, device=dev)
+            self._check(self.lib.ggl_plan_long_fill(_ptr(p.rowptr), N, chunk, p.n_long,
+                                                    _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws),
+                                                    lwb, st))
+        self.stats["plans_built"] += 1
+        return p
+
+    def seg_plan(self, ids, N):
+        plan = self.seg_cache.get(ids, (int(N), self.chunk))
+        if plan is None:
+            plan = self.build_plan(ids, N)
+            self.seg_cache.put(ids, (int(N), self.chunk), plan)
+        else:
+            self.stats["plan_hits"] += 1
+        return plan
+
+    def graph_plan(self, index, n_dst, n_src=None):
+        n_src = n_dst if n_src is None else n_src
+        gp = self.graph_cache.get(index, (int(n_dst), int(n_src), self.chunk))
+        if gp is None:
+            self._dev(index)
+            if index.dim() != 2 or index.shape[0] != 2:
+                raise RuntimeError("index must have shape [2, num_edges]")
+            idx = index if index.dtype == torch.int64 else index.to(torch.int64)
+            gp = GraphPlan(self, idx.contiguous(), n_dst, n_src)
+            self.graph_cache.put(index, (int(n_dst), int(n_src), self.chunk), gp)
+        else:
+            self.stats["plan_hits"] += 1
+        return gp
+
+    def gather_i32(self, src_i64, perm):
+        dev = src_i64.device
+        src_i64 = src_i64.contiguous()
+        E = int(src_i64.shape[0])
+        out = torch.empty(E, dtype=torch.int32, device=dev)
+        self._check(self.lib.ggl_gather_i64_to_i32(_ptr(src_i64), _ptr(perm), E, _ptr(out),
+                                                   self._stream(dev)))
+        return out
+
+    def _partial(self, plan, dtype, K, with_arg, dev):
+        if plan.n_long == 0:
+            return None
+        nb = self.lib.ggl_partial_bytes(_DTYPE_CODE[dtype], plan.n_chunks, K, 1 if with_arg else 0)
+        return torch.empty(nb + 16, dtype=torch.uint8, device=dev)
+
+    # ---- raw (non-autograd) forward launches -------------------------------------------------
+    def _segment_fwd(self, op, x, plan):
+        dev = x.device
+        E = int(x.shape[0])
+        if E != plan.E:
+            raise IndexError("fisrt dimension of x and index should be same")  # segment_sum_cpu.cpp:17-19
+        K = x.numel() // E if E > 0 else int(math.prod(x.shape[1:]))
+        out = torch.empty((plan.N,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
+        st = self._stream(dev)
+        code = self._code(x)
+        part = self._partial(plan, x.dtype, K, op == "max", dev)
+        cs = plan.c_struct(part)
+        if op == "sum":
+            self._check(self.lib.ggl_segment_sum(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
+            return out, None
+        if op == "mean":
+            self._check(self.lib.ggl_segment_mean(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
+            return out, None
+        arg = torch.empty((plan.N,) + tuple(x.shape[1:]), dtype=torch.int64, device=dev)
+        self._check(self.lib.ggl_segment_max(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), _ptr(arg),
+                                             E, st))
+        return out, arg
+
+    def _spmm_fwd(self, op, plan, col, w, x, n_out, perm_override=None, aux=None):
+        """op in sum/mean/max/mean_bwd/max_bwd.  x [N_in, *]; returns out [n_out, *] (+argsrc)."""
+        dev = x.device
+        K = int(math.prod(x.shape[1:]))
+        out = torch.empty((n_out,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
+        st = self._stream(dev)
+        part = self._partial(plan, torch.float32, K, op == "max", dev)
+        cs = plan.c_struct(part, perm_override)
+        w_by_pos = 0
+        L = self.lib
+        if op == "sum":
+            self._check(L.ggl_spmm_sum(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), K,
+                                       _ptr(out), st))
+        elif op == "mean":
+            self._check(L.ggl_spmm_mean(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), K,
+                                        _ptr(out), st))
+        elif op == "max":
+            arg = torch.empty(out.shape, dtype=torch.int64, device=dev)
+            self._check(L.ggl_spmm_max(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), K,
+                                       _ptr(out), _ptr(arg), st))
+            return out, arg
+        elif op == "mean_bwd":
+            self._check(L.ggl_spmm_mean_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
+                                            _ptr(aux), K, _ptr(out), st))
+        elif op == "max_bwd":
+            self._check(L.ggl_spmm_max_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
+                                           _ptr(aux), K, _ptr(out), st))
+        else:
+            raise ValueError(op)
+        return out, None
+
+    def _bspmm_fwd(self, plan, col, w, x, n_out, perm_override=None):
+        dev = x.device
+        H, C = int(x.shape[1]), int(x.shape[2])
+        out = torch.empty((n_out, H, C), dtype=torch.float32, device=dev)
+        part = self._partial(plan, torch.float32, H * C, False, dev)
+        cs = plan.c_struct(part, perm_override)
+        self._check(self.lib.ggl_bspmm_sum(ctypes.byref(cs), _ptr(col), _ptr(w), 0, _ptr(x), H, C,
+                                           _ptr(out), self._stream(dev)))
+        return out
+
+    @staticmethod
+    def _check_f32(name, t):
+        if t.dtype != torch.float32:
+            # spmm_sum_cpu.cpp:22 data_ptr<float>() on a non-float tensor
+            raise RuntimeError(f"expected scalar type Float but found {t.dtype} for {name}")
+
+    # ---- autograd Functions (closures over this engine) ---------------------------------------
+    def _make_functions(self):
+        eng = self
+
+        class SegmentSum(torch.autograd.Function):  # src/segment_sum.cpp:35-54
+            @staticmethod
+            def forward(ctx, x, ids, N):
+                plan = eng.seg_plan(ids, N)
+                out, _ = eng._segment_fwd("sum", x, plan)
+                ctx.save_for_backward(ids)
+                ctx.x_shape = x.shape
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                (ids,) = ctx.saved_tensors
+                g = g.contiguous()
+                E = ctx.x_shape[0]
+                K = int(math.prod(ctx.x_shape[1:]))
+                gin = torch.empty(ctx.x_shape, dtype=g.dtype, device=g.device)
+                eng._check(eng.lib.ggl_segment_sum_bwd(eng._code(g), _ptr(g), _ptr(ids), E, K,
+                                                       _ptr(gin), eng._stream(g.device)))
+                return gin, None, None
+
+        class SegmentMean(torch.autograd.Function):  # src/segment_mean.cpp:36-63
+            @staticmethod
+            def forward(ctx, x, ids, N):
+                plan = eng.seg_plan(ids, N)
+                out, _ = eng._segment_fwd("mean", x, plan)
+                ctx.save_for_backward(ids, plan.rowptr)
+                ctx.x_shape = x.shape
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                ids, rowptr = ctx.saved_tensors
+                g = g.contiguous()
+                if g.dtype not in _FLOAT_DTYPES:
+                    raise RuntimeError("segment_mean backward needs a floating dtype")
+                E = ctx.x_shape[0]
+                K = int(math.prod(ctx.x_shape[1:]))
+                gin = torch.empty(ctx.x_shape, dtype=g.dtype, device=g.device)
+                eng._check(eng.lib.ggl_segment_mean_bwd(eng._code(g), _ptr(g), _ptr(ids), _ptr(rowptr),
+                                                        E, K, _ptr(gin), eng._stream(g.device)))
+                return gin, None, None
+
+        class SegmentMax(torch.autograd.Function):  # src/segment_max.cpp:37-61
+            @staticmethod
+            def forward(ctx, x, ids, N):
+                plan = eng.seg_plan(ids, N)
+                out, arg = eng._segment_fwd("max", x, plan)
+                ctx.save_for_backward(arg)
+                ctx.x_shape = x.shape
+                ctx.mark_non_differentiable(arg)
+                return out, arg
+
+            @staticmethod
+            def backward(ctx, g, _garg):
+                (arg,) = ctx.saved_tensors
+                g = g.contiguous()
+                E = ctx.x_shape[0]
+                K = int(math.prod(ctx.x_shape[1:]))
+                gin = torch.empty(ctx.x_shape, dtype=g.dtype, device=g.device)
+                eng._check(eng.lib.ggl_segment_max_bwd(eng._code(g), _ptr(g), _ptr(arg), E,
+                                                       int(arg.shape[0]), K, _ptr(gin),
+                                                       eng._stream(g.device)))
+                return gin, None, None
+
+        class SpMMSum(torch.autograd.Function):  # src/gspmm.cpp:26-80
+            @staticmethod
+            def forward(ctx, gp, w, x):
+                out, _ = eng._spmm_fwd("sum", gp.fwd, gp.col, w, x, gp.N_dst)
+                ctx.gp, ctx.w = gp, w
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                gp = ctx.gp
+                gx, _ = eng._spmm_fwd("sum", gp.bwd, gp.colT, ctx.w, g.contiguous(), gp.N_src)
+                return None, None, gx  # weight is non-differentiable in the reference (gspmm.cpp:30)
+
+        class SpMMMean(torch.autograd.Function):  # src/gspmm.cpp:82-141
+            @staticmethod
+            def forward(ctx, gp, w, x):
+                out, _ = eng._spmm_fwd("mean", gp.fwd, gp.col, w, x, gp.N_dst)
+                ctx.gp, ctx.w = gp, w
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                gp = ctx.gp
+                gx, _ = eng._spmm_fwd("mean_bwd", gp.bwd, gp.colT, ctx.w, g.contiguous(), gp.N_src,
+                                      aux=gp.fwd.rowptr)
+                return None, None, gx
+
+        class SpMMMax(torch.autograd.Function):  # src/gspmm.cpp:143-202
+            @staticmethod
+            def forward(ctx, gp, w, x):
+                out, arg = eng._spmm_fwd("max", gp.fwd, gp.col, w, x, gp.N_dst)
+                ctx.gp, ctx.w = gp, w
+                ctx.save_for_backward(arg)
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                gp = ctx.gp
+                (arg,) = ctx.saved_tensors
+                gx, _ = eng._spmm_fwd("max_bwd", gp.bwd, gp.colT, ctx.w, g.contiguous(), gp.N_src,
+                                      aux=arg)
+                return None, None, gx
+
+        class BSpMMSum(torch.autograd.Function):  # src/gspmm.cpp:204-260
+            @staticmethod
+            def forward(ctx, gp, w, x):
+                out = eng._bspmm_fwd(gp.fwd, gp.col, w, x, gp.N_dst)
+                ctx.gp = gp
+                ctx.save_for_backward(w, x)
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                gp = ctx.gp
+                w, x = ctx.saved_tensors
+                g = g.contiguous()
+                gx = eng._bspmm_fwd(gp.bwd, gp.colT, w, g, gp.N_src)
+                H, C = int(x.shape[1]), int(x.shape[2])
+                gw = torch.empty_like(w)
+                eng._check(eng.lib.ggl_bspmm_grad_w(_ptr(gp.index), _ptr(x), _ptr(g), gp.E, H, C,
+                                                    _ptr(gw), eng._stream(g.device)))
+                # the reference returns grad_weight although it marked weight non-differentiable
+                # (gspmm.cpp:208,259): w.grad is populated there, and here.
+                return None, gw, gx
+
+        class GATFused(torch.autograd.Function):
+            """edge-softmax + aggregate in one kernel (gat_conv.py:103-112 + softmax.py:29-35)."""
+
+            @staticmethod
+            def forward(ctx, gp, el, er, x, slope):
+                dev = x.device
+                N, H, C = gp.N_dst, int(x.shape[1]), int(x.shape[2])
+                out = torch.empty((N, H, C), dtype=torch.float32, device=dev)
+                rmax = torch.empty((N, H), dtype=torch.float32, device=dev)
+                rden = torch.empty((N, H), dtype=torch.float32, device=dev)
+                cs = gp.fwd.c_struct(None)
+                eng._check(eng.lib.ggl_gat_fused_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er),
+                                                     _ptr(x), float(slope), H, C, _ptr(out),
+                                                     _ptr(rmax), _ptr(rden), eng._stream(dev)))
+                ctx.gp, ctx.slope = gp, float(slope)
+                ctx.save_for_backward(el, er, x, out, rmax, rden)
+                return out
+
+            @staticmethod
+            def backward(ctx, g):
+                gp = ctx.gp
+                el, er, x, out, rmax, rden = ctx.saved_tensors
+                g = g.contiguous()
+                dev = g.device
+                H, C = int(x.shape[1]), int(x.shape[2])
+                st = eng._stream(dev)
+                alpha = torch.empty((gp.E, H), dtype=torch.float32, device=dev)
+                de = torch.empty((gp.E, H), dtype=torch.float32, device=dev)
+                ger = torch.empty_like(er)
+                cs = gp.fwd.c_struct(None)
+                eng._check(eng.lib.ggl_gat_fused_bwd_dst(
+                    ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er), _ptr(x), _ptr(g), _ptr(out),
+                    _ptr(rmax), _ptr(rden), ctx.slope, H, C, _ptr(alpha), _ptr(de), _ptr(ger), st))
+                bwd = gp.bwd
+                gx = torch.empty((gp.N_src, H, C), dtype=torch.float32, device=dev)
+                gel = torch.empty((gp.N_src, H), dtype=torch.float32, device=dev)
+                part = eng._partial(bwd, torch.float32, H * C, False, dev)
+                csT = bwd.c_struct(part)
+                eng._check(eng.lib.ggl_gat_fused_bwd_src(ctypes.byref(csT), _ptr(gp.colT), _ptr(gp.posT),
+                                                         _ptr(alpha), _ptr(de), _ptr(g), H, C,
+                                                         _ptr(gx), _ptr(gel), st))
+                return None, gel, ger, gx, None
+
+        self.SegmentSum, self.SegmentMean, self.SegmentMax = SegmentSum, SegmentMean, SegmentMax
+        self.SpMMSum, self.SpMMMean, self.SpMMMax = SpMMSum, SpMMMean, SpMMMax
+        self.BSpMMSum, self.GATFused = BSpMMSum, GATFused
+
+    # ---- the seven reference entry points (src/operators.cpp:51-59) + the fused GAT op ---------
+    def _seg_args(self, x, index, N):
+        self._dev(x, index)
+        if index.dim() != 1:
+            raise IndexError(f"index dimension should be 1, but got {index.dim()}")
+        if x.shape[0] != index.shape[0]:
+            raise IndexError("fisrt dimension of x and index should be same")
+        if index.dtype != torch.int64:
+            raise RuntimeError(f"expected scalar type Long but found {index.dtype}")
+        return x.contiguous(), index, int(N)
+
+    def c_segment_sum(self, x, index, N):
+        return self.SegmentSum.apply(*self._seg_args(x, index, N))
+
+    def c_segment_mean(self, x, index, N):
+        return self.SegmentMean.apply(*self._seg_args(x, index, N))
+
+    def c_segment_max(self, x, index, N):
+        return self.SegmentMax.apply(*self._seg_args(x, index, N))[0]
+
+    def segment_max_with_arg(self, x, index, N):
+        return self.SegmentMax.apply(*self._seg_args(x, index, N))
+
+    def _spmm_args(self, index, weight, x):
+        self._dev(index, weight, x)
+        self._check_f32("x", x)
+        if weight is not None:
+            self._check_f32("weight", weight)
+            weight = weight.contiguous()
+        gp = self.graph_plan(index, x.shape[0])
+        return gp, weight, x.contiguous()
+
+    def c_spmm_sum(self, index, weight, x):
+        return self.SpMMSum.apply(*self._spmm_args(index, weight, x))
+
+    def c_spmm_mean(self, index, weight, x):
+        return self.SpMMMean.apply(*self._spmm_args(index, weight, x))
+
+    def c_spmm_max(self, index, weight, x):
+        return self.SpMMMax.apply(*self._spmm_args(index, weight, x))
+
+    def c_bspmm_sum(self, index, weight, x):
+        if x.dim() != 3:
+            raise RuntimeError("bspmm expects x of shape [num_nodes, heads, channels]")
+        gp, weight, x = self._spmm_args(index, weight, x)
+        if weight is None or weight.dim() != 2 or weight.shape[1] != x.shape[1]:
+            raise RuntimeError("bspmm expects weight of shape [num_edges, heads]")
+        return self.BSpMMSum.apply(gp, weight, x)
+
+    def gat_fused(self, index, el, er, x, negative_slope=0.2, num_nodes=None):
+        """out[i,h,:] = sum_{j->i} softmax_i(LeakyReLU(el[j,h] + er[i,h])) * x[j,h,:]."""
+        self._dev(index, el, er, x)
+        for n, t in (("el", el), ("er", er), ("x", x)):
+            self._check_f32(n, t)
+        n = x.shape[0] if num_nodes is None else num_nodes
+        gp = index if isinstance(index, GraphPlan) else self.graph_plan(index, n, x.shape[0])
+        return self.GATFused.apply(gp, el.contiguous(), er.contiguous(), x.contiguous(),
+                                   negative_slope)
+
+    # rectangular / explicit-plan variants used by the harness and the multi-GPU layer
+    def spmm(self, gp, weight, x, reduce="sum"):
+        fn = {"sum": self.SpMMSum, "mean": self.SpMMMean, "max": self.SpMMMax}[reduce]
+        return fn.apply(gp, weight, x.contiguous())
+
+    def set_option(self, name, value):
+        self._check(self.lib.ggl_set_option(name.encode(), int(value)))
+
+    def time_spmm_sum(self, gp, weight, x, reps=10):
+        """Average ms per launch of the dominant SpMM-sum kernel (hipEvents on the current stream)."""
+        dev = x.device
+        K = int(math.prod(x.shape[1:]))
+        out = torch.empty((gp.N_dst,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
+        part = self._partial(gp.fwd, torch.float32, K, False, dev)
+        cs = gp.fwd.c_struct(part)
+        ms = ctypes.c_float(0.0)
+        self._check(self.lib.ggl_time_spmm_sum(ctypes.byref(cs), _ptr(gp.col), _ptr(weight), 0, _ptr(x),
+                                               K, _ptr(out), self._stream(dev), int(reps),
+                                               ctypes.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,233 @@
+/*
+ * include/ggl_mpops.h — C ABI of libggl_mpops_hip.so: the MI355X (gfx950) message-passing backend
+ * that replaces GammaGL's gammagl/mpops/torch_ext (`_torch_ext`) for the torch backend.
+ *
+ * Boundary.  The reference binds its native ops to Python through a pybind11 module with seven
+ * free functions (gammagl/mpops/torch_ext/src/operators.cpp:51-59):
+ *     c_segment_sum / c_segment_mean / c_segment_max (Tensor x, Tensor index, int64 N) -> Tensor
+ *     c_spmm_sum / c_spmm_mean / c_spmm_max / c_bspmm_sum (Tensor index, Tensor weight, Tensor x)
+ * each a torch::autograd::Function (include/<op>.h, src/<op>.cpp) that dispatches to a CPU loop
+ * (cpu/<op>_cpu.cpp) or an atomic CUDA kernel (cuda/<op>_cuda.cu).  This header is what an FFI for that path
+ * binds instead: plain device pointers, sizes and a HIP stream — no torch types.  Every entry
+ * point cites the reference function it supersedes.  The ctypes stub a GammaGL maintainer would
+ * add is in INTEGRATION.md; gammagl_amd/mpops.py is that stub, complete.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers on the current HIP device unless named *_host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every compute entry
+ *     point is asynchronous and stream-ordered and performs NO host synchronisation; the
+ *     ggl_plan_* entry points are synchronous (they return host-side facts about the graph) and are
+ *     meant to run once per edge list, not once per step.
+ *   - Return value: GGL_OK or a negative GGL_E* code; ggl_last_error() gives a message.
+ *   - Feature rows are contiguous, row-major: x[e*K + k].  K = product of trailing dims
+ *     (segment_sum_cpu.cpp:44: K = x.numel() / x.size(0)).
+ *   - No atomics anywhere on the reduction path: every output row is produced by exactly one
+ *     wavefront group that walks the row's edges in ascending ORIGINAL edge order, which makes the
+ *     results run-to-run deterministic and, for rows shorter than the long-row threshold,
+ *     bit-identical to the reference's serial CPU loops (same order of the same rounded adds).
+ */
+#ifndef GGL_MPOPS_H
+#define GGL_MPOPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGL_ABI_VERSION 1
+
+/* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
+enum {
+  GGL_U8 = 0, GGL_I8 = 1, GGL_I16 = 2, GGL_I32 = 3, GGL_I64 = 4,
+  GGL_F16 = 5, GGL_BF16 = 6, GGL_F32 = 7, GGL_F64 = 8
+};
+
+enum {
+  GGL_OK = 0,
+  GGL_EINVAL = -1,   /* bad argument (TORCH_CHECK in the reference -> RuntimeError) */
+  GGL_EINDEX = -2,   /* id out of range (TORCH_CHECK_INDEX -> IndexError, segment_max_cpu.cpp:50) */
+  GGL_EDTYPE = -3,   /* unsupported dtype ("expected scalar type Float", spmm_sum_cpu.cpp:22) */
+  GGL_EHIP = -4,     /* HIP runtime error */
+  GGL_EWORKSPACE = -5 /* workspace too small */
+};
+
+int ggl_abi_version(void);
+const char *ggl_last_error(void);          /* thread-local message of the last failing call */
+/* compute-unit count, wavefront size and gfx arch string of the current device (host query) */
+int ggl_device_info(int *cus_host, int *wave_host, char *arch_host, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segment plan: a destination-sorted (CSR-like) view of an unsorted id vector.
+ * The reference walks `index[e]` for e = 0..E-1 and scatters (segment_sum_cpu.cpp:47-56;
+ * CUDA: one atomicAdd per (e,k), segment_sum_cuda.cu:19-31).  Here the ids are stably sorted once
+ * per edge list (rocPRIM LSD radix sort on (id, e) pairs), giving
+ *   perm[p]   : original element index of the p-th element in sorted order (ascending e inside
+ *               a segment), or no perm at all when the ids already arrive sorted;
+ *   rowptr[s] : first sorted position of segment s (int64, N+1 entries).
+ * Rows longer than `chunk` are listed in long_rows and are reduced chunk-by-chunk into a partial
+ * buffer and then combined in chunk order (still deterministic).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ggl_segplan {
+  const int64_t *rowptr;    /* [N+1] */
+  const int32_t *perm;      /* [E] or NULL when the ids were already sorted */
+  const int32_t *long_rows; /* [n_long] row ids with more than `chunk` elements, or NULL */
+  const int64_t *chunk_ptr; /* [n_long+1] exclusive prefix of per-long-row chunk counts, or NULL */
+  int64_t n_long;
+  int64_t n_chunks;         /* chunk_ptr[n_long] */
+  int64_t chunk;            /* elements per chunk == long-row threshold (> 0) */
+  void *partial;            /* workspace: ggl_partial_bytes(...) bytes, or NULL when n_long == 0 */
+  int64_t N;                /* number of segments (output rows) */
+  int64_t E;                /* number of elements (edges) */
+} ggl_segplan_t;
+
+/* bytes of workspace ggl_plan_build needs */
+size_t ggl_plan_workspace_bytes(int64_t E, int64_t N);
+
+/* Build perm/rowptr from ids[E] (int64 on device, the reference's index dtype:
+ * segment_sum_cpu.cpp:36 data_ptr<int64_t>).  SYNCHRONOUS.  perm may be written even when the
+ * input turns out sorted (then *is_sorted_host = 1 and the caller may drop it).
+ * Errors: GGL_EINDEX if any id < 0 or >= N (the reference: IndexError for max,
+ * segment_max_cpu.cpp:50; silent out-of-bounds write for sum/mean). */
+int ggl_plan_build(const int64_t *ids, int64_t E, int64_t N, int32_t *perm, int64_t *rowptr,
+                   void *workspace, size_t workspace_bytes, void *stream, int32_t *is_sorted_host,
+                   int64_t *max_len_host);
+
+/* Long-row bookkeeping (SYNCHRONOUS): count, then fill long_rows[n_long] (ascending row id) and
+ * chunk_ptr[n_long+1].  Both need ggl_plan_long_workspace_bytes(N) bytes of scratch. */
+size_t ggl_plan_long_workspace_bytes(int64_t N);
+int ggl_plan_long_count(const int64_t *rowptr, int64_t N, int64_t chunk, void *workspace,
+                        size_t workspace_bytes, void *stream, int64_t *n_long_host,
+                        int64_t *n_chunks_host);
+int ggl_plan_long_fill(const int64_t *rowptr, int64_t N, int64_t chunk, int64_t n_long,
+                       int32_t *long_rows, int64_t *chunk_ptr, void *workspace,
+                       size_t workspace_bytes, void *stream);
+/* bytes of `partial` for n_chunks chunks of K features of dtype (value + int64 arg for max) */
+size_t ggl_partial_bytes(int dtype, int64_t n_chunks, int64_t K, int with_arg);
+
+/* p[0..n) = v */
+int ggl_fill_i64(int64_t *p, int64_t n, int64_t v, void *stream);
+
+/* out_i32[p] = (int32) src_i64[perm ? perm[p] : p]   — e.g. the CSR column array from edge_index[0] */
+int ggl_gather_i64_to_i32(const int64_t *src, const int32_t *perm, int64_t E, int32_t *out,
+                          void *stream);
+/* out[p, :] = src[perm[p], :] for rows of H floats (edge weights into sorted order) */
+int ggl_gather_rows_f32(const float *src, const int32_t *perm, int64_t E, int64_t H, float *out,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Segment reductions — supersede segment_{sum,mean,max}_{cpu,cuda}_forward
+ * (cpu/segment_sum_cpu.cpp:11-60, cpu/segment_mean_cpu.cpp:11-80, cpu/segment_max_cpu.cpp:11-69;
+ *  cuda/segment_sum_cuda.cu:33-116, cuda/segment_mean_cuda.cu, cuda/segment_max_cuda.cu).
+ * x [E,K] of `dtype`, out [N,K] (every element written).  Semantics are those of the CPU
+ * extension: accumulate in the storage dtype; mean = sum / count with count held in the storage
+ * dtype and applied only where count > 1 (integer dtypes: truncating division); max pre-fills
+ * with numeric_limits<T>::lowest(), strict `<` so the smallest e wins ties and NaN never wins;
+ * if E*K == 0 max returns zeros.  arg [N,K] int64 = winning element index, `arg_fill` for empty
+ * segments (the caller passes E; the reference's N aliases real rows — see DESIGN.md).
+ * ---------------------------------------------------------------------------------------------- */
+int ggl_segment_sum(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,
+                    void *stream);
+int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,
+                     void *stream);
+int ggl_segment_max(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,
+                    int64_t *arg, int64_t arg_fill, void *stream);
+
+/* Backward passes — supersede SegmentSum/Mean/Max::backward (src/segment_sum.cpp:43-54,
+ * src/segment_mean.cpp:44-63, src/segment_max.cpp:48-61).  f16/bf16/f32/f64 gradients.
+ *   sum : gin[e,:]  = gout[ids[e],:]
+ *   mean: gin[e,:]  = gout[ids[e],:] / count[ids[e]]       (count from rowptr)
+ *   max : gin = 0;  gin[arg[s,k],k] = gout[s,k] for arg < E (empty segments contribute nothing) */
+int ggl_segment_sum_bwd(int dtype, const void *gout, const int64_t *ids, int64_t E, int64_t K,
+                        void *gin, void *stream);
+int ggl_segment_mean_bwd(int dtype, const void *gout, const int64_t *ids, const int64_t *rowptr,
+                         int64_t E, int64_t K, void *gin, void *stream);
+int ggl_segment_max_bwd(int dtype, const void *gout, const int64_t *arg, int64_t E, int64_t N,
+                        int64_t K, void *gin, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * gspmm — CSR x dense SpMM, f32; supersedes spmm_{sum,mean,max}_cpu_{forward,backward}
+ * (cpu/spmm_sum_cpu.cpp:5-80, cpu/spmm_mean_cpu.cpp:5-105, cpu/spmm_max_cpu.cpp:5-99) and
+ * spmm_sum_cuda_{forward,backward} (cuda/spmm_sum_cuda.cu:15-87).
+ * plan  : rows = destination nodes (N_out = plan->N), sorted positions p = rowptr[i]..rowptr[i+1]
+ * col   : [E] int32, source node of sorted position p
+ * w     : [E] f32 edge weights or NULL (= all ones).  w_by_pos != 0: indexed by sorted position p;
+ *         w_by_pos == 0: indexed by original edge id (through plan->perm when present).
+ * x     : [N_in, K] f32;  out : [N_out, K] f32
+ *   sum : out[i,:] = sum_p  w[p] * x[col[p],:]          (rounded multiply, then rounded add)
+ *   mean: sum / (number of edges into i), only where that count > 0   (spmm_mean_cpu.cpp:51-58)
+ *   max : out pre-filled with -FLT_MAX; arg [N_out,K] int64 = SOURCE NODE id of the winner
+ *         (spmm_max_cpu.cpp:47), 0 where the row is empty.
+ * The backward of `sum` w.r.t. x is the same call on the transposed plan (rows = source nodes,
+ * col = destination nodes), which is exactly spmm_sum_cpu_backward's gx[src] += w[e] * g[dst].
+ * ---------------------------------------------------------------------------------------------- */
+int ggl_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                 const float *x, int64_t K, float *out, void *stream);
+int ggl_spmm_mean(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                  const float *x, int64_t K, float *out, void *stream);
+int ggl_spmm_max(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                 const float *x, int64_t K, float *out, int64_t *argsrc, void *stream);
+/* planT: rows = source nodes; colT[p] = destination node; fwd_rowptr = forward plan's rowptr
+ *   mean bwd: gx[j,:] = sum_p (g[colT[p],:] / count[colT[p]]) * w[p]     (spmm_mean_cpu.cpp:95-101)
+ *   max  bwd: gx[j,k] = sum_p [argsrc[colT[p],k] == j] w[p] * g[colT[p],k] (spmm_max_cpu.cpp:88-93) */
+int ggl_spmm_mean_bwd(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
+                      const float *g, const int64_t *fwd_rowptr, int64_t K, float *gx,
+                      void *stream);
+int ggl_spmm_max_bwd(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
+                     const float *g, const int64_t *argsrc, int64_t K, float *gx, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bspmm — multi-head SpMM, f32; supersedes bspmm_sum_cpu_{forward,backward}
+ * (cpu/bspmm_sum_cpu.cpp:7-56, 58-113).  x [N_in,H,C], w [E,H], out [N_out,H,C]:
+ *   out[i,h,c] = sum_p w[p,h] * x[col[p],h,c]
+ * backward: gx = the same call on the transposed plan with g in place of x;
+ *           gw[e,h] = sum_c x[src[e],h,c] * g[dst[e],h,c]  (edge-parallel, original edge order).
+ * ---------------------------------------------------------------------------------------------- */
+int ggl_bspmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                  const float *x, int64_t H, int64_t C, float *out, void *stream);
+int ggl_bspmm_grad_w(const int64_t *index /* [2,E] int64 */, const float *x, const float *g,
+                     int64_t E, int64_t H, int64_t C, float *gw, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused GAT edge-softmax + weighted aggregate: ONE kernel per direction.  Replaces the external
+ * dgNN GATConvFuse that FusedGATConv calls (layers/conv/fusedgat_conv.py:70-71,121) and the
+ * unfused chain in GATConv.forward (layers/conv/gat_conv.py:103-112 + utils/softmax.py:29-35):
+ *   s[p,h]   = LeakyReLU_slope(el[col[p],h] + er[i,h])       for p in row i
+ *   m[i,h]   = max_p s;  d[i,h] = sum_p exp(s - m)           (saved for backward)
+ *   out[i,h,:] = sum_p exp(s[p,h]-m[i,h]) / (d[i,h] + 1e-16) * x[col[p],h,:]
+ * el/er [N,H] f32 (source / destination attention terms), x [N_in,H,C] f32.
+ * Backward (two kernels, destination-major then source-major):
+ *   ggl_gat_fused_bwd_dst: per destination row recomputes alpha, writes alpha[E,H] and ds[E,H]
+ *       (both in forward sorted positions) and ger[N,H] = sum_p ds * lrelu'(.)
+ *   ggl_gat_fused_bwd_src: on the transposed plan, gx[j,h,:] = sum_p alpha * g[dst,h,:] and
+ *       gel[j,h] = sum_p de, reading alpha/de through posT (transposed position -> forward position)
+ * ---------------------------------------------------------------------------------------------- */
+int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
+                      const float *er, const float *x, float slope, int64_t H, int64_t C,
+                      float *out, float *rowmax, float *rowden, void *stream);
+int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *col, const float *el,
+                          const float *er, const float *x, const float *g, const float *out,
+                          const float *rowmax, const float *rowden, float slope, int64_t H,
+                          int64_t C, float *alpha, float *de, float *ger, void *stream);
+int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *colT, const int32_t *posT,
+                          const float *alpha, const float *de, const float *g, int64_t H,
+                          int64_t C, float *gx, float *gel, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tuning knobs (process-wide; also read once from the environment: GGL_UNROLL, GGL_XCD_SWIZZLE,
+ * GGL_FORCE_GENERIC).  For A/B measurements only — results do not depend on them.
+ * ---------------------------------------------------------------------------------------------- */
+int ggl_set_option(const char *name, int64_t value);
+int64_t ggl_get_option(const char *name);
+
+/* Profiling aid: run `reps` launches of the dominant SpMM-sum kernel bracketed by hipEvents on
+ * `stream` and return the average milliseconds per launch in *ms_host (SYNCHRONOUS). */
+int ggl_time_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                      const float *x, int64_t K, float *out, void *stream, int reps,
+                      float *ms_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGL_MPOPS_H */

@@ -1,0 +1,66 @@
+// tests/emul/emul_shim.hpp — minimal host stand-in for the HIP device environment.
+//
+// TEST INFRASTRUCTURE ONLY.  The round-1 kernels use no LDS, no cross-lane shuffles, no barriers
+// and no atomics, so running their bodies one thread at a time on the host executes exactly the
+// same arithmetic in the same order.  tests/emul/build.sh compiles gammagl_amd/csrc/*.hip with
+// -DGGL_EMULATE into tests/emul/libggl_emul.so so the `-m "not gpu"` suite can check kernel LOGIC
+// (indexing, row splitting, tie-breaking, dtype semantics) in a container that has no GPU.  The
+// product package never loads this library (gammagl_amd/_lib.py loads libggl_mpops_hip.so only
+// and raises if it is missing).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+struct ggl_emul_dim3 { unsigned x = 1, y = 1, z = 1; };
+inline thread_local ggl_emul_dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__
+
+typedef void *hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyDeviceToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToDevice };
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
+  std::memcpy(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
+  std::memset(d, v, n);
+  return hipSuccess;
+}
+
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+static inline double __dadd_rn(double a, double b) { return a + b; }
+static inline double __ddiv_rn(double a, double b) { return a / b; }
+static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+template <typename T> static inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
+
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+
+namespace ggl_emul {
+template <typename F> static inline void launch(int64_t grid, int64_t block, F &&body) {
+  gridDim.x = (unsigned)grid;
+  blockDim.x = (unsigned)block;
+  for (int64_t b = 0; b < grid; ++b) {
+    blockIdx.x = (unsigned)b;
+    for (int64_t t = 0; t < block; ++t) {
+      threadIdx.x = (unsigned)t;
+      body();
+    }
+  }
+}
+}  // namespace ggl_emul

@@ -1,0 +1,410 @@
+"""Parity checks shared by the GPU suite (tests/test_gpu_parity.py: the HIP library on a real
+MI355X, through the C ABI) and the CPU logic suite (tests/test_emul_kernels.py: the same kernel
+sources compiled for the host, see tests/emul/).  Every check compares an Engine against the
+golden vectors the reference produced and/or against the oracle on seeded inputs.
+
+Tolerances: integer/index work and argmax witnesses are bit-exact; float reductions are bit-exact
+wherever a row is reduced in one piece (same order of the same rounded operations as the serial
+reference) and within 1e-5 relative (north_star) where long rows are split into chunks.
+"""
+import numpy as np
+import torch
+
+DT = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "int32": torch.int32,
+      "int64": torch.int64, "float16": torch.float16, "bfloat16": torch.bfloat16,
+      "float32": torch.float32, "float64": torch.float64}
+KAT_DT = ["int8", "int16", "int32", "int64", "float16", "float32", "float64"]
+
+
+def to_t(a, dev, dt=None):
+    a = np.asarray(a)
+    if dt == "bfloat16":
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).to(dev)
+    return torch.from_numpy(a.copy()).to(dev)
+
+
+def to_np(t):
+    t = t.detach().cpu()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.numpy()
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    if a.dtype.kind == "f":
+        ok = ((a == b) | (np.isnan(a) & np.isnan(b))) & (np.signbit(a) == np.signbit(b))
+        return bool(ok.all())
+    return bool((a == b).all())
+
+
+def assert_same(a, b, what=""):
+    assert same(a, b), f"{what}: max|diff|={np.nanmax(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))}"
+
+
+# --------------------------------------------------------------------------------------------------
+def check_kat(eng, dev, golden):
+    g = golden["kat"]
+    idx = to_t(g["idx"], dev)
+    for op, fn in (("sum", eng.c_segment_sum), ("mean", eng.c_segment_mean), ("max", eng.c_segment_max)):
+        for dt in KAT_DT:
+            for dim in (1, 2, 3):
+                x = to_t(g[f"{op}_{dt}_d{dim}_x"], dev)
+                assert_same(to_np(fn(x, idx, 2)), g[f"{op}_{dt}_d{dim}_y"], f"kat {op} {dt} d{dim}")
+    ei = to_t(g["mp_ei"], dev)
+    msg = to_t(g["mp_x"], dev)[ei[0]]
+    assert_same(to_np(eng.c_segment_sum(msg, ei[1].contiguous(), 4)), g["mp_sum"], "mp sum")
+    assert_same(to_np(eng.c_segment_mean(msg, ei[1].contiguous(), 4)), g["mp_mean"], "mp mean")
+    assert_same(to_np(eng.c_segment_max(msg, ei[1].contiguous(), 4)), g["mp_max"], "mp max")
+    ones = torch.ones(5, dtype=torch.int64, device=dev)
+    assert_same(to_np(eng.c_segment_sum(ones, to_t(g["deg_row"], dev), 3)), g["deg_out"], "degree")
+    assert_same(to_np(eng.c_segment_max(to_t(g["doc_x"], dev), to_t(g["doc_ids"], dev), 3)), g["doc_max"], "doc max")
+    y = eng.c_spmm_sum(to_t(g["doc_gi"], dev), 2 * torch.ones(8, device=dev), 2 * torch.ones(5, 8, device=dev))
+    assert_same(to_np(y), g["doc_gspmm"], "doc gspmm")
+    # segment_softmax composed exactly like utils/softmax.py:29-35
+    x_e = to_t(g["sm_x"], dev)
+    dst = ei[1].contiguous()
+    mx = eng.c_segment_max(x_e, dst, 4)
+    ex = torch.exp(x_e - mx[dst])
+    den = eng.c_segment_sum(ex, dst, 4)
+    score = ex / (den[dst] + 1e-16)
+    np.testing.assert_allclose(to_np(score), g["sm_score"], rtol=1e-6)
+
+
+def check_segment_all_dtypes(eng, dev, golden):
+    g = golden["segment"]
+    for ci in range(int(g["ncases"])):
+        ids = to_t(g[f"c{ci}_ids"], dev)
+        N = int(g[f"c{ci}_N"])
+        for dt in DT:
+            x = to_t(g[f"c{ci}_{dt}_x"], dev, dt)
+            assert_same(to_np(eng.c_segment_sum(x, ids, N)), g[f"c{ci}_{dt}_sum"], f"c{ci} {dt} sum")
+            assert_same(to_np(eng.c_segment_mean(x, ids, N)), g[f"c{ci}_{dt}_mean"], f"c{ci} {dt} mean")
+            assert_same(to_np(eng.c_segment_max(x, ids, N)), g[f"c{ci}_{dt}_max"], f"c{ci} {dt} max")
+
+
+def check_segment_fwd_bwd(eng, dev, golden):
+    g = golden["segment"]
+    for bi in range(int(g["nbwd"])):
+        ids = to_t(g[f"b{bi}_ids"], dev)
+        N = int(g[f"b{bi}_N"])
+        for dt in ("float32", "float64"):
+            k = f"b{bi}_{dt}"
+            go = to_t(g[k + "_g"], dev)
+            for name, fn in (("sum", eng.c_segment_sum), ("mean", eng.c_segment_mean), ("max", eng.c_segment_max)):
+                x = to_t(g[k + "_x"], dev).requires_grad_(True)
+                y = fn(x, ids, N)
+                y.backward(go)
+                assert_same(to_np(y), g[f"{k}_{name}"], f"{k} {name}")
+                # for max the gradient is the argmax witness: bit-exact <=> every argmax agrees
+                assert_same(to_np(x.grad), g[f"{k}_{name}_gx"], f"{k} {name} grad")
+
+
+def check_special_values(eng, dev, golden):
+    g = golden["segment"]
+    ids = to_t(g["sp_ids"], dev)
+    x = to_t(g["sp_x"], dev).requires_grad_(True)
+    y = eng.c_segment_max(x, ids, 4)
+    y.backward(torch.arange(16, dtype=torch.float32, device=dev).reshape(4, 4) + 1)
+    assert_same(to_np(y), g["sp_max"], "nan/inf/-0 max")
+    assert_same(to_np(x.grad), g["sp_gx"], "nan/inf/-0 max grad")
+    assert_same(to_np(eng.c_segment_sum(x.detach(), ids, 4)), g["sp_sum"], "nan/inf sum")
+    sid = to_t(g["sat_ids"], dev)
+    for nm, dt in (("f16", "float16"), ("bf16", "bfloat16")):
+        xs = to_t(g[f"sat_{nm}_x"], dev, dt)
+        assert_same(to_np(eng.c_segment_sum(xs, sid, 3)), g[f"sat_{nm}_sum"], nm + " sum saturation")
+        assert_same(to_np(eng.c_segment_mean(xs, sid, 3)), g[f"sat_{nm}_mean"], nm + " count saturation")
+
+
+def check_spmm_golden(eng, dev, golden):
+    g = golden["spmm"]
+    for ci in range(int(g["nspmm"])):
+        k = f"s{ci}"
+        idx, w, go = to_t(g[k + "_index"], dev), to_t(g[k + "_w"], dev), to_t(g[k + "_g"], dev)
+        for red, fn in (("sum", eng.c_spmm_sum), ("mean", eng.c_spmm_mean), ("max", eng.c_spmm_max)):
+            x = to_t(g[k + "_x"], dev).requires_grad_(True)
+            y = fn(idx, w, x)
+            assert_same(to_np(y), g[f"{k}_{red}"], f"{k} {red}")
+            if idx.shape[1] > 0:
+                y.backward(go)
+                assert_same(to_np(x.grad), g[f"{k}_{red}_gx"], f"{k} {red} grad")
+    for bi in range(int(g["nbspmm"])):
+        k = f"bs{bi}"
+        idx, go = to_t(g[k + "_index"], dev), to_t(g[k + "_g"], dev)
+        w = to_t(g[k + "_w"], dev).requires_grad_(True)
+        x = to_t(g[k + "_x"], dev).requires_grad_(True)
+        y = eng.c_bspmm_sum(idx, w, x)
+        y.backward(go)
+        assert_same(to_np(y), g[k + "_y"], k)
+        assert_same(to_np(x.grad), g[k + "_gx"], k + " gx")
+        assert_same(to_np(w.grad), g[k + "_gw"], k + " gw")
+
+
+def check_layers_golden(eng, dev, golden):
+    g = golden["layers"]
+    ei = to_t(g["gcn_ei"], dev)
+    x, b = to_t(g["gcn_x"], dev), to_t(g["gcn_b"], dev)
+    W = to_t(g["gcn_W"], dev).requires_grad_(True)
+    N = x.shape[0]
+    src, dst = ei[0].contiguous(), ei[1].contiguous()
+    ones = torch.ones(ei.shape[1], device=dev)
+    wts = eng.c_segment_sum(ones, src, N).pow(-0.5)[src] * ones
+    wts = wts * eng.c_segment_sum(ones, dst, N).pow(-0.5)[dst]
+    np.testing.assert_allclose(to_np(wts), g["gcn_w"], rtol=1e-6)
+    # unfused, as GCNConv runs today: gather * w -> unsorted_segment_sum (message_passing.py:56-59,84-86)
+    h = x @ W
+    y = eng.c_segment_sum(h[src] * wts.unsqueeze(-1), dst, N) + b
+    y.backward(to_t(g["gcn_g"], dev))
+    np.testing.assert_allclose(to_np(y), g["gcn_y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(to_np(W.grad), g["gcn_gW"], rtol=1e-4, atol=1e-5)
+    # fused: gspmm
+    W2 = to_t(g["gcn_W"], dev).requires_grad_(True)
+    y2 = eng.c_spmm_sum(ei, wts.detach(), x @ W2) + b
+    y2.backward(to_t(g["gcn_g"], dev))
+    np.testing.assert_allclose(to_np(y2), g["gcn_y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(to_np(W2.grad), g["gcn_gW"], rtol=1e-4, atol=1e-5)
+
+    # GAT: fused kernel vs the reference's unfused chain (gat_conv.py:103-112)
+    gei = to_t(g["gat_ei"], dev)
+    att = to_t(g["gat_att"], dev)
+    xg = to_t(g["gat_x"], dev).requires_grad_(True)
+    C = xg.shape[2]
+    el = (xg * att[:, :, :C]).sum(-1)
+    er = (xg * att[:, :, C:]).sum(-1)
+    yg = eng.gat_fused(gei, el, er, xg, 0.2)
+    yg.backward(to_t(g["gat_g"], dev))
+    np.testing.assert_allclose(to_np(yg), g["gat_y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(to_np(xg.grad), g["gat_gx"], rtol=2e-4, atol=2e-5)
+
+
+# --------------------------------------------------------------------------------------------------
+def _rand_graph(rng, N, E, hub=None):
+    src = rng.integers(0, N, size=E)
+    dst = rng.integers(0, N, size=E)
+    if hub:
+        dst[: E // 3] = hub
+    return np.stack([src, dst]).astype(np.int64)
+
+
+def check_random_vs_oracle(eng, dev, oracle, seed=0, sizes=None):
+    """segment ops + gspmm + bspmm on seeded graphs vs the oracle, many K, sorted and unsorted ids."""
+    rng = np.random.default_rng(seed)
+    sizes = sizes or [(50, 400), (257, 3000)]
+    for (N, E) in sizes:
+        for K in (1, 3, 4, 8, 16, 47, 64, 100, 256, 260):
+            ids = rng.integers(0, N, size=E).astype(np.int64)
+            if K in (8, 256):
+                ids.sort()  # already-sorted fast path (no perm)
+            x = rng.standard_normal((E, K)).astype(np.float32)
+            xt, it = to_t(x, dev), to_t(ids, dev)
+            assert_same(to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids, N), f"sum N{N} K{K}")
+            assert_same(to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids, N), f"mean N{N} K{K}")
+            mx, arg = eng.segment_max_with_arg(xt, it, N)
+            omx, oarg = oracle.segment_max(x, ids, N)
+            assert_same(to_np(mx), omx, f"max N{N} K{K}")
+            assert_same(to_np(arg), oarg, f"argmax N{N} K{K}")
+        for K in (1, 4, 7, 16, 47, 64, 256):
+            index = _rand_graph(rng, N, E)
+            if K == 16:
+                index = index[:, np.argsort(index[1], kind="stable")]  # CSR-ordered edge list
+            w = rng.standard_normal(E).astype(np.float32)
+            x = rng.standard_normal((N, K)).astype(np.float32)
+            go = rng.standard_normal((N, K)).astype(np.float32)
+            it, wt, gt = to_t(index, dev), to_t(w, dev), to_t(go, dev)
+            for red, fn in (("sum", eng.c_spmm_sum), ("mean", eng.c_spmm_mean), ("max", eng.c_spmm_max)):
+                xt = to_t(x, dev).requires_grad_(True)
+                y = fn(it, wt, xt)
+                y.backward(gt)
+                if red == "sum":
+                    oy, ogx = oracle.spmm_sum_fwd(index, w, x), oracle.spmm_sum_bwd(index, w, go)
+                elif red == "mean":
+                    oy, cnt = oracle.spmm_mean_fwd(index, w, x)
+                    ogx = oracle.spmm_mean_bwd(index, w, go, cnt)
+                else:
+                    oy, arg = oracle.spmm_max_fwd(index, w, x)
+                    ogx = oracle.spmm_max_bwd(index, w, go, arg)
+                assert_same(to_np(y), oy, f"spmm {red} N{N} K{K}")
+                assert_same(to_np(xt.grad), ogx, f"spmm {red} grad N{N} K{K}")
+            # weight=None == ones
+            y1 = eng.c_spmm_sum(it, None, to_t(x, dev))
+            assert_same(to_np(y1), oracle.spmm_sum_fwd(index, np.ones(E, np.float32), x), "spmm w=None")
+        for (H, C) in ((8, 8), (4, 16), (3, 5), (1, 64), (8, 32)):
+            index = _rand_graph(rng, N, E)
+            w = rng.standard_normal((E, H)).astype(np.float32)
+            x = rng.standard_normal((N, H, C)).astype(np.float32)
+            go = rng.standard_normal((N, H, C)).astype(np.float32)
+            wt = to_t(w, dev).requires_grad_(True)
+            xt = to_t(x, dev).requires_grad_(True)
+            y = eng.c_bspmm_sum(to_t(index, dev), wt, xt)
+            y.backward(to_t(go, dev))
+            ogx, ogw = oracle.bspmm_sum_bwd(index, w, x, go)
+            assert_same(to_np(y), oracle.bspmm_sum_fwd(index, w, x), f"bspmm H{H} C{C}")
+            assert_same(to_np(xt.grad), ogx, f"bspmm gx H{H} C{C}")
+            assert_same(to_np(wt.grad), ogw, f"bspmm gw H{H} C{C}")
+
+
+def check_long_rows(eng, dev, oracle, chunk=8):
+    """Force the chunked long-row path (threshold `chunk`) with hubs far longer than it."""
+    old = eng.chunk
+    eng.chunk = chunk
+    eng.seg_cache.clear()
+    eng.graph_cache.clear()
+    try:
+        rng = np.random.default_rng(5)
+        N, E = 40, 1500
+        for K in (1, 4, 5, 64, 256):
+            ids = rng.integers(0, N, size=E).astype(np.int64)
+            ids[:700] = 7
+            ids[700:900] = 0
+            ids[900:905] = 39
+            # tie-prone values so that the chunk-ordered argmax tie-break is exercised
+            x = (rng.integers(-3, 4, size=(E, K)) * 0.5).astype(np.float32)
+            xt, it = to_t(x, dev), to_t(ids, dev)
+            plan = eng.seg_plan(it, N)
+            assert plan.n_long >= 2 and plan.n_chunks > plan.n_long
+            np.testing.assert_allclose(to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids, N),
+                                       rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids, N),
+                                       rtol=1e-5, atol=1e-5)
+            mx, arg = eng.segment_max_with_arg(xt, it, N)
+            omx, oarg = oracle.segment_max(x, ids, N)
+            assert_same(to_np(mx), omx, f"long max K{K}")
+            assert_same(to_np(arg), oarg, f"long argmax K{K}")
+            # integers: wrap-around sums are order independent -> bit exact even when chunked
+            xi = rng.integers(-100, 100, size=(E, K)).astype(np.int32)
+            assert_same(to_np(eng.c_segment_sum(to_t(xi, dev), it, N)), oracle.segment_sum(xi, ids, N), "long i32")
+            assert_same(to_np(eng.c_segment_mean(to_t(xi, dev), it, N)), oracle.segment_mean(xi, ids, N), "long i32 mean")
+        for K in (4, 47, 256):
+            index = _rand_graph(rng, N, E, hub=3)
+            index[0, : E // 2] = 11  # a source hub too: long rows in the transposed plan
+            w = rng.standard_normal(E).astype(np.float32)
+            x = rng.standard_normal((N, K)).astype(np.float32)
+            go = rng.standard_normal((N, K)).astype(np.float32)
+            it, wt = to_t(index, dev), to_t(w, dev)
+            gp = eng.graph_plan(it, N)
+            assert gp.fwd.n_long >= 1 and gp.bwd.n_long >= 1
+            xt = to_t(x, dev).requires_grad_(True)
+            y = eng.c_spmm_sum(it, wt, xt)
+            y.backward(to_t(go, dev))
+            np.testing.assert_allclose(to_np(y), oracle.spmm_sum_fwd(index, w, x), rtol=1e-5, atol=1e-4)
+            np.testing.assert_allclose(to_np(xt.grad), oracle.spmm_sum_bwd(index, w, go), rtol=1e-5, atol=1e-4)
+            ym = eng.c_spmm_mean(it, wt, to_t(x, dev))
+            np.testing.assert_allclose(to_np(ym), oracle.spmm_mean_fwd(index, w, x)[0], rtol=1e-5, atol=1e-5)
+            xt2 = to_t(x, dev).requires_grad_(True)
+            yx = eng.c_spmm_max(it, wt, xt2)
+            yx.backward(to_t(go, dev))
+            oyx, oarg = oracle.spmm_max_fwd(index, w, x)
+            assert_same(to_np(yx), oyx, "long spmm max")
+            np.testing.assert_allclose(to_np(xt2.grad), oracle.spmm_max_bwd(index, w, go, oarg), rtol=1e-5, atol=1e-4)
+        # fused GAT with long rows in the transposed (source-major) backward
+        H, C = 4, 8
+        index = _rand_graph(rng, N, 600, hub=5)
+        index[0, :300] = 2
+        _check_gat(eng, dev, oracle, index, N, H, C, rng)
+    finally:
+        eng.chunk = old
+        eng.seg_cache.clear()
+        eng.graph_cache.clear()
+
+
+def _check_gat(eng, dev, oracle, index, N, H, C, rng):
+    el = rng.standard_normal((N, H)).astype(np.float32)
+    er = rng.standard_normal((N, H)).astype(np.float32)
+    x = rng.standard_normal((N, H, C)).astype(np.float32)
+    go = rng.standard_normal((N, H, C)).astype(np.float32)
+    elt, ert, xt = (to_t(a, dev).requires_grad_(True) for a in (el, er, x))
+    y = eng.gat_fused(to_t(index, dev), elt, ert, xt, 0.2)
+    y.backward(to_t(go, dev))
+    oy = oracle.gat_fwd(index, el, er, x, 0.2)
+    gel, ger, gx = oracle.gat_bwd(index, el, er, x, go, 0.2)
+    np.testing.assert_allclose(to_np(y), oy, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(to_np(xt.grad), gx, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(to_np(elt.grad), gel, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(to_np(ert.grad), ger, rtol=1e-4, atol=2e-5)
+
+
+def check_gat_random(eng, dev, oracle):
+    rng = np.random.default_rng(9)
+    for (N, E, H, C) in ((30, 200, 8, 8), (64, 700, 4, 16), (17, 90, 1, 5), (40, 300, 3, 7), (25, 250, 8, 64)):
+        index = _rand_graph(rng, N, E)
+        index[1, :5] = N - 1
+        _check_gat(eng, dev, oracle, index, N, H, C, rng)
+    # isolated destination rows: out = 0, no NaN (den = 0 + 1e-16)
+    index = np.array([[0, 1, 2], [1, 1, 1]], dtype=np.int64)
+    x = rng.standard_normal((4, 2, 4)).astype(np.float32)
+    el = rng.standard_normal((4, 2)).astype(np.float32)
+    y = eng.gat_fused(to_t(index, dev), to_t(el, dev), to_t(el, dev), to_t(x, dev), 0.2)
+    ynp = to_np(y)
+    assert np.isfinite(ynp).all() and (ynp[[0, 2, 3]] == 0).all()
+    np.testing.assert_allclose(ynp, oracle.gat_fwd(index, el, el, x, 0.2), rtol=1e-5, atol=1e-6)
+
+
+def check_edge_cases(eng, dev, oracle):
+    f32 = torch.float32
+    # empty inputs
+    x0 = torch.zeros((0, 4), dtype=f32, device=dev)
+    i0 = torch.zeros((0,), dtype=torch.int64, device=dev)
+    assert to_np(eng.c_segment_sum(x0, i0, 3)).tolist() == [[0.0] * 4] * 3
+    assert to_np(eng.c_segment_mean(x0, i0, 3)).tolist() == [[0.0] * 4] * 3
+    mx, arg = eng.segment_max_with_arg(x0, i0, 3)
+    assert (to_np(mx) == 0).all() and (to_np(arg) == 0).all()  # segment_max_cpu.cpp:28-30; fill = E = 0
+    # N = 0
+    assert eng.c_segment_sum(x0, i0, 0).shape == (0, 4)
+    # ragged: single element, N > E with empty tail rows, 1-D and 3-D x
+    x1 = torch.tensor([2.5], device=dev)
+    i1 = torch.tensor([3], device=dev)
+    assert to_np(eng.c_segment_sum(x1, i1, 6)).tolist() == [0, 0, 0, 2.5, 0, 0]
+    low = float(np.finfo(np.float32).min)
+    assert to_np(eng.c_segment_max(x1, i1, 6)).tolist() == [low, low, low, 2.5, low, low]
+    x3 = torch.arange(24, dtype=f32, device=dev).reshape(3, 2, 4)
+    i3 = torch.tensor([1, 0, 1], device=dev)
+    assert_same(to_np(eng.c_segment_mean(x3, i3, 2)), oracle.segment_mean(to_np(x3), to_np(i3), 2), "3-D mean")
+    # mean with ids >= E (outside the reference's defined domain): mathematically correct mean
+    xm = torch.tensor([[2.0], [4.0], [1.0], [3.0]], device=dev)
+    im = torch.tensor([0, 0, 5, 5], device=dev)
+    assert to_np(eng.c_segment_mean(xm, im, 6)).reshape(-1).tolist() == [3.0, 0, 0, 0, 0, 2.0]
+    # non-contiguous x
+    xn = torch.arange(40, dtype=f32, device=dev).reshape(5, 8)[:, ::2]
+    i_n = torch.tensor([0, 1, 0, 1, 2], device=dev)
+    assert_same(to_np(eng.c_segment_sum(xn, i_n, 3)), oracle.segment_sum(to_np(xn.contiguous()), to_np(i_n), 3), "strided x")
+    # errors: same exception types as the reference's TORCH_CHECK_INDEX / dtype checks
+    import pytest
+
+    xe = torch.ones((3, 2), device=dev)
+    with pytest.raises(IndexError):
+        eng.c_segment_max(xe, torch.tensor([0, 5, 1], device=dev), 3)
+    with pytest.raises(IndexError):
+        eng.c_segment_sum(xe, torch.tensor([0, -1, 1], device=dev), 3)
+    with pytest.raises(IndexError):
+        eng.c_segment_sum(xe, torch.tensor([[0, 1, 1]], device=dev), 3)  # index.dim() != 1
+    with pytest.raises(IndexError):
+        eng.c_segment_sum(xe, torch.tensor([0, 1], device=dev), 3)  # size mismatch
+    with pytest.raises(RuntimeError, match="Long"):
+        eng.c_segment_sum(xe, torch.tensor([0, 1, 1], device=dev, dtype=torch.int32), 3)
+    with pytest.raises(RuntimeError, match="Float"):
+        eng.c_spmm_sum(torch.tensor([[0, 1], [1, 0]], device=dev), torch.ones(2, device=dev),
+                       torch.ones((2, 2), dtype=torch.float64, device=dev))
+    with pytest.raises(IndexError):
+        eng.c_spmm_sum(torch.tensor([[0, 7], [1, 0]], device=dev), torch.ones(2, device=dev), torch.ones((2, 2), device=dev))
+
+
+def check_plan_cache(eng, dev):
+    eng.seg_cache.clear()
+    ids = torch.tensor([2, 0, 1, 0, 2, 2], device=dev)
+    x = torch.arange(12, dtype=torch.float32, device=dev).reshape(6, 2)
+    b0 = eng.stats["plans_built"]
+    y1 = eng.c_segment_sum(x, ids, 3)
+    y2 = eng.c_segment_sum(x, ids, 3)
+    assert eng.stats["plans_built"] == b0 + 1, "second call must hit the plan cache"
+    assert torch.equal(y1, y2)
+    ids[0] = 1  # in-place edit bumps the version counter -> stale plan must not be reused
+    y3 = eng.c_segment_sum(x, ids, 3)
+    assert eng.stats["plans_built"] == b0 + 2
+    assert to_np(y3).tolist() == [[8.0, 10.0], [4.0, 6.0], [18.0, 20.0]]
+    # a view of the same storage (edge_index[1]) hits the same entry
+    ei = torch.stack([ids, ids]).contiguous()
+    eng.c_segment_sum(x, ei[1], 3)
+    b1 = eng.stats["plans_built"]
+    eng.c_segment_sum(x, ei[1], 3)
+    assert eng.stats["plans_built"] == b1
