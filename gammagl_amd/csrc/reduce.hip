@@ -33,48 +33,55 @@ enum Mode {
   MODE_MAXBWD = 4      // value = w * g[col[p],k] if argsrc[col[p],k] == row (spmm_max_cpu.cpp:88-93)
 };
 
-struct ReduceArgs {
-  const void *x;
-  const int32_t *perm;
-  const int32_t *col;
-  const float *w;
-  int w_by_pos;
-  const int64_t *rowptr;
+// How positions map to element / weight indices, fixed at compile time for the hot f32 kernels so
+// the inner loop carries no pointer tests:
+//   MODE_SEG : IDX_DIRECT = ids arrived sorted (e = p), IDX_PERM = e = perm[p]
+//   others   : IDX_NONE = no weights, IDX_DIRECT = w[p], IDX_PERM = w[perm[p]]
+//   IDX_RUNTIME = decide from the pointers at run time (rare modes, non-f32 dtypes)
+enum IdxMode { IDX_RUNTIME = -1, IDX_NONE = 0, IDX_DIRECT = 1, IDX_PERM = 2 };
+
+// Scalars of one launch.  Pointers travel as separate `const T* __restrict__` kernel parameters:
+// that is what lets the backend prove the index/weight loads are not clobbered by the output
+// stores and issue them on the scalar path (s_load) when the row is wave-uniform.
+struct ReduceDims {
   int64_t N, K, E;
-  void *out;
-  int64_t *arg;
   int64_t arg_fill;
   int64_t chunk;
-  int logL;
-  int swizzle;
   int64_t nblocks;
   int64_t H, C;
-  const int64_t *aux_rowptr;
-  const int64_t *aux_arg;
-  const int32_t *long_rows;
-  const int64_t *chunk_ptr;
   int64_t n_long, n_chunks;
-  void *partial;
-  int64_t *partial_arg;
+  int logL;
+  int swizzle;
+  int w_by_pos;
+};
+
+template <typename S> struct RPtrs {
+  const S *__restrict__ x;
+  const int32_t *__restrict__ perm;
+  const int32_t *__restrict__ col;
+  const float *__restrict__ w;
+  const int64_t *__restrict__ rowptr;
+  const int64_t *__restrict__ aux_rowptr;
+  const int64_t *__restrict__ aux_arg;
 };
 
 // ---- VEC-wide loads / stores of storage elements ------------------------------------------------
 template <typename S, int VEC> struct VecIO {
-  static __device__ __forceinline__ void load(const S *p, S (&v)[VEC]) {
+  static __device__ __forceinline__ void load(const S *__restrict__ p, S (&v)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) v[i] = p[i];
   }
-  static __device__ __forceinline__ void store(S *p, const S (&v)[VEC]) {
+  static __device__ __forceinline__ void store(S *__restrict__ p, const S (&v)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) p[i] = v[i];
   }
 };
 template <> struct VecIO<float, 4> {
-  static __device__ __forceinline__ void load(const float *p, float (&v)[4]) {
+  static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[4]) {
     const float4 t = *reinterpret_cast<const float4 *>(p);  // global_load_dwordx4
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
-  static __device__ __forceinline__ void store(float *p, const float (&v)[4]) {
+  static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[4]) {
     float4 t;
     t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
     *reinterpret_cast<float4 *>(p) = t;
@@ -82,31 +89,33 @@ template <> struct VecIO<float, 4> {
 };
 
 // ---- reduce sorted positions [beg, end) of `row` for the VEC features starting at kk -------------
-template <typename T, int VEC, int OP, int MODE, int U>
-__device__ __forceinline__ void reduce_range(const ReduceArgs &a, int64_t row, int64_t beg,
-                                             int64_t end, int64_t kk,
+template <typename T, int VEC, int OP, int MODE, int IDX, int U>
+__device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, const ReduceDims &d,
+                                             int64_t row, int64_t beg, int64_t end, int64_t kk,
                                              typename TT<T>::A (&acc)[VEC], int64_t (&arg)[VEC]) {
   using S = typename TT<T>::S;
   using A = typename TT<T>::A;
-  const S *xs = static_cast<const S *>(a.x);
-  const int64_t K = a.K;
-  const int64_t head = (MODE == MODE_BSPMM) ? kk / a.C : 0;
+  const int64_t K = d.K;
+  const int64_t head = (MODE == MODE_BSPMM) ? kk / d.C : 0;
+  // resolve the index mode (compile time unless IDX_RUNTIME)
+  const bool seg_perm = (MODE == MODE_SEG) && (IDX == IDX_RUNTIME ? q.perm != nullptr : IDX == IDX_PERM);
+  const bool has_w = (MODE != MODE_SEG) && (IDX == IDX_RUNTIME ? q.w != nullptr : IDX != IDX_NONE);
+  const bool w_perm = has_w && (IDX == IDX_RUNTIME ? (!d.w_by_pos && q.perm != nullptr) : IDX == IDX_PERM);
 
   auto element = [&](int64_t p, int64_t &xrow, float &wv, int64_t &who) {
     if (MODE == MODE_SEG) {
-      const int64_t e = a.perm ? (int64_t)a.perm[p] : p;
+      const int64_t e = seg_perm ? (int64_t)q.perm[p] : p;
       xrow = e;
       who = e;
       wv = 1.0f;
     } else {
-      const int64_t c = (int64_t)a.col[p];
+      const int64_t c = (int64_t)q.col[p];
       xrow = c;
       who = c;
-      if (a.w) {
-        const int64_t wi = (a.w_by_pos || !a.perm) ? p : (int64_t)a.perm[p];
-        wv = (MODE == MODE_BSPMM) ? a.w[wi * a.H + head] : a.w[wi];
-      } else {
-        wv = 1.0f;
+      wv = 1.0f;
+      if (has_w) {
+        const int64_t wi = w_perm ? (int64_t)q.perm[p] : p;
+        wv = (MODE == MODE_BSPMM) ? q.w[wi * d.H + head] : q.w[wi];
       }
     }
   };
@@ -116,14 +125,14 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int64_t row, i
     for (int i = 0; i < VEC; ++i) {
       A v = TT<T>::load(raw[i]);
       if (MODE == MODE_SPMM || MODE == MODE_BSPMM) {
-        if (a.w) v = (A)__fmul_rn(wv, (float)v);
+        if (has_w) v = (A)__fmul_rn(wv, (float)v);
       } else if (MODE == MODE_MEANBWD) {
-        const int64_t cnt = a.aux_rowptr[xrow + 1] - a.aux_rowptr[xrow];
+        const int64_t cnt = q.aux_rowptr[xrow + 1] - q.aux_rowptr[xrow];
         v = (A)__fdiv_rn((float)v, (float)cnt);
-        if (a.w) v = (A)__fmul_rn((float)v, wv);
+        if (has_w) v = (A)__fmul_rn((float)v, wv);
       } else if (MODE == MODE_MAXBWD) {
-        if (a.aux_arg[xrow * K + kk + i] != row) continue;
-        if (a.w) v = (A)__fmul_rn(wv, (float)v);
+        if (q.aux_arg[xrow * K + kk + i] != row) continue;
+        if (has_w) v = (A)__fmul_rn(wv, (float)v);
       }
       if (OP == OP_MAX) {
         if (TT<T>::less(acc[i], v)) {
@@ -144,7 +153,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int64_t row, i
 #pragma unroll
     for (int u = 0; u < U; ++u) element(p + u, xrow[u], wv[u], who[u]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) VecIO<S, VEC>::load(xs + xrow[u] * K + kk, raw[u]);
+    for (int u = 0; u < U; ++u) VecIO<S, VEC>::load(q.x + xrow[u] * K + kk, raw[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) accumulate(raw[u], xrow[u], wv[u], who[u]);
   }
@@ -153,7 +162,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int64_t row, i
     float wv;
     S raw[VEC];
     element(p, xrow, wv, who);
-    VecIO<S, VEC>::load(xs + xrow * K + kk, raw);
+    VecIO<S, VEC>::load(q.x + xrow * K + kk, raw);
     accumulate(raw, xrow, wv, who);
   }
 }
@@ -170,8 +179,9 @@ __device__ __forceinline__ void init_acc(typename TT<T>::A (&acc)[VEC], int64_t 
 
 // mean / store epilogue of a finished row
 template <typename T, int VEC, int OP, int MODE>
-__device__ __forceinline__ void finish_row(const ReduceArgs &a, int64_t row, int64_t len,
-                                           int64_t kk, typename TT<T>::A (&acc)[VEC],
+__device__ __forceinline__ void finish_row(typename TT<T>::S *__restrict__ out,
+                                           int64_t *__restrict__ argout, int64_t K, int64_t row,
+                                           int64_t len, int64_t kk, typename TT<T>::A (&acc)[VEC],
                                            const int64_t (&arg)[VEC]) {
   using S = typename TT<T>::S;
   if (OP == OP_MEAN) {
@@ -193,172 +203,247 @@ __device__ __forceinline__ void finish_row(const ReduceArgs &a, int64_t row, int
   S o[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
-  VecIO<S, VEC>::store(static_cast<S *>(a.out) + row * a.K + kk, o);
+  VecIO<S, VEC>::store(out + row * K + kk, o);
   if (OP == OP_MAX) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) a.arg[row * a.K + kk + i] = arg[i];
+    for (int i = 0; i < VEC; ++i) argout[row * K + kk + i] = arg[i];
   }
 }
 
+#define GGL_RPTR_PARAMS(S)                                                                         \
+  const S *__restrict__ x, const int32_t *__restrict__ perm, const int32_t *__restrict__ col,      \
+      const float *__restrict__ w, const int64_t *__restrict__ rowptr,                             \
+      const int64_t *__restrict__ aux_rowptr, const int64_t *__restrict__ aux_arg
+#define GGL_RPTR_PACK(S) RPtrs<S> q{x, perm, col, w, rowptr, aux_rowptr, aux_arg}
+
 // ---- main kernel: every row with len <= chunk ---------------------------------------------------
-template <typename T, int VEC, int OP, int MODE, bool UNIFORM, int U>
-__global__ __launch_bounds__(kBlock) void row_reduce_kernel(const ReduceArgs a) {
+template <typename T, int VEC, int OP, int MODE, int IDX, bool UNIFORM, int U>
+__global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(typename TT<T>::S),
+                                                            typename TT<T>::S *__restrict__ out,
+                                                            int64_t *__restrict__ argout,
+                                                            const ReduceDims d) {
   using A = typename TT<T>::A;
+  GGL_RPTR_PACK(typename TT<T>::S);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int64_t blk = xcd_remap((int64_t)blockIdx.x, a.nblocks, a.swizzle);
-  const int L = 1 << a.logL;
+  const int64_t blk = xcd_remap((int64_t)blockIdx.x, d.nblocks, d.swizzle);
+  const int L = 1 << d.logL;
   int64_t row;
   int li;
   if (UNIFORM) {  // one wavefront per row: everything about the row is wave-uniform (scalar path)
-    row = blk * kWavesPerBlock + wave;
-    row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(row >> 32)) << 32) |
-          (uint32_t)__builtin_amdgcn_readfirstlane((int)(row & 0xffffffff));
+    const int r32 = __builtin_amdgcn_readfirstlane((int)(blk * kWavesPerBlock + wave));
+    row = (int64_t)(uint32_t)r32;  // nblocks * 4 < 2^32 is checked at launch
     li = lane;
   } else {
-    const int rows_per_wave = kWave >> a.logL;
-    row = (blk * kWavesPerBlock + wave) * rows_per_wave + (lane >> a.logL);
+    const int rows_per_wave = kWave >> d.logL;
+    row = (blk * kWavesPerBlock + wave) * rows_per_wave + (lane >> d.logL);
     li = lane & (L - 1);
   }
-  if (row >= a.N) return;
-  const int64_t beg = a.rowptr[row], end = a.rowptr[row + 1];
+  if (row >= d.N) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
   const int64_t len = end - beg;
-  if (len > a.chunk) return;  // long row: handled by long_chunk_kernel + long_final_kernel
-  for (int64_t kk = (int64_t)li * VEC; kk < a.K; kk += (int64_t)L * VEC) {
+  if (len > d.chunk) return;  // long row: handled by long_chunk_kernel + long_final_kernel
+  for (int64_t kk = (int64_t)li * VEC; kk < d.K; kk += (int64_t)L * VEC) {
     A acc[VEC];
     int64_t arg[VEC];
-    init_acc<T, VEC, OP>(acc, arg, a.arg_fill);
-    reduce_range<T, VEC, OP, MODE, U>(a, row, beg, end, kk, acc, arg);
-    finish_row<T, VEC, OP, MODE>(a, row, len, kk, acc, arg);
+    init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
+    reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
+    finish_row<T, VEC, OP, MODE>(out, argout, d.K, row, len, kk, acc, arg);
   }
 }
 
 // ---- long rows: one wavefront per chunk, then an ordered combine --------------------------------
-template <typename T, int VEC, int OP, int MODE, int U>
-__global__ __launch_bounds__(kBlock) void long_chunk_kernel(const ReduceArgs a) {
+template <typename T, int VEC, int OP, int MODE, int IDX, int U>
+__global__ __launch_bounds__(kBlock) void long_chunk_kernel(GGL_RPTR_PARAMS(typename TT<T>::S),
+                                                            const int32_t *__restrict__ long_rows,
+                                                            const int64_t *__restrict__ chunk_ptr,
+                                                            typename TT<T>::S *__restrict__ partial,
+                                                            int64_t *__restrict__ partial_arg,
+                                                            const ReduceDims d) {
   using S = typename TT<T>::S;
   using A = typename TT<T>::A;
+  GGL_RPTR_PACK(S);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  int64_t cid = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (cid >= a.n_chunks) return;
+  const int c32 = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * kWavesPerBlock + wave));
+  const int64_t cid = (int64_t)(uint32_t)c32;
+  if (cid >= d.n_chunks) return;
   // owning long row: last j with chunk_ptr[j] <= cid
-  int64_t lo = 0, hi = a.n_long - 1;
+  int64_t lo = 0, hi = d.n_long - 1;
   while (lo < hi) {
     const int64_t mid = (lo + hi + 1) >> 1;
-    if (a.chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
+    if (chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
   }
-  const int64_t row = a.long_rows[lo];
-  const int64_t local = cid - a.chunk_ptr[lo];
-  const int64_t rbeg = a.rowptr[row], rend = a.rowptr[row + 1];
-  const int64_t beg = rbeg + local * a.chunk;
-  const int64_t end = (beg + a.chunk < rend) ? beg + a.chunk : rend;
-  for (int64_t kk = (int64_t)lane * VEC; kk < a.K; kk += (int64_t)kWave * VEC) {
+  const int64_t row = long_rows[lo];
+  const int64_t local = cid - chunk_ptr[lo];
+  const int64_t rbeg = rowptr[row], rend = rowptr[row + 1];
+  const int64_t beg = rbeg + local * d.chunk;
+  const int64_t end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
+  for (int64_t kk = (int64_t)lane * VEC; kk < d.K; kk += (int64_t)kWave * VEC) {
     A acc[VEC];
     int64_t arg[VEC];
-    init_acc<T, VEC, OP>(acc, arg, a.arg_fill);
-    reduce_range<T, VEC, OP, MODE, U>(a, row, beg, end, kk, acc, arg);
+    init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
+    reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
     S o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
-    VecIO<S, VEC>::store(static_cast<S *>(a.partial) + cid * a.K + kk, o);
+    VecIO<S, VEC>::store(partial + cid * d.K + kk, o);
     if (OP == OP_MAX) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) a.partial_arg[cid * a.K + kk + i] = arg[i];
+      for (int i = 0; i < VEC; ++i) partial_arg[cid * d.K + kk + i] = arg[i];
     }
   }
 }
 
 template <typename T, int OP, int MODE>
-__global__ __launch_bounds__(kBlock) void long_final_kernel(const ReduceArgs a) {
-  using S = typename TT<T>::S;
+__global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__restrict__ rowptr,
+                                                            const int32_t *__restrict__ long_rows,
+                                                            const int64_t *__restrict__ chunk_ptr,
+                                                            const typename TT<T>::S *__restrict__ partial,
+                                                            const int64_t *__restrict__ partial_arg,
+                                                            typename TT<T>::S *__restrict__ out,
+                                                            int64_t *__restrict__ argout,
+                                                            const ReduceDims d) {
   using A = typename TT<T>::A;
   const int64_t j = blockIdx.x;  // one block per long row
-  const int64_t row = a.long_rows[j];
-  const int64_t c0 = a.chunk_ptr[j], c1 = a.chunk_ptr[j + 1];
-  const int64_t len = a.rowptr[row + 1] - a.rowptr[row];
-  const S *part = static_cast<const S *>(a.partial);
-  for (int64_t k = threadIdx.x; k < a.K; k += kBlock) {
+  const int64_t row = long_rows[j];
+  const int64_t c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
+  const int64_t len = rowptr[row + 1] - rowptr[row];
+  for (int64_t k = threadIdx.x; k < d.K; k += kBlock) {
     A acc[1];
     int64_t arg[1];
-    init_acc<T, 1, OP>(acc, arg, a.arg_fill);
+    init_acc<T, 1, OP>(acc, arg, d.arg_fill);
     for (int64_t c = c0; c < c1; ++c) {
-      const A v = TT<T>::load(part[c * a.K + k]);
+      const A v = TT<T>::load(partial[c * d.K + k]);
       if (OP == OP_MAX) {
         if (TT<T>::less(acc[0], v)) {  // strict <: the earliest chunk (smallest e) keeps ties
           acc[0] = v;
-          arg[0] = a.partial_arg[c * a.K + k];
+          arg[0] = partial_arg[c * d.K + k];
         }
       } else {
         acc[0] = TT<T>::add(acc[0], v);
       }
     }
-    finish_row<T, 1, OP, MODE>(a, row, len, k, acc, arg);
+    finish_row<T, 1, OP, MODE>(out, argout, d.K, row, len, k, acc, arg);
   }
 }
 
 // ---- host-side dispatch -------------------------------------------------------------------------
+struct ReduceArgs {  // host-side bundle: everything one logical op needs
+  const void *x;
+  const int32_t *perm;
+  const int32_t *col;
+  const float *w;
+  int w_by_pos;
+  const int64_t *rowptr;
+  int64_t N, K, E;
+  void *out;
+  int64_t *arg;
+  int64_t arg_fill;
+  int64_t chunk;
+  int64_t H, C;
+  const int64_t *aux_rowptr;
+  const int64_t *aux_arg;
+  const int32_t *long_rows;
+  const int64_t *chunk_ptr;
+  int64_t n_long, n_chunks;
+  void *partial;
+  int64_t *partial_arg;
+};
+
 static inline int pow2_ceil_log2(int64_t v) {
   int l = 0;
   while (((int64_t)1 << l) < v) ++l;
   return l;
 }
 
-template <typename T, int VEC, int OP, int MODE>
-static int launch_typed(ReduceArgs a, hipStream_t stream) {
-  const int64_t kv = ceil_div(a.K, VEC);
-  a.logL = pow2_ceil_log2(kv < kWave ? kv : kWave);
-  if (a.logL > 6) a.logL = 6;
-  const bool uniform = (a.logL == 6) && std::is_same<T, float>::value;
-  const int rows_per_block = kWavesPerBlock * (kWave >> a.logL);
-  a.nblocks = ceil_div(a.N, rows_per_block);
-  a.swizzle = (int)options().xcd_swizzle;
-  GGL_REQUIRE(a.nblocks < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
-  if (a.N > 0 && a.K > 0) {
-    if (uniform) {
-      if (options().unroll >= 8)
-        GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, true, 8>), a.nblocks, kBlock, stream, a);
-      else
-        GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, true, 4>), a.nblocks, kBlock, stream, a);
+#define GGL_RPTR_ARGS(S)                                                                           \
+  static_cast<const S *>(a.x), a.perm, a.col, a.w, a.rowptr, a.aux_rowptr, a.aux_arg
+
+template <typename T, int VEC, int OP, int MODE, int IDX>
+static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
+  using S = typename TT<T>::S;
+  const bool uniform = (d.logL == 6) && std::is_same<T, float>::value;
+  S *out = static_cast<S *>(a.out);
+  if (uniform) {
+    // the f32 wave-per-row kernels; U = 8 only for the dominant SpMM-sum (A/B knob)
+    if (std::is_same<T, float>::value && VEC == 4 && OP == OP_SUM && MODE == MODE_SPMM &&
+        options().unroll >= 8) {
+      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 8>),
+                 d.nblocks, kBlock, stream, GGL_RPTR_ARGS(S), out, a.arg, d);
     } else {
-      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, false, 4>), a.nblocks, kBlock, stream, a);
+      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 4>),
+                 d.nblocks, kBlock, stream, GGL_RPTR_ARGS(S), out, a.arg, d);
     }
+  } else {
+    GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 4>), d.nblocks, kBlock, stream,
+               GGL_RPTR_ARGS(S), out, a.arg, d);
+  }
+  GGL_LAUNCH_CHECK();
+  if (a.n_long > 0) {
+    GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
+    GGL_LAUNCH((long_chunk_kernel<T, VEC, OP, MODE, IDX, 4>), ceil_div(a.n_chunks, kWavesPerBlock),
+               kBlock, stream, GGL_RPTR_ARGS(S), a.long_rows, a.chunk_ptr,
+               static_cast<S *>(a.partial), a.partial_arg, d);
     GGL_LAUNCH_CHECK();
-    if (a.n_long > 0) {
-      GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
-      GGL_LAUNCH((long_chunk_kernel<T, VEC, OP, MODE, 4>), ceil_div(a.n_chunks, kWavesPerBlock),
-                 kBlock, stream, a);
-      GGL_LAUNCH_CHECK();
-      GGL_LAUNCH((long_final_kernel<T, OP, MODE>), a.n_long, kBlock, stream, a);
-      GGL_LAUNCH_CHECK();
-    }
+    GGL_LAUNCH((long_final_kernel<T, OP, MODE>), a.n_long, kBlock, stream, a.rowptr, a.long_rows,
+               a.chunk_ptr, static_cast<const S *>(a.partial), (const int64_t *)a.partial_arg, out,
+               a.arg, d);
+    GGL_LAUNCH_CHECK();
   }
   return GGL_OK;
+}
+
+// STATIC_IDX: compile-time index modes (hot f32 segment / SpMM kernels); otherwise IDX_RUNTIME
+template <typename T, int VEC, int OP, int MODE, bool STATIC_IDX>
+static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
+  ReduceDims d{};
+  d.N = a.N; d.K = a.K; d.E = a.E; d.arg_fill = a.arg_fill; d.chunk = a.chunk; d.H = a.H; d.C = a.C;
+  d.n_long = a.n_long; d.n_chunks = a.n_chunks; d.w_by_pos = a.w_by_pos;
+  const int64_t kv = ceil_div(a.K, VEC);
+  d.logL = pow2_ceil_log2(kv < kWave ? kv : kWave);
+  if (d.logL > 6) d.logL = 6;
+  const int rows_per_block = kWavesPerBlock * (kWave >> d.logL);
+  d.nblocks = ceil_div(a.N, rows_per_block);
+  d.swizzle = (int)options().xcd_swizzle;
+  GGL_REQUIRE(d.nblocks < ((int64_t)1 << 30), GGL_EINVAL, "too many rows for one launch");
+  if (a.N <= 0 || a.K <= 0) return GGL_OK;
+  if constexpr (!STATIC_IDX) {
+    return launch_idx<T, VEC, OP, MODE, IDX_RUNTIME>(a, d, stream);
+  } else if constexpr (MODE == MODE_SEG) {
+    if (a.perm) return launch_idx<T, VEC, OP, MODE, IDX_PERM>(a, d, stream);
+    return launch_idx<T, VEC, OP, MODE, IDX_DIRECT>(a, d, stream);
+  } else {
+    if (!a.w) return launch_idx<T, VEC, OP, MODE, IDX_NONE>(a, d, stream);
+    if (a.w_by_pos || !a.perm) return launch_idx<T, VEC, OP, MODE, IDX_DIRECT>(a, d, stream);
+    return launch_idx<T, VEC, OP, MODE, IDX_PERM>(a, d, stream);
+  }
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int OP, int MODE>
-static int launch_f32(ReduceArgs a, hipStream_t stream) {
+static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
+  constexpr bool kStatic = (MODE == MODE_SEG || MODE == MODE_SPMM);
   const bool vec4 = !options().force_generic && (a.K % 4 == 0) && aligned16(a.x) &&
                     aligned16(a.out) && (!a.partial || aligned16(a.partial)) &&
                     (MODE != MODE_BSPMM || a.C % 4 == 0);
-  if (vec4) return launch_typed<float, 4, OP, MODE>(a, stream);
-  return launch_typed<float, 1, OP, MODE>(a, stream);
+  if (vec4) return launch_typed<float, 4, OP, MODE, kStatic>(a, stream);
+  return launch_typed<float, 1, OP, MODE, kStatic>(a, stream);
 }
 
 template <int OP>
-static int launch_seg(int dtype, ReduceArgs a, hipStream_t stream) {
+static int launch_seg(int dtype, const ReduceArgs &a, hipStream_t stream) {
   switch (dtype) {
     case GGL_F32: return launch_f32<OP, MODE_SEG>(a, stream);
-    case GGL_F64: return launch_typed<double, 1, OP, MODE_SEG>(a, stream);
-    case GGL_F16: return launch_typed<f16_t, 1, OP, MODE_SEG>(a, stream);
-    case GGL_BF16: return launch_typed<bf16_t, 1, OP, MODE_SEG>(a, stream);
-    case GGL_U8: return launch_typed<uint8_t, 1, OP, MODE_SEG>(a, stream);
-    case GGL_I8: return launch_typed<int8_t, 1, OP, MODE_SEG>(a, stream);
-    case GGL_I16: return launch_typed<int16_t, 1, OP, MODE_SEG>(a, stream);
-    case GGL_I32: return launch_typed<int32_t, 1, OP, MODE_SEG>(a, stream);
-    case GGL_I64: return launch_typed<int64_t, 1, OP, MODE_SEG>(a, stream);
+    case GGL_F64: return launch_typed<double, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_F16: return launch_typed<f16_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_BF16: return launch_typed<bf16_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_U8: return launch_typed<uint8_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_I8: return launch_typed<int8_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_I16: return launch_typed<int16_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_I32: return launch_typed<int32_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_I64: return launch_typed<int64_t, 1, OP, MODE_SEG, false>(a, stream);
     default: set_error("unsupported dtype code %d", dtype); return GGL_EDTYPE;
   }
 }

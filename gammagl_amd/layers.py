@@ -1,0 +1,243 @@
+"""Harness-side callers of the hot path: torch restatements of the
+reference layers that sit directly on ``gammagl.mpops`` — just enough of them to drive the ops the
+way GammaGL does.  The reference classes are TensorLayerX modules (``tlx`` is not installable
+here); every tlx call they make on this path maps 1:1 onto torch (``tlx.gather`` = index_select,
+``tlx.pow``, ``tlx.reshape`` ...), so these are line-for-line the same computations:
+
+* ``MessagePassing``  — layers/conv/message_passing.py:35-156 (message / aggregate /
+  message_aggregate / propagate, including the "fused route only if the class defines
+  message_aggregate itself" rule at :144)
+* ``GCNConv``         — layers/conv/gcn_conv.py:78-115, with the reference's own (commented-out)
+  ``message_aggregate`` -> ``gspmm`` override at :110-115 enabled, which is what makes
+  ogbn-products-sized graphs fit one GPU (the unfused route materialises an [E,K] = 129 GB message)
+* ``SAGEConv``        — layers/conv/sage_conv.py:56-108 ('mean', 'gcn' and 'pool' aggregators)
+* ``GATConv``         — layers/conv/gat_conv.py:98-122 (unfused: segment_softmax + propagate)
+* ``FusedGATConv``    — layers/conv/fusedgat_conv.py:89-130 with our single-kernel op in place of
+  the external dgNN GATConvFuse
+* ``GCNModel``        — models/gcn.py:30-64
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import engine as _engine
+from . import mpops
+from .mpops import (gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
+                    unsorted_segment_sum, use_ext)
+
+
+def degree(index, num_nodes, dtype=torch.float32):
+    """utils/degree.py:10-40: unsorted_segment_sum(ones[E], index, N) (K = 1)."""
+    one = torch.ones((index.shape[0],), dtype=dtype, device=index.device)
+    return unsorted_segment_sum(one, index, num_nodes)
+
+
+def calc_gcn_norm(edge_index, num_nodes, edge_weight=None):
+    """utils/norm.py:5-30."""
+    src, dst = edge_index[0], edge_index[1]
+    if edge_weight is None:
+        edge_weight = torch.ones((edge_index.shape[1], 1), device=edge_index.device)
+    deg = unsorted_segment_sum(edge_weight, src, num_segments=num_nodes).reshape(-1)
+    deg_inv_sqrt = deg.pow(-0.5)
+    return deg_inv_sqrt[src] * edge_weight.reshape(-1) * deg_inv_sqrt[dst]
+
+
+def segment_softmax(data, segment_ids, num_segments):
+    """utils/softmax.py:10-36."""
+    max_values = unsorted_segment_max(data, segment_ids, num_segments=num_segments)
+    exp = torch.exp(data - max_values[segment_ids])
+    denominator = unsorted_segment_sum(exp, segment_ids, num_segments=num_segments)
+    return exp / (denominator[segment_ids] + 1e-16)
+
+
+def add_self_loops(edge_index, num_nodes):
+    """utils/loop.py:57-142 with n_loops=1, no edge attributes: loops are appended at the end."""
+    loops = torch.arange(num_nodes, device=edge_index.device, dtype=edge_index.dtype)
+    return torch.cat([edge_index, torch.stack([loops, loops])], dim=1)
+
+
+class MessagePassing(nn.Module):
+    def message(self, x, edge_index, edge_weight=None):
+        msg = x.index_select(0, edge_index[0, :])
+        if edge_weight is not None:
+            return msg * edge_weight.unsqueeze(-1)
+        return msg
+
+    def aggregate(self, msg, edge_index, num_nodes=None, aggr='sum'):
+        dst_index = edge_index[1, :]
+        if aggr == 'sum':
+            return unsorted_segment_sum(msg, dst_index, num_nodes)
+        elif aggr == 'mean':
+            return unsorted_segment_mean(msg, dst_index, num_nodes)
+        elif aggr == 'max':
+            return unsorted_segment_max(msg, dst_index, num_nodes)
+        raise NotImplementedError('Not support for this opearator')
+
+    def message_aggregate(self, x, edge_index, edge_weight=None, aggr='sum'):
+        if use_ext:
+            if edge_weight is None:
+                edge_weight = torch.ones(edge_index.shape[1], device=x.device, dtype=x.dtype)
+            return gspmm(edge_index, edge_weight, x, aggr)
+        msg = self.message(x, edge_index, edge_weight)
+        return self.aggregate(msg, edge_index)
+
+    def update(self, x):
+        return x
+
+    def propagate(self, x, edge_index, aggr='sum', **kwargs):
+        if kwargs.get('num_nodes') is None:
+            kwargs['num_nodes'] = x.shape[0]
+        if 'message_aggregate' in self.__class__.__dict__:  # message_passing.py:144
+            x = self.message_aggregate(x, edge_index, edge_weight=kwargs.get('edge_weight'), aggr=aggr)
+        else:
+            msg = self.message(x, edge_index, edge_weight=kwargs.get('edge_weight'))
+            x = self.aggregate(msg, edge_index, num_nodes=kwargs['num_nodes'], aggr=aggr)
+        return self.update(x)
+
+
+class GCNConv(MessagePassing):
+    def __init__(self, in_channels, out_channels, norm='both', add_bias=True):
+        super().__init__()
+        if norm not in ['left', 'right', 'none', 'both']:
+            raise ValueError('Invalid norm value. Must be either "none", "both", "right" or "left".'
+                             ' But got "{}".'.format(norm))
+        self._norm = norm
+        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+        nn.init.xavier_uniform_(self.linear.weight)
+        self.bias = nn.Parameter(torch.zeros(1, out_channels)) if add_bias else None
+
+    def forward(self, x, edge_index, edge_weight=None, num_nodes=None):
+        x = self.linear(x)
+        src, dst = edge_index[0], edge_index[1]
+        if edge_weight is None:
+            edge_weight = torch.ones((edge_index.shape[1],), device=x.device)
+        edge_weight = edge_weight.reshape(-1)
+        weights = edge_weight
+        num_nodes = x.shape[0]
+        if self._norm in ['left', 'both']:
+            deg = degree(src, num_nodes=num_nodes, dtype=torch.float32)
+            norm = deg.pow(-0.5) if self._norm == 'both' else 1.0 / deg
+            weights = norm[src] * edge_weight
+        if self._norm in ['right', 'both']:
+            deg = degree(dst, num_nodes=num_nodes, dtype=torch.float32)
+            norm = deg.pow(-0.5) if self._norm == 'both' else 1.0 / deg
+            weights = weights * norm[dst]
+        out = self.propagate(x, edge_index, edge_weight=weights, num_nodes=num_nodes)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+    def message_aggregate(self, x, edge_index, edge_weight=None, aggr="sum"):  # gcn_conv.py:110-115
+        if edge_weight is None:
+            edge_weight = torch.ones((edge_index.shape[1],), dtype=torch.float32, device=x.device)
+        return gspmm(edge_index, edge_weight, x, aggr)
+
+
+class SAGEConv(MessagePassing):
+    def __init__(self, in_channels, out_channels, activation=None, aggr="mean", add_bias=True):
+        super().__init__()
+        self.aggr = aggr
+        self.act = activation
+        self.fc_neigh = nn.Linear(in_channels, out_channels, bias=False)
+        if aggr != 'gcn':
+            self.fc_self = nn.Linear(in_channels, out_channels, bias=False)
+        if aggr == 'pool':
+            self.pool = nn.Linear(in_channels, in_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(1, out_channels)) if add_bias else None
+
+    def forward(self, feat, edge):
+        src_feat, dst_feat = feat if isinstance(feat, tuple) else (feat, feat)
+        num_nodes = int(dst_feat.shape[0])
+        if self.aggr == 'mean':
+            src_feat = self.fc_neigh(src_feat)
+            out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='mean')
+        elif self.aggr == 'gcn':
+            src_feat = self.fc_neigh(src_feat)
+            n = int(1 + edge[0].max())
+            edge = add_self_loops(edge, n)
+            weight = calc_gcn_norm(edge, n)
+            out = self.propagate(src_feat, edge, edge_weight=weight, num_nodes=n, aggr='sum')
+            out = out[:num_nodes]
+        elif self.aggr == 'pool':
+            src_feat = torch.relu(self.pool(src_feat))
+            out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='max')
+            out = self.fc_neigh(out)
+        else:
+            raise NotImplementedError(self.aggr)
+        if self.aggr != 'gcn':
+            out = out + self.fc_self(dst_feat)
+        if self.bias is not None:
+            out = out + self.bias
+        return self.act(out) if self.act is not None else out
+
+
+class GATConv(MessagePassing):
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, add_bias=True):
+        super().__init__()
+        self.heads, self.out_channels, self.concat = heads, out_channels, concat
+        self.negative_slope = negative_slope
+        self.w = nn.Parameter(torch.empty(in_channels, out_channels * heads))
+        self.att = nn.Parameter(torch.empty(1, heads, out_channels * 2))
+        nn.init.trunc_normal_(self.w, std=0.05)
+        nn.init.trunc_normal_(self.att, std=0.05)
+        nb = heads * out_channels if concat else out_channels
+        self.bias = nn.Parameter(torch.zeros(nb)) if add_bias else None
+
+    def _finish(self, x):
+        if self.concat:
+            x = x.reshape(-1, self.heads * self.out_channels)
+        else:
+            x = x.mean(dim=1)
+        return x + self.bias if self.bias is not None else x
+
+    def forward(self, x, edge_index, num_nodes=None):
+        x = (x @ self.w).reshape(-1, self.heads, self.out_channels)
+        node_src, node_dst = edge_index[0, :], edge_index[1, :]
+        feat = torch.cat((x[node_src], x[node_dst]), dim=-1)
+        e = (feat * self.att).sum(dim=-1)
+        e = torch.nn.functional.leaky_relu(e, self.negative_slope)
+        alpha = segment_softmax(e, node_dst, num_nodes)
+        x = self.propagate(x, edge_index, num_nodes=num_nodes, edge_weight=alpha)
+        return self._finish(x)
+
+
+class FusedGATConv(GATConv):
+    """Same parameters and math as GATConv; logits, softmax and aggregate run in one HIP kernel."""
+
+    def forward(self, x, edge_index, num_nodes=None):
+        x = (x @ self.w).reshape(-1, self.heads, self.out_channels)
+        C = self.out_channels
+        el = (x * self.att[:, :, :C]).sum(dim=-1)   # source term  a_src . x_j
+        er = (x * self.att[:, :, C:]).sum(dim=-1)   # destination term a_dst . x_i
+        x = _engine().gat_fused(edge_index, el, er, x, self.negative_slope, num_nodes=num_nodes)
+        return self._finish(x)
+
+
+class GCNModel(nn.Module):
+    """models/gcn.py:30-64."""
+
+    def __init__(self, feature_dim, hidden_dim, num_class, drop_rate=0.2, num_layers=2, norm='both'):
+        super().__init__()
+        self.num_layers = num_layers
+        if num_layers == 1:
+            self.conv = nn.ModuleList([GCNConv(feature_dim, num_class, norm=norm)])
+        else:
+            self.conv = nn.ModuleList([GCNConv(feature_dim, hidden_dim, norm=norm)])
+            for _ in range(1, num_layers - 1):
+                self.conv.append(GCNConv(hidden_dim, hidden_dim, norm=norm))
+            self.conv.append(GCNConv(hidden_dim, num_class, norm=norm))
+        self.dropout = nn.Dropout(drop_rate)
+
+    def forward(self, x, edge_index, edge_weight, num_nodes):
+        if self.num_layers == 1:
+            return self.conv[0](x, edge_index, edge_weight, num_nodes)
+        for i in range(self.num_layers - 1):
+            x = self.conv[i](x, edge_index, edge_weight, num_nodes)
+            x = torch.relu(x)
+            x = self.dropout(x)
+        return self.conv[-1](x, edge_index, edge_weight, num_nodes)
+
+
+__all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "degree",
+           "calc_gcn_norm", "segment_softmax", "add_self_loops", "mpops", "math"]

@@ -68,7 +68,9 @@ class GraphPlan:
         self.index = index
         self.N_dst, self.N_src = int(n_dst), int(n_src)
         self.E = int(index.shape[1])
-        self.fwd = engine.build_plan(index[1], self.N_dst)
+        # shared with the segment-op cache: degree(dst) / unsorted_segment_*(.., edge_index[1], N)
+        # on the same edge list reuse this very plan (and vice versa)
+        self.fwd = engine.seg_plan(index[1], self.N_dst)
         engine._check_range(index[0], self.N_src)
         self.col = engine.gather_i32(index[0], self.fwd.perm)
         self._bwd = self._colT = self._posT = None
@@ -76,7 +78,7 @@ class GraphPlan:
     @property
     def bwd(self):
         if self._bwd is None:
-            self._bwd = self.engine.build_plan(self.index[0], self.N_src)
+            self._bwd = self.engine.seg_plan(self.index[0], self.N_src)
             self._colT = self.engine.gather_i32(self.index[1], self._bwd.perm)
         return self._bwd
 

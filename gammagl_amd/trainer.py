@@ -1,0 +1,28 @@
+"""Training-step harness: what examples/gcn/gcn_trainer.py:51-117 does per
+epoch — SemiSpvzLoss (forward, gather train rows, softmax cross-entropy) + TrainOneStep (backward,
+Adam with weight decay) — in plain torch around the gammagl_amd layers."""
+import torch
+import torch.nn.functional as F
+
+from .layers import GCNModel
+
+
+class GCNTrainer:
+    def __init__(self, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, lr=0.01,
+                 l2_coef=5e-4, norm="both", seed=0, device="cuda"):
+        torch.manual_seed(seed)
+        self.net = GCNModel(feature_dim, hidden_dim, num_class, drop_rate=drop_rate,
+                            num_layers=num_layers, norm=norm).to(device)
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef)
+
+    def loss(self, x, edge_index, y, train_idx, num_nodes):
+        logits = self.net(x, edge_index, None, num_nodes)
+        return F.cross_entropy(logits[train_idx], y[train_idx])
+
+    def step(self, x, edge_index, y, train_idx, num_nodes):
+        self.net.train()
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.loss(x, edge_index, y, train_idx, num_nodes)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
