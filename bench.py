@@ -4,16 +4,20 @@ ogbn-products-sized synthetic graph, MI355X, through the gammagl_amd HIP kernels
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE JSON line on rank 0.
 
-* a "step" = one full training step of GCNModel(100 -> 256 -> 256 -> 47) exactly as
-  examples/gcn/gcn_trainer.py runs it (forward with per-layer degree normalisation, ReLU, dropout,
-  softmax cross-entropy on the train nodes, backward, Adam with weight decay) over the whole graph;
-  every step aggregates 6 x E edges (3 forward SpMMs + 3 transposed SpMMs in backward);
-* value = 6 * E * K / (time of K steps) over the whole job (all ranks), inputs resident in HBM;
-* roofline = the dominant kernel (CSR SpMM-sum, feature width 256, forward) timed with hipEvents on
-  its launch stream: algorithmic bytes E*(4*256+8) + N*(4*256+8) per launch (SURVEY.md §8d) / time;
-* cpu_baseline = the reference's own CPU extension (oracle/_ref, built from the reference sources;
-  falls back to our C restatement) running the same 6 aggregations on a bounded R-MAT sample, 1 core
-  (the shipped extension is serial: setup.py:50 never defines its OpenMP macro).
+* a "step" = one full training step of GCNModel(100 -> 256 -> 256 -> 47, norm='none') on
+  precomputed symmetric-normalised edge weights (edge_weight = calc_gcn_norm(edge_index), the
+  configuration examples/gcn/gcn_trainer.py:59 sketches) over the whole graph: forward (Linear ->
+  aggregate -> +bias -> ReLU -> dropout per layer), softmax cross-entropy on the train nodes,
+  backward, Adam with weight decay.  Every step aggregates 6 x E edges: 3 forward CSR SpMMs + 3
+  transposed SpMMs in backward.  Same code path for every N (N = 1: no halo exchange);
+* value = 6 * E * steps / time over the whole job (max over ranks), inputs resident in HBM;
+  scaling = "strong": the graph is fixed and node-partitioned over the N GPUs;
+* roofline = the dominant kernel (CSR SpMM-sum, feature width 256, forward, rank 0's rows) timed
+  with hipEvents on its launch stream: algorithmic bytes E*(4*256+8) + N*(4*256+8) per launch
+  (SURVEY.md §8d) / time, against the 8 TB/s HBM3E peak;
+* cpu_baseline (N = 1 only) = the reference's own CPU extension (oracle/_ref, compiled from the
+  reference sources; our C restatement if it is absent) running the same 6 aggregations on a bounded
+  R-MAT sample, 1 core (the shipped extension is serial: setup.py:50 never defines its OpenMP macro).
 """
 import argparse
 import json
@@ -26,14 +30,12 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default=os.environ.get("GGL_BENCH_WORKLOAD", "products"),
                    help="products | arxiv | tiny  (node/edge counts of the named dataset, R-MAT)")
     p.add_argument("--hidden", type=int, default=256)
@@ -51,7 +53,7 @@ def cpu_baseline(hidden, classes, seed):
     from gammagl_amd.synth import rmat_graph
     from oracle import oracle as orc
 
-    n_s, e_s = 40000, 1_500_000
+    n_s, e_s = 400000, 16_000_000
     ei = rmat_graph(n_s, e_s, seed=seed + 17, device="cpu")
     E = ei.shape[1]
     gen = torch.Generator().manual_seed(seed)
@@ -69,7 +71,7 @@ def cpu_baseline(hidden, classes, seed):
         kind = "reference"
         eiT = ei.flip(0).contiguous()
         for x in feats:
-            ref.c_spmm_sum(ei, w, x)        # forward aggregate
+            ref.c_spmm_sum(ei, w, x)        # forward aggregate (spmm_sum_cpu_forward)
             ref.c_spmm_sum(eiT, w, x)       # backward = the same loop on the transposed edge list
     else:
         kind = "port"
@@ -79,11 +81,11 @@ def cpu_baseline(hidden, classes, seed):
             orc.spmm_sum_fwd(ein, wn, x.numpy())
             orc.spmm_sum_bwd(ein, wn, x.numpy())
     dt = time.perf_counter() - t0
+    impl = "reference c_spmm_sum (oracle/_ref)" if kind == "reference" else "oracle C port"
     return {
         "value": 6 * E / dt, "unit": "edges/s", "cores": 1, "kind": kind,
         "sample": f"R-MAT N={n_s} E={E} (loops incl.), the 6 aggregations of one 3-layer GCN step "
-                  f"(K={widths} fwd + transposed bwd), {'reference c_spmm_sum (oracle/_ref)' if kind == 'reference' else 'oracle C port'}, "
-                  f"{dt:.1f} s on 1 core of {os.cpu_count()}",
+                  f"(K={widths} fwd + transposed bwd), {impl}, {dt:.1f} s on 1 core of {os.cpu_count()}",
     }
 
 
@@ -101,79 +103,23 @@ def main():
 
         dist.init_process_group("nccl", device_id=dev)
 
-    from gammagl_amd import engine
-    from gammagl_amd.synth import DATASETS, rmat_graph
+    from gammagl_amd.dist import run_distributed_bench
+    from gammagl_amd.synth import DATASETS
 
-    eng = engine()
     if args.workload == "tiny":
         n_nodes, n_edges, f_in, n_cls = 20000, 400000, 100, 47
     else:
         n_nodes, n_edges, f_in, n_cls = DATASETS[args.workload]
-        if args.workload == "arxiv":
-            pass
-
+    out = run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.hidden, n_cls, args.seed)
+        print(json.dumps(out))
     if world > 1:
-        from gammagl_amd.dist import run_distributed_bench
+        import torch.distributed as dist
 
-        out = run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls)
-        if rank == 0:
-            print(json.dumps(out))
-        return
-
-    from gammagl_amd.trainer import GCNTrainer
-
-    t_gen = time.perf_counter()
-    ei = rmat_graph(n_nodes, n_edges, seed=args.seed, device=dev, relabel=args.relabel, order=args.order)
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
-    E = int(ei.shape[1])
-    gen = torch.Generator(device=dev).manual_seed(args.seed)
-    x = torch.randn(n_nodes, f_in, generator=gen, device=dev)
-    y = torch.randint(0, n_cls, (n_nodes,), generator=gen, device=dev)
-    train_idx = torch.randperm(n_nodes, generator=gen, device=dev)[: max(1, int(0.08 * n_nodes))]
-    tr = GCNTrainer(f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev)
-
-    for _ in range(args.warmup):
-        tr.step(x, ei, y, train_idx, n_nodes)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = tr.step(x, ei, y, train_idx, n_nodes)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    n_agg = 2 * args.layers
-    value = n_agg * E * args.steps / dt
-
-    # dominant kernel, live: forward SpMM-sum at K = hidden on the real plan and the real weights
-    gp = eng.graph_plan(ei, n_nodes)
-    from gammagl_amd.layers import calc_gcn_norm
-
-    w = calc_gcn_norm(ei, n_nodes).contiguous()
-    h = torch.randn(n_nodes, args.hidden, generator=gen, device=dev)
-    ms = eng.time_spmm_sum(gp, w, h, reps=10)
-    K = args.hidden
-    alg_bytes = E * (4 * K + 8) + n_nodes * (4 * K + 8)
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
-    roof = {"bound": "hbm", "kernel": "row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, K=%d)" % K,
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "ms_per_launch": ms, "alg_bytes_per_launch": alg_bytes,
-            "edges_per_s_kernel": E / (ms * 1e-3)}
-
-    out = {
-        "metric": "edges aggregated/sec, 3-layer GCN hidden=256 training step, ogbn-products-sized graph",
-        "value": value, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}-sized R-MAT: N={n_nodes}, E={E} directed incl. self-loops, "
-                               f"features {f_in}->{args.hidden}x{args.layers - 1}->{n_cls}, edge order={args.order}, "
-                               f"relabel={args.relabel}, full-graph GCN train step (fwd+bwd+Adam), "
-                               f"{n_agg} aggregations/step",
-                   "parallelism": "1 GPU", "graph_gen_s": round(t_gen, 2), "loss": float(loss)},
-        "roofline": roof,
-    }
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.hidden, n_cls, args.seed)
-    print(json.dumps(out))
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SegPlanC(ctypes.Structure):
@@ -21,7 +21,7 @@ class SegPlanC(ctypes.Structure):
     _fields_ = [
         ("rowptr", c_void_p), ("perm", c_void_p), ("long_rows", c_void_p), ("chunk_ptr", c_void_p),
         ("n_long", c_int64), ("n_chunks", c_int64), ("chunk", c_int64), ("partial", c_void_p),
-        ("N", c_int64), ("E", c_int64),
+        ("N", c_int64), ("E", c_int64), ("row_order", c_void_p),
     ]
 
 
@@ -57,6 +57,8 @@ SIGNATURES = {
     "ggl_spmm_max_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
     "ggl_bspmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, _V]),
     "ggl_bspmm_grad_w": (c_int, [_V, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
+    "ggl_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ggl_colsum_f32": (c_int, [_V, c_int64, c_int64, _V, _V, c_size_t, _V]),
     "ggl_gat_fused_fwd": (c_int, [_P, _V, _V, _V, _V, c_float, c_int64, c_int64, _V, _V, _V, _V]),
     "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,
                                       _V, _V, _V, _V]),

@@ -161,6 +161,82 @@ extern "C" int ggl_segment_max_bwd(int dtype, const void *gout, const int64_t *a
   return GGL_OK;
 }
 
+// ---- column sums of a row-major [N,K] f32 matrix (bias gradient), two deterministic stages ----------
+// stage 1: block b owns rows [b*R, (b+1)*R); its threads are G = 256 / Kp groups of Kp lanes
+//          (Kp = min(K, 256)); group j accumulates rows b*R + j, + G, ... for its columns, in order,
+//          and writes partial[(b*G + j), k].  stage 2: one thread per column adds the partials in
+//          order.  No atomics, no LDS: the result does not depend on scheduling.
+__global__ __launch_bounds__(kBlock) void colsum_stage1_kernel(const float *__restrict__ g, int64_t N,
+                                                               int64_t K, int64_t rows_per_block,
+                                                               int kp, int groups,
+                                                               float *__restrict__ partial) {
+  const int j = threadIdx.x / kp;
+  const int k0 = threadIdx.x - j * kp;
+  if (j >= groups) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+  for (int64_t k = k0; k < K; k += kp) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains, combined in a fixed order
+    int64_t r = r0 + j;
+    for (; r + 3 * (int64_t)groups < r1; r += 4 * (int64_t)groups) {
+      a0 = __fadd_rn(a0, g[r * K + k]);
+      a1 = __fadd_rn(a1, g[(r + groups) * K + k]);
+      a2 = __fadd_rn(a2, g[(r + 2 * (int64_t)groups) * K + k]);
+      a3 = __fadd_rn(a3, g[(r + 3 * (int64_t)groups) * K + k]);
+    }
+    for (; r < r1; r += groups) a0 = __fadd_rn(a0, g[r * K + k]);
+    partial[((int64_t)blockIdx.x * groups + j) * K + k] = __fadd_rn(__fadd_rn(a0, a1), __fadd_rn(a2, a3));
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void colsum_stage2_kernel(const float *__restrict__ partial,
+                                                               int64_t P, int64_t K,
+                                                               float *__restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float a = 0.f;
+  for (int64_t p = 0; p < P; ++p) a = __fadd_rn(a, partial[p * K + k]);
+  out[k] = a;
+}
+
+static inline void colsum_geometry(int64_t N, int64_t K, int *kp, int *groups, int64_t *blocks,
+                                   int64_t *rows_per_block) {
+  *kp = (int)(K < kBlock ? (K > 0 ? K : 1) : kBlock);
+  *groups = kBlock / *kp;
+  int64_t b = ceil_div(N > 0 ? N : 1, (int64_t)*groups * 64);  // >= 64 rows per group
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  *blocks = b;
+  *rows_per_block = ceil_div(N > 0 ? N : 1, b);
+}
+
+extern "C" size_t ggl_colsum_workspace_bytes(int64_t N, int64_t K) {
+  int kp, groups;
+  int64_t blocks, rpb;
+  colsum_geometry(N, K, &kp, &groups, &blocks, &rpb);
+  return (size_t)blocks * (size_t)groups * (size_t)(K > 0 ? K : 1) * sizeof(float);
+}
+
+extern "C" int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+  GGL_REQUIRE(N >= 0 && K >= 0, GGL_EINVAL, "negative size");
+  if (K == 0) return GGL_OK;
+  GGL_REQUIRE(out != nullptr && (g != nullptr || N == 0), GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_colsum_workspace_bytes(N, K), GGL_EWORKSPACE,
+              "colsum workspace too small");
+  int kp, groups;
+  int64_t blocks, rpb;
+  colsum_geometry(N, K, &kp, &groups, &blocks, &rpb);
+  hipStream_t s = as_stream(stream);
+  float *partial = static_cast<float *>(workspace);
+  GGL_LAUNCH((colsum_stage1_kernel), blocks, kBlock, s, g, N, K, rpb, kp, groups, partial);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((colsum_stage2_kernel), ceil_div(K, kBlock), kBlock, s, (const float *)partial,
+             blocks * groups, K, out);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
 extern "C" int ggl_bspmm_grad_w(const int64_t *index, const float *x, const float *g, int64_t E,
                                 int64_t H, int64_t C, float *gw, void *stream) {
   GGL_REQUIRE(E >= 0 && H > 0 && C > 0, GGL_EINVAL, "bad sizes");

@@ -56,8 +56,14 @@ void set_error(const char *fmt, ...);
 
 struct Options {
   int64_t unroll = 4;        // neighbour loads in flight per lane in the f32 fast path (4 or 8)
-  int64_t xcd_swizzle = 1;   // give each XCD a contiguous range of row blocks (private L2 locality)
+  // 1 = give each XCD a contiguous range of row blocks (private-L2 locality).  OFF by default: measured
+  // on MI355X (profiles/kbench_r1.txt) it changes nothing on a randomly ordered graph and is 4x SLOWER
+  // on a degree-ordered one (one XCD inherits all the hub rows); round-robin is the load balancer.
+  int64_t xcd_swizzle = 0;
   int64_t force_generic = 0; // route f32 through the VEC=1 generic kernel (A/B aid)
+  // 0 = natural row order; 1 = length-sorted rows where several rows share a wavefront (balances
+  // the lanes of a wave); 2 = also for the wave-per-row kernels (heavy rows first)
+  int64_t row_order = 1;
   int64_t rows_per_block_log2 = -1;  // reserved
 };
 Options &options();

@@ -41,6 +41,7 @@ Options &options() {
     t.unroll = env_i64("GGL_UNROLL", t.unroll);
     t.xcd_swizzle = env_i64("GGL_XCD_SWIZZLE", t.xcd_swizzle);
     t.force_generic = env_i64("GGL_FORCE_GENERIC", t.force_generic);
+    t.row_order = env_i64("GGL_ROW_ORDER", t.row_order);
     return t;
   }();
   return o;
@@ -219,6 +220,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   if (!strcmp(name, "unroll")) o.unroll = value;
   else if (!strcmp(name, "xcd_swizzle")) o.xcd_swizzle = value;
   else if (!strcmp(name, "force_generic")) o.force_generic = value;
+  else if (!strcmp(name, "row_order")) o.row_order = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
 }
@@ -228,6 +230,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "unroll")) return o.unroll;
   if (!strcmp(name, "xcd_swizzle")) return o.xcd_swizzle;
   if (!strcmp(name, "force_generic")) return o.force_generic;
+  if (!strcmp(name, "row_order")) return o.row_order;
   return -1;
 }
 

@@ -50,6 +50,7 @@ struct ReduceDims {
   int64_t nblocks;
   int64_t H, C;
   int64_t n_long, n_chunks;
+  int64_t chunk_blocks;  // leading blocks of the launch that reduce long-row chunks
   int logL;
   int swizzle;
   int w_by_pos;
@@ -216,82 +217,83 @@ __device__ __forceinline__ void finish_row(typename TT<T>::S *__restrict__ out,
       const int64_t *__restrict__ aux_rowptr, const int64_t *__restrict__ aux_arg
 #define GGL_RPTR_PACK(S) RPtrs<S> q{x, perm, col, w, rowptr, aux_rowptr, aux_arg}
 
-// ---- main kernel: every row with len <= chunk ---------------------------------------------------
+// ---- the one launch: chunks of long rows first, then every row with len <= chunk -----------------
+// Blocks [0, chunk_blocks) each reduce 4 chunks of long rows (one wavefront per chunk) into the
+// partial buffer; they carry the lowest block ids so the hub work is dispatched first and the tail
+// of the launch is made of short rows.  Blocks [chunk_blocks, chunk_blocks + nblocks) own rows.
+// long_final_kernel then combines the partials of each long row in chunk order.
 template <typename T, int VEC, int OP, int MODE, int IDX, bool UNIFORM, int U>
 __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(typename TT<T>::S),
-                                                            typename TT<T>::S *__restrict__ out,
-                                                            int64_t *__restrict__ argout,
-                                                            const ReduceDims d) {
-  using A = typename TT<T>::A;
-  GGL_RPTR_PACK(typename TT<T>::S);
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  const int64_t blk = xcd_remap((int64_t)blockIdx.x, d.nblocks, d.swizzle);
-  const int L = 1 << d.logL;
-  int64_t row;
-  int li;
-  if (UNIFORM) {  // one wavefront per row: everything about the row is wave-uniform (scalar path)
-    const int r32 = __builtin_amdgcn_readfirstlane((int)(blk * kWavesPerBlock + wave));
-    row = (int64_t)(uint32_t)r32;  // nblocks * 4 < 2^32 is checked at launch
-    li = lane;
-  } else {
-    const int rows_per_wave = kWave >> d.logL;
-    row = (blk * kWavesPerBlock + wave) * rows_per_wave + (lane >> d.logL);
-    li = lane & (L - 1);
-  }
-  if (row >= d.N) return;
-  const int64_t beg = rowptr[row], end = rowptr[row + 1];
-  const int64_t len = end - beg;
-  if (len > d.chunk) return;  // long row: handled by long_chunk_kernel + long_final_kernel
-  for (int64_t kk = (int64_t)li * VEC; kk < d.K; kk += (int64_t)L * VEC) {
-    A acc[VEC];
-    int64_t arg[VEC];
-    init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
-    reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
-    finish_row<T, VEC, OP, MODE>(out, argout, d.K, row, len, kk, acc, arg);
-  }
-}
-
-// ---- long rows: one wavefront per chunk, then an ordered combine --------------------------------
-template <typename T, int VEC, int OP, int MODE, int IDX, int U>
-__global__ __launch_bounds__(kBlock) void long_chunk_kernel(GGL_RPTR_PARAMS(typename TT<T>::S),
+                                                            const int32_t *__restrict__ row_order,
                                                             const int32_t *__restrict__ long_rows,
                                                             const int64_t *__restrict__ chunk_ptr,
                                                             typename TT<T>::S *__restrict__ partial,
                                                             int64_t *__restrict__ partial_arg,
+                                                            typename TT<T>::S *__restrict__ out,
+                                                            int64_t *__restrict__ argout,
                                                             const ReduceDims d) {
   using S = typename TT<T>::S;
   using A = typename TT<T>::A;
   GGL_RPTR_PACK(S);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int c32 = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * kWavesPerBlock + wave));
-  const int64_t cid = (int64_t)(uint32_t)c32;
-  if (cid >= d.n_chunks) return;
-  // owning long row: last j with chunk_ptr[j] <= cid
-  int64_t lo = 0, hi = d.n_long - 1;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi + 1) >> 1;
-    if (chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
+  if ((int64_t)blockIdx.x < d.chunk_blocks) {
+    const int c32 = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * kWavesPerBlock + wave));
+    const int64_t cid = (int64_t)(uint32_t)c32;
+    if (cid >= d.n_chunks) return;
+    // owning long row: last j with chunk_ptr[j] <= cid
+    int64_t lo = 0, hi = d.n_long - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
+    }
+    const int64_t row = long_rows[lo];
+    const int64_t local = cid - chunk_ptr[lo];
+    const int64_t rbeg = rowptr[row], rend = rowptr[row + 1];
+    const int64_t beg = rbeg + local * d.chunk;
+    const int64_t end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
+    for (int64_t kk = (int64_t)lane * VEC; kk < d.K; kk += (int64_t)kWave * VEC) {
+      A acc[VEC];
+      int64_t arg[VEC];
+      init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
+      reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
+      S o[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
+      VecIO<S, VEC>::store(partial + cid * d.K + kk, o);
+      if (OP == OP_MAX) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) partial_arg[cid * d.K + kk + i] = arg[i];
+      }
+    }
+    return;
   }
-  const int64_t row = long_rows[lo];
-  const int64_t local = cid - chunk_ptr[lo];
-  const int64_t rbeg = rowptr[row], rend = rowptr[row + 1];
-  const int64_t beg = rbeg + local * d.chunk;
-  const int64_t end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
-  for (int64_t kk = (int64_t)lane * VEC; kk < d.K; kk += (int64_t)kWave * VEC) {
+  const int64_t blk = xcd_remap((int64_t)blockIdx.x - d.chunk_blocks, d.nblocks, d.swizzle);
+  const int L = 1 << d.logL;
+  int64_t slot;
+  int li;
+  if (UNIFORM) {  // one wavefront per row: everything about the row is wave-uniform (scalar path)
+    const int r32 = __builtin_amdgcn_readfirstlane((int)(blk * kWavesPerBlock + wave));
+    slot = (int64_t)(uint32_t)r32;  // nblocks * 4 < 2^32 is checked at launch
+    li = lane;
+  } else {
+    const int rows_per_wave = kWave >> d.logL;
+    slot = (blk * kWavesPerBlock + wave) * rows_per_wave + (lane >> d.logL);
+    li = lane & (L - 1);
+  }
+  if (slot >= d.N) return;
+  // row_order (rows sorted by length, longest first) packs rows of similar length into one
+  // wavefront when several rows share it, and starts the heavy rows early
+  const int64_t row = row_order ? (int64_t)row_order[slot] : slot;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  const int64_t len = end - beg;
+  if (len > d.chunk) return;  // long row: reduced by the chunk blocks above + long_final_kernel
+  for (int64_t kk = (int64_t)li * VEC; kk < d.K; kk += (int64_t)L * VEC) {
     A acc[VEC];
     int64_t arg[VEC];
     init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
     reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
-    S o[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
-    VecIO<S, VEC>::store(partial + cid * d.K + kk, o);
-    if (OP == OP_MAX) {
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) partial_arg[cid * d.K + kk + i] = arg[i];
-    }
+    finish_row<T, VEC, OP, MODE>(out, argout, d.K, row, len, kk, acc, arg);
   }
 }
 
@@ -346,6 +348,7 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   const int64_t *aux_arg;
   const int32_t *long_rows;
   const int64_t *chunk_ptr;
+  const int32_t *row_order;
   int64_t n_long, n_chunks;
   void *partial;
   int64_t *partial_arg;
@@ -365,27 +368,29 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
   using S = typename TT<T>::S;
   const bool uniform = (d.logL == 6) && std::is_same<T, float>::value;
   S *out = static_cast<S *>(a.out);
+  if (a.n_long > 0)
+    GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
+  d.chunk_blocks = a.n_long > 0 ? ceil_div(a.n_chunks, kWavesPerBlock) : 0;
+  const int64_t grid = d.chunk_blocks + d.nblocks;
+  GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "grid too large");
+  const int32_t *order = (options().row_order && (!uniform || options().row_order > 1)) ? a.row_order : nullptr;
+#define GGL_RR_ARGS GGL_RPTR_ARGS(S), order, a.long_rows, a.chunk_ptr, static_cast<S *>(a.partial), a.partial_arg, out, a.arg, d
   if (uniform) {
     // the f32 wave-per-row kernels; U = 8 only for the dominant SpMM-sum (A/B knob)
     if (std::is_same<T, float>::value && VEC == 4 && OP == OP_SUM && MODE == MODE_SPMM &&
         options().unroll >= 8) {
-      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 8>),
-                 d.nblocks, kBlock, stream, GGL_RPTR_ARGS(S), out, a.arg, d);
+      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 8>), grid,
+                 kBlock, stream, GGL_RR_ARGS);
     } else {
-      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 4>),
-                 d.nblocks, kBlock, stream, GGL_RPTR_ARGS(S), out, a.arg, d);
+      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 4>), grid,
+                 kBlock, stream, GGL_RR_ARGS);
     }
   } else {
-    GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 4>), d.nblocks, kBlock, stream,
-               GGL_RPTR_ARGS(S), out, a.arg, d);
+    GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 4>), grid, kBlock, stream, GGL_RR_ARGS);
   }
+#undef GGL_RR_ARGS
   GGL_LAUNCH_CHECK();
   if (a.n_long > 0) {
-    GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
-    GGL_LAUNCH((long_chunk_kernel<T, VEC, OP, MODE, IDX, 4>), ceil_div(a.n_chunks, kWavesPerBlock),
-               kBlock, stream, GGL_RPTR_ARGS(S), a.long_rows, a.chunk_ptr,
-               static_cast<S *>(a.partial), a.partial_arg, d);
-    GGL_LAUNCH_CHECK();
     GGL_LAUNCH((long_final_kernel<T, OP, MODE>), a.n_long, kBlock, stream, a.rowptr, a.long_rows,
                a.chunk_ptr, static_cast<const S *>(a.partial), (const int64_t *)a.partial_arg, out,
                a.arg, d);
@@ -460,6 +465,7 @@ static int fill_plan(ReduceArgs &a, const ggl_segplan_t *plan, int dtype, int64_
   a.chunk = plan->chunk;
   a.long_rows = plan->long_rows;
   a.chunk_ptr = plan->chunk_ptr;
+  a.row_order = plan->row_order;
   a.n_long = plan->n_long;
   a.n_chunks = plan->n_chunks;
   a.partial = plan->partial;

@@ -43,7 +43,7 @@ class SegPlan:
     """Destination-sorted view of one id vector (struct ggl_segplan + the tensors that own it)."""
 
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
-                 "chunk_ptr", "n_long", "n_chunks", "device")
+                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order")
 
     def c_struct(self, partial=None, perm_override=None):
         perm = self.perm if perm_override is None else perm_override
@@ -52,7 +52,8 @@ class SegPlan:
             long_rows=(self.long_rows.data_ptr() if self.n_long else None),
             chunk_ptr=(self.chunk_ptr.data_ptr() if self.n_long else None),
             n_long=self.n_long, n_chunks=self.n_chunks, chunk=self.chunk,
-            partial=(partial.data_ptr() if partial is not None else None), N=self.N, E=self.E)
+            partial=(partial.data_ptr() if partial is not None else None), N=self.N, E=self.E,
+            row_order=(self.row_order.data_ptr() if self.row_order is not None else None))
 
     def counts(self):
         return self.rowptr[1:] - self.rowptr[:-1]
@@ -225,6 +226,10 @@ class Engine:
             self._check(self.lib.ggl_plan_long_fill(_ptr(p.rowptr), N, chunk, p.n_long,
                                                     _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws),
                                                     lwb, st))
+        # scheduling aid: rows by descending length (stable), see ggl_segplan.row_order
+        p.row_order = None
+        if N > 1:
+            p.row_order = torch.argsort(p.counts(), descending=True, stable=True).to(torch.int32)
         self.stats["plans_built"] += 1
         return p
 
@@ -512,6 +517,20 @@ class Engine:
                                                          _ptr(gx), _ptr(gel), st))
                 return None, gel, ger, gx, None
 
+        class BiasAdd(torch.autograd.Function):
+            """out = x + bias (bias broadcast over rows); d bias = column sums of the gradient."""
+
+            @staticmethod
+            def forward(ctx, x, bias):
+                ctx.bias_shape = bias.shape
+                return x + bias
+
+            @staticmethod
+            def backward(ctx, g):
+                gb = eng.colsum(g.reshape(g.shape[0], -1)).reshape(ctx.bias_shape)
+                return g, gb
+
+        self.BiasAdd = BiasAdd
         self.SegmentSum, self.SegmentMean, self.SegmentMax = SegmentSum, SegmentMean, SegmentMax
         self.SpMMSum, self.SpMMMean, self.SpMMMax = SpMMSum, SpMMMean, SpMMMax
         self.BSpMMSum, self.GATFused = BSpMMSum, GATFused
@@ -579,6 +598,23 @@ class Engine:
     def spmm(self, gp, weight, x, reduce="sum"):
         fn = {"sum": self.SpMMSum, "mean": self.SpMMMean, "max": self.SpMMMax}[reduce]
         return fn.apply(gp, weight, x.contiguous())
+
+    def colsum(self, g):
+        """out[k] = sum_r g[r, k] for a row-major f32 [N, K] matrix (deterministic two-stage kernel)."""
+        dev = self._dev(g)
+        self._check_f32("g", g)
+        g = g.contiguous()
+        N = int(g.shape[0])
+        K = g.numel() // N if N > 0 else int(math.prod(g.shape[1:]))
+        out = torch.empty(tuple(g.shape[1:]), dtype=torch.float32, device=dev)
+        wsb = self.lib.ggl_colsum_workspace_bytes(N, K)
+        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+        self._check(self.lib.ggl_colsum_f32(_ptr(g), N, K, _ptr(out), _ptr(ws), wsb, self._stream(dev)))
+        return out
+
+    def bias_add(self, x, bias):
+        """x + bias with the bias gradient computed by ggl_colsum_f32 (gcn_conv.py:105-106)."""
+        return self.BiasAdd.apply(x, bias)
 
     def set_option(self, name, value):
         self._check(self.lib.ggl_set_option(name.encode(), int(value)))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GGL_ABI_VERSION 1
+#define GGL_ABI_VERSION 2
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
 enum {
@@ -80,6 +80,8 @@ typedef struct ggl_segplan {
   void *partial;            /* workspace: ggl_partial_bytes(...) bytes, or NULL when n_long == 0 */
   int64_t N;                /* number of segments (output rows) */
   int64_t E;                /* number of elements (edges) */
+  const int32_t *row_order; /* [N] rows sorted by length (longest first) or NULL: the order in which
+                               row slots are handed to wavefronts — scheduling only, results identical */
 } ggl_segplan_t;
 
 /* bytes of workspace ggl_plan_build needs */
@@ -190,6 +192,15 @@ int ggl_bspmm_grad_w(const int64_t *index /* [2,E] int64 */, const float *x, con
                      int64_t E, int64_t H, int64_t C, float *gw, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Column sums of a row-major [N,K] f32 matrix: out[k] = sum_r g[r,k] — the gradient of the
+ * "+ bias" that follows every aggregate (gcn_conv.py:105-106, sage_conv.py:102-103).  Two
+ * deterministic stages (no atomics); needs ggl_colsum_workspace_bytes(N, K) bytes of scratch.
+ * ---------------------------------------------------------------------------------------------- */
+size_t ggl_colsum_workspace_bytes(int64_t N, int64_t K);
+int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused GAT edge-softmax + weighted aggregate: ONE kernel per direction.  Replaces the external
  * dgNN GATConvFuse that FusedGATConv calls (layers/conv/fusedgat_conv.py:70-71,121) and the
  * unfused chain in GATConv.forward (layers/conv/gat_conv.py:103-112 + utils/softmax.py:29-35):
@@ -216,7 +227,7 @@ int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *colT, const
 
 /* ------------------------------------------------------------------------------------------------
  * Tuning knobs (process-wide; also read once from the environment: GGL_UNROLL, GGL_XCD_SWIZZLE,
- * GGL_FORCE_GENERIC).  For A/B measurements only — results do not depend on them.
+ * GGL_FORCE_GENERIC, GGL_ROW_ORDER).  For A/B measurements only — results do not depend on them.
  * ---------------------------------------------------------------------------------------------- */
 int ggl_set_option(const char *name, int64_t value);
 int64_t ggl_get_option(const char *name);

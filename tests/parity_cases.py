@@ -389,6 +389,26 @@ def check_edge_cases(eng, dev, oracle):
         eng.c_spmm_sum(torch.tensor([[0, 7], [1, 0]], device=dev), torch.ones(2, device=dev), torch.ones((2, 2), device=dev))
 
 
+def check_colsum(eng, dev):
+    """bias-gradient kernel: column sums vs an f64 sum; also through BiasAdd's autograd."""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for (N, K) in ((0, 5), (1, 1), (7, 3), (1000, 47), (5000, 256), (3000, 300), (70000, 16)):
+        x = torch.randn(N, K, generator=g).to(dev)
+        got = eng.colsum(x)
+        ref = x.double().sum(0)
+        bound = x.double().abs().sum(0)
+        assert got.shape == (K,)
+        assert bool(((got.double() - ref).abs() <= 1e-6 * bound + 1e-30).all()), (N, K)
+        assert torch.equal(got, eng.colsum(x))  # deterministic
+    x = torch.randn(300, 47, generator=g).to(dev).requires_grad_(True)
+    b = torch.randn(1, 47, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(300, 47, generator=g).to(dev)
+    y = eng.bias_add(x, b)
+    y.backward(go)
+    assert torch.equal(y.detach(), x.detach() + b.detach()) and torch.equal(x.grad, go)
+    torch.testing.assert_close(b.grad, go.sum(0, keepdim=True), rtol=1e-5, atol=1e-5)
+
+
 def check_plan_cache(eng, dev):
     eng.seg_cache.clear()
     ids = torch.tensor([2, 0, 1, 0, 2, 2], device=dev)

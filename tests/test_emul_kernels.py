@@ -65,3 +65,7 @@ def test_edge_cases_and_errors(eng, oracle):
 
 def test_plan_cache(eng):
     pc.check_plan_cache(eng, DEV)
+
+
+def test_colsum_bias_gradient(eng):
+    pc.check_colsum(eng, DEV)
