@@ -101,9 +101,17 @@ class PartitionedGraph:
 
 class _HaloAggregate(torch.autograd.Function):
     @staticmethod
+    def _pad4(t):
+        """Feature width to a multiple of 4 so the float4 kernels apply (K = 47 classes -> 48: measured
+        9.3 -> 5.8 ms forward, 7.3 -> 3.9 ms backward on the products-sized graph, profiles/)."""
+        k = t.shape[1]
+        return t if k % 4 == 0 else torch.nn.functional.pad(t, (0, (-k) % 4))
+
+    @staticmethod
     def forward(ctx, h, pg):
         eng = pg.eng
-        h = h.contiguous()
+        ctx.k_orig = h.shape[1]
+        h = _HaloAggregate._pad4(h.contiguous())
         work = recv = None
         if pg.world > 1:
             send = h.index_select(0, pg.send_idx)
@@ -115,13 +123,13 @@ class _HaloAggregate(torch.autograd.Function):
                 o2, _ = eng._spmm_fwd("sum", pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, pg.n_local)
                 out.add_(o2)
         ctx.pg = pg
-        return out
+        return out if out.shape[1] == ctx.k_orig else out[:, :ctx.k_orig].contiguous()
 
     @staticmethod
     def backward(ctx, g):
         pg = ctx.pg
         eng = pg.eng
-        g = g.contiguous()
+        g = _HaloAggregate._pad4(g.contiguous())
         work = gsend = None
         if pg.world > 1:
             if pg.n_halo > 0:
@@ -135,7 +143,7 @@ class _HaloAggregate(torch.autograd.Function):
             if pg.n_send > 0:
                 back, _ = eng._segment_fwd("sum", gsend, pg.send_plan)  # deterministic scatter-add
                 gh.add_(back)
-        return gh, None
+        return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None
 
 
 class DistGCN(torch.nn.Module):
@@ -242,6 +250,20 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
     e_loc = pg.gp_loc.E
     alg = e_loc * (4 * K + 8) + pg.n_local * (4 * K + 8)
     achieved = alg / (ms * 1e-3) / 1e9
+    # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
+    # WRITE_SIZE runs of tools/pmc_probe.py on the same graph; gfx950 read-side x2 correction applied by
+    # tools/pmc_summary.py) — only meaningful for the exact workload it was collected on
+    traffic = None
+    if world == 1 and args.workload == "products" and K == 256 and args.order == "src" and args.relabel == "random":
+        try:
+            import json
+            import os
+
+            prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                "r1_pmc_products_k256.json")
+            traffic = json.load(open(prof))["ggl::row_reduce_kernel<float, 4, 0, 1, 1, true, 4>"]["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            traffic = None
     out = {
         "metric": "edges aggregated/sec, 3-layer GCN hidden=256 training step, ogbn-products-sized graph",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -257,7 +279,7 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
             "setup_s": round(t_gen, 2), "loss": float(lsum)},
         "roofline": {"bound": "hbm", "kernel": f"row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, K={K}, rank 0 local rows)",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "ms_per_launch": ms, "alg_bytes_per_launch": alg,
+                     "traffic": traffic, "ms_per_launch": ms, "alg_bytes_per_launch": alg,
                      "edges_per_s_kernel": e_loc / (ms * 1e-3)},
     }
     return out
