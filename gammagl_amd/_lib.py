@@ -60,8 +60,9 @@ SIGNATURES = {
     "ggl_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_colsum_f32": (c_int, [_V, c_int64, c_int64, _V, _V, c_size_t, _V]),
     "ggl_gat_fused_fwd": (c_int, [_P, _V, _V, _V, _V, c_float, c_int64, c_int64, _V, _V, _V, _V]),
-    "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,
-                                      _V, _V, _V, _V]),
+    "ggl_gat_partial_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,
+                                      _V, _V, _V, _V, _V]),
     "ggl_gat_fused_bwd_src": (c_int, [_P, _V, _V, _V, _V, _V, c_int64, c_int64, _V, _V, _V]),
     "ggl_set_option": (c_int, [c_char_p, c_int64]),
     "ggl_get_option": (c_int64, [c_char_p]),

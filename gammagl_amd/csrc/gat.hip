@@ -1,17 +1,31 @@
-// gammagl_amd/csrc/gat.hip — fused GAT edge-softmax + weighted aggregate, one kernel per direction.
+// gammagl_amd/csrc/gat.hip — fused GAT edge-softmax + weighted aggregate.
 //
 // Replaces (a) the external dgNN GATConvFuse CUDA kernel that FusedGATConv calls
 // (layers/conv/fusedgat_conv.py:70-71,121 — not in the reference tree, parity unpinned) and (b) the
 // unfused chain GATConv.forward runs today (layers/conv/gat_conv.py:103-112 + utils/softmax.py:29-35):
 // 2 gathers [E,H,C] + concat + reduce -> leaky_relu -> segment_max -> gather -> exp -> segment_sum ->
 // gather -> divide -> gather [E,H,C] * alpha -> segment_sum, i.e. three segment passes and five
-// [E,.] intermediates in HBM.  Here a lane group owns one destination row, each lane VEC channels of
-// one head; it walks the row three times (max, denominator, weighted sum).  The first two walks only
-// touch el[col[p],h] (N*H floats: cache resident), the third streams the feature rows once.  The
-// arithmetic follows the in-tree math exactly: max with strict <, denominator summed in edge order,
-// alpha = exp(s - m) / (d + 1e-16), message = x * alpha (rounded), sum in edge order.
-// No LDS, no shuffles, no atomics: lanes of the same head recompute the (cheap) scalar softmax terms
-// redundantly instead of exchanging them.
+// [E,.] intermediates in HBM.
+//
+// Forward (ONE launch + a tiny combine for hub rows): a lane group owns one destination row, each lane
+// VEC channels of one head; it walks the row three times (max, denominator, weighted sum).  The first
+// two walks only touch el[col[p],h] (N*H floats: cache resident), the third streams the feature rows
+// once.  The arithmetic follows the in-tree math exactly: max with strict <, denominator summed in
+// edge order, alpha = exp(s - m) / (d + 1e-16), message = x * alpha (rounded), sum in edge order.
+// Lanes of the same head recompute the (cheap) scalar softmax terms redundantly instead of
+// exchanging them: no LDS, no shuffles, no atomics.
+// Rows longer than plan->chunk (a Reddit-sized R-MAT graph has a 109 110-edge hub: 100 ms on one lane
+// group) are cut into chunks reduced by whole wavefronts in the leading blocks of the same launch with
+// a chunk-local max (m_c, d_c = sum exp(s - m_c), acc_c = sum exp(s - m_c) x); gat_long_final_kernel
+// merges them in chunk order: m = max m_c, d = sum d_c e^{m_c - m}, out = sum acc_c e^{m_c - m} / (d + 1e-16).
+//
+// Backward: everything per edge is independent once the row statistics are known, so it is
+// edge-parallel (balanced regardless of the degree distribution):
+//   gat_rowdot_kernel : dot[i,h] = <g[i,h,:], out[i,h,:]>            (= sum_p alpha_p dalpha_p)
+//   gat_bwd_edge_kernel: one thread per (sorted position p, head h): alpha, dalpha = <g_i, x_j>,
+//                        de = alpha (dalpha - dot) LeakyReLU'(.)  -> alpha[E,H], de[E,H]
+//   ger = ggl_segment_sum(de) on the forward plan, gel / gx = row reductions on the transposed plan
+//   (ggl_segment_sum, ggl_bspmm_sum through posT).
 // Roofline: HBM; algorithmic bytes per edge = 4*H*C (feature row) + 4 (col) + 4*H (el row).
 #include "common.hpp"
 
@@ -23,118 +37,231 @@
 
 namespace ggl {
 
-struct GatArgs {
-  const int64_t *rowptr;
-  const int32_t *col;
-  const float *el, *er, *x, *g, *out;
+struct GatDims {
   float slope;
-  int64_t N, H, C, K;
-  int logL, swizzle;
-  int64_t nblocks;
-  float *y, *rowmax, *rowden;
-  float *alpha, *de, *ger;
+  int64_t N, H, C, K, E;
+  int64_t chunk, n_long, n_chunks, chunk_blocks, nblocks;
+  int logL;
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : __fmul_rn(v, slope); }
 
+template <int VEC> struct F32V {
+  static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = p[i];
+  }
+  static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = v[i];
+  }
+};
+template <> struct F32V<4> {
+  static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[4]) {
+    float4 t;
+    t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+    *reinterpret_cast<float4 *>(p) = t;
+  }
+};
+
+// softmax statistics of positions [beg, end) for head h of destination row `row`
+__device__ __forceinline__ void gat_stats(const int32_t *__restrict__ col, const float *__restrict__ el,
+                                          float er_i, float slope, int64_t H, int64_t h, int64_t beg,
+                                          int64_t end, float &m, float &d) {
+  m = -FLT_MAX;  // unsorted_segment_max: lowest() fill, strict <
+  int64_t p = beg;
+  for (; p + 4 <= end; p += 4) {
+    const int64_t c0 = col[p], c1 = col[p + 1], c2 = col[p + 2], c3 = col[p + 3];
+    const float s0 = lrelu(__fadd_rn(el[c0 * H + h], er_i), slope);
+    const float s1 = lrelu(__fadd_rn(el[c1 * H + h], er_i), slope);
+    const float s2 = lrelu(__fadd_rn(el[c2 * H + h], er_i), slope);
+    const float s3 = lrelu(__fadd_rn(el[c3 * H + h], er_i), slope);
+    if (m < s0) m = s0;
+    if (m < s1) m = s1;
+    if (m < s2) m = s2;
+    if (m < s3) m = s3;
+  }
+  for (; p < end; ++p) {
+    const float s = lrelu(__fadd_rn(el[(int64_t)col[p] * H + h], er_i), slope);
+    if (m < s) m = s;
+  }
+  d = 0.0f;  // unsorted_segment_sum of exp(s - m), in edge order
+  p = beg;
+  for (; p + 4 <= end; p += 4) {
+    const int64_t c0 = col[p], c1 = col[p + 1], c2 = col[p + 2], c3 = col[p + 3];
+    const float e0 = GGL_EXPF(__fadd_rn(lrelu(__fadd_rn(el[c0 * H + h], er_i), slope), -m));
+    const float e1 = GGL_EXPF(__fadd_rn(lrelu(__fadd_rn(el[c1 * H + h], er_i), slope), -m));
+    const float e2 = GGL_EXPF(__fadd_rn(lrelu(__fadd_rn(el[c2 * H + h], er_i), slope), -m));
+    const float e3 = GGL_EXPF(__fadd_rn(lrelu(__fadd_rn(el[c3 * H + h], er_i), slope), -m));
+    d = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(d, e0), e1), e2), e3);
+  }
+  for (; p < end; ++p)
+    d = __fadd_rn(d, GGL_EXPF(__fadd_rn(lrelu(__fadd_rn(el[(int64_t)col[p] * H + h], er_i), slope), -m)));
+}
+
+// acc[:] = sum_p (exp(s_p - m) * scale) * x[col[p], kk:kk+VEC], in edge order, 4 feature rows in flight.
+// NORMALISE: multiply by alpha = exp(.)/den (short rows);  otherwise by the bare exponential (chunks).
+template <int VEC, bool NORMALISE>
+__device__ __forceinline__ void gat_weighted_sum(const int32_t *__restrict__ col,
+                                                 const float *__restrict__ el,
+                                                 const float *__restrict__ x, float er_i, float slope,
+                                                 float m, float den, int64_t H, int64_t K, int64_t h,
+                                                 int64_t kk, int64_t beg, int64_t end,
+                                                 float (&acc)[VEC]) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+  int64_t p = beg;
+  for (; p + 4 <= end; p += 4) {
+    int64_t c[4];
+    float v[4][VEC], a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = col[p + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) F32V<VEC>::load(x + c[u] * K + kk, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float e = GGL_EXPF(__fadd_rn(lrelu(__fadd_rn(el[c[u] * H + h], er_i), slope), -m));
+      a[u] = NORMALISE ? __fdiv_rn(e, den) : e;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(v[u][i], a[u]));
+    }
+  }
+  for (; p < end; ++p) {
+    const int64_t c0 = col[p];
+    float v0[VEC];
+    F32V<VEC>::load(x + c0 * K + kk, v0);
+    const float e = GGL_EXPF(__fadd_rn(lrelu(__fadd_rn(el[c0 * H + h], er_i), slope), -m));
+    const float a0 = NORMALISE ? __fdiv_rn(e, den) : e;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(v0[i], a0));
+  }
+}
+
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void gat_fwd_kernel(const GatArgs a) {
+__global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ er,
+    const float *__restrict__ x, float *__restrict__ y, float *__restrict__ rowmax,
+    float *__restrict__ rowden, float *__restrict__ pacc, float *__restrict__ pm,
+    float *__restrict__ pd, const GatDims d) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int64_t blk = xcd_remap((int64_t)blockIdx.x, a.nblocks, a.swizzle);
-  const int L = 1 << a.logL;
-  const int64_t row = (blk * kWavesPerBlock + wave) * (kWave >> a.logL) + (lane >> a.logL);
-  if (row >= a.N) return;
+  const int64_t H = d.H, K = d.K;
+  if ((int64_t)blockIdx.x < d.chunk_blocks) {  // one wavefront per chunk of a long row
+    const int64_t cid = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (cid >= d.n_chunks) return;
+    int64_t lo = 0, hi = d.n_long - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
+    }
+    const int64_t row = long_rows[lo];
+    const int64_t beg = rowptr[row] + (cid - chunk_ptr[lo]) * d.chunk;
+    const int64_t rend = rowptr[row + 1];
+    const int64_t end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
+    for (int64_t kk = (int64_t)lane * VEC; kk < K; kk += (int64_t)kWave * VEC) {
+      const int64_t h = kk / d.C;
+      const float er_i = er[row * H + h];
+      float m, dsum, acc[VEC];
+      gat_stats(col, el, er_i, d.slope, H, h, beg, end, m, dsum);
+      gat_weighted_sum<VEC, false>(col, el, x, er_i, d.slope, m, 1.0f, H, K, h, kk, beg, end, acc);
+      F32V<VEC>::store(pacc + cid * K + kk, acc);
+      if (kk == h * d.C) {
+        pm[cid * H + h] = m;
+        pd[cid * H + h] = dsum;
+      }
+    }
+    return;
+  }
+  const int L = 1 << d.logL;
+  const int64_t slot = (((int64_t)blockIdx.x - d.chunk_blocks) * kWavesPerBlock + wave) * (kWave >> d.logL) +
+                       (lane >> d.logL);
+  if (slot >= d.N) return;
+  const int64_t row = row_order ? (int64_t)row_order[slot] : slot;
   const int li = lane & (L - 1);
-  const int64_t beg = a.rowptr[row], end = a.rowptr[row + 1];
-  const int64_t H = a.H, K = a.K;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  if (end - beg > d.chunk) return;
   for (int64_t kk = (int64_t)li * VEC; kk < K; kk += (int64_t)L * VEC) {
-    const int64_t h = kk / a.C;
-    const float er_i = a.er[row * H + h];
-    // walk 1: m = max_p s   (unsorted_segment_max: lowest() fill, strict <)
-    float m = -FLT_MAX;
-    for (int64_t p = beg; p < end; ++p) {
-      const float s = lrelu(__fadd_rn(a.el[(int64_t)a.col[p] * H + h], er_i), a.slope);
-      if (m < s) m = s;
-    }
-    // walk 2: d = sum_p exp(s - m) in edge order (unsorted_segment_sum)
-    float d = 0.0f;
-    for (int64_t p = beg; p < end; ++p) {
-      const float s = lrelu(__fadd_rn(a.el[(int64_t)a.col[p] * H + h], er_i), a.slope);
-      d = __fadd_rn(d, GGL_EXPF(__fadd_rn(s, -m)));
-    }
-    const float den = __fadd_rn(d, 1e-16f);
-    // walk 3: out = sum_p (exp(s - m) / den) * x[col[p]]
-    float acc[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-    int64_t p = beg;
-    for (; p + 2 <= end; p += 2) {  // two feature rows in flight
-      const int64_t c0 = a.col[p], c1 = a.col[p + 1];
-      float v0[VEC], v1[VEC];
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) { v0[i] = a.x[c0 * K + kk + i]; v1[i] = a.x[c1 * K + kk + i]; }
-      const float s0 = lrelu(__fadd_rn(a.el[c0 * H + h], er_i), a.slope);
-      const float s1 = lrelu(__fadd_rn(a.el[c1 * H + h], er_i), a.slope);
-      const float a0 = __fdiv_rn(GGL_EXPF(__fadd_rn(s0, -m)), den);
-      const float a1 = __fdiv_rn(GGL_EXPF(__fadd_rn(s1, -m)), den);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(v0[i], a0));
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(v1[i], a1));
-    }
-    for (; p < end; ++p) {
-      const int64_t c0 = a.col[p];
-      const float s0 = lrelu(__fadd_rn(a.el[c0 * H + h], er_i), a.slope);
-      const float a0 = __fdiv_rn(GGL_EXPF(__fadd_rn(s0, -m)), den);
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(a.x[c0 * K + kk + i], a0));
-    }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) a.y[row * K + kk + i] = acc[i];
-    if (kk == h * a.C) {  // first lane of the head records the softmax statistics
-      a.rowmax[row * H + h] = m;
-      a.rowden[row * H + h] = d;
+    const int64_t h = kk / d.C;
+    const float er_i = er[row * H + h];
+    float m, dsum, acc[VEC];
+    gat_stats(col, el, er_i, d.slope, H, h, beg, end, m, dsum);
+    gat_weighted_sum<VEC, true>(col, el, x, er_i, d.slope, m, __fadd_rn(dsum, 1e-16f), H, K, h, kk, beg, end, acc);
+    F32V<VEC>::store(y + row * K + kk, acc);
+    if (kk == h * d.C) {  // first lane of the head records the softmax statistics
+      rowmax[row * H + h] = m;
+      rowden[row * H + h] = dsum;
     }
   }
 }
 
-// Backward, destination-major: one lane per (row, head).  With alpha_p = softmax_p(s_p):
-//   dalpha_p = <g[i,h,:], x[col[p],h,:]>,   sum_p alpha_p dalpha_p = <g[i,h,:], out[i,h,:]>
-//   ds_p = alpha_p (dalpha_p - <g,out>),    de_p = ds_p * LeakyReLU'(el+er)
-//   ger[i,h] = sum_p de_p;   alpha / de are written in forward sorted positions for the source pass.
-__global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(const GatArgs a) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  const int L = 1 << a.logL;  // lanes per row = pow2 >= H
-  const int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * (kWave >> a.logL) + (lane >> a.logL);
-  if (row >= a.N) return;
-  const int64_t H = a.H, C = a.C, K = a.K;
-  for (int64_t h = lane & (L - 1); h < H; h += L) {
-    const int64_t beg = a.rowptr[row], end = a.rowptr[row + 1];
-    const float er_i = a.er[row * H + h];
-    const float m = a.rowmax[row * H + h];
-    const float den = __fadd_rn(a.rowden[row * H + h], 1e-16f);
-    const float *gi = a.g + row * K + h * C;
-    const float *oi = a.out + row * K + h * C;
-    float dot = 0.0f;
-    for (int64_t c = 0; c < C; ++c) dot = __fadd_rn(dot, __fmul_rn(gi[c], oi[c]));
-    float gacc = 0.0f;
-    for (int64_t p = beg; p < end; ++p) {
-      const int64_t src = a.col[p];
-      const float raw = __fadd_rn(a.el[src * H + h], er_i);
-      const float s = lrelu(raw, a.slope);
-      const float al = __fdiv_rn(GGL_EXPF(__fadd_rn(s, -m)), den);
-      const float *xj = a.x + src * K + h * C;
-      float da = 0.0f;
-      for (int64_t c = 0; c < C; ++c) da = __fadd_rn(da, __fmul_rn(gi[c], xj[c]));
-      const float ds = __fmul_rn(al, __fadd_rn(da, -dot));
-      const float dv = raw > 0.0f ? ds : __fmul_rn(ds, a.slope);
-      a.alpha[p * H + h] = al;
-      a.de[p * H + h] = dv;
-      gacc = __fadd_rn(gacc, dv);
+__global__ __launch_bounds__(kBlock) void gat_long_final_kernel(
+    const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr,
+    const float *__restrict__ pacc, const float *__restrict__ pm, const float *__restrict__ pd,
+    float *__restrict__ y, float *__restrict__ rowmax, float *__restrict__ rowden, const GatDims d) {
+  const int64_t j = blockIdx.x;
+  const int64_t row = long_rows[j];
+  const int64_t c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
+  for (int64_t k = threadIdx.x; k < d.K; k += kBlock) {
+    const int64_t h = k / d.C;
+    float m = -FLT_MAX;
+    for (int64_t c = c0; c < c1; ++c)
+      if (m < pm[c * d.H + h]) m = pm[c * d.H + h];
+    float den = 0.0f, acc = 0.0f;
+    for (int64_t c = c0; c < c1; ++c) {
+      const float sc = GGL_EXPF(__fadd_rn(pm[c * d.H + h], -m));
+      den = __fadd_rn(den, __fmul_rn(pd[c * d.H + h], sc));
+      acc = __fadd_rn(acc, __fmul_rn(pacc[c * d.K + k], sc));
     }
-    a.ger[row * H + h] = gacc;
+    y[row * d.K + k] = __fdiv_rn(acc, __fadd_rn(den, 1e-16f));
+    if (k == h * d.C) {
+      rowmax[row * d.H + h] = m;
+      rowden[row * d.H + h] = den;
+    }
+  }
+}
+
+// dot[i,h] = <g[i,h,:], out[i,h,:]>
+__global__ __launch_bounds__(kBlock) void gat_rowdot_kernel(const float *__restrict__ g,
+                                                            const float *__restrict__ out, int64_t NH,
+                                                            int64_t C, float *__restrict__ dot) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NH; i += stride) {
+    float a = 0.0f;
+    for (int64_t c = 0; c < C; ++c) a = __fadd_rn(a, __fmul_rn(g[i * C + c], out[i * C + c]));
+    dot[i] = a;
+  }
+}
+
+// one thread per (sorted position p, head h)
+__global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
+    const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const float *__restrict__ el,
+    const float *__restrict__ er, const float *__restrict__ x, const float *__restrict__ g,
+    const float *__restrict__ rowmax, const float *__restrict__ rowden, const float *__restrict__ dot,
+    float *__restrict__ alpha, float *__restrict__ de, const GatDims d) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t H = d.H, C = d.C, K = d.K;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < d.E * H; t += stride) {
+    const int64_t p = t / H, h = t - p * H;
+    const int64_t i = rowidx[p], src = col[p];
+    const float raw = __fadd_rn(el[src * H + h], er[i * H + h]);
+    const float s = lrelu(raw, d.slope);
+    const float al = __fdiv_rn(GGL_EXPF(__fadd_rn(s, -rowmax[i * H + h])), __fadd_rn(rowden[i * H + h], 1e-16f));
+    const float *__restrict__ gi = g + i * K + h * C;
+    const float *__restrict__ xj = x + src * K + h * C;
+    float da = 0.0f;
+    for (int64_t c = 0; c < C; ++c) da = __fadd_rn(da, __fmul_rn(gi[c], xj[c]));
+    const float ds = __fmul_rn(al, __fadd_rn(da, -dot[i * H + h]));
+    alpha[t] = al;
+    de[t] = raw > 0.0f ? ds : __fmul_rn(ds, d.slope);
   }
 }
 
@@ -144,57 +271,93 @@ static inline int pow2_log2(int64_t v) {
   return l;
 }
 
+static inline int64_t grid_for(int64_t n) {
+  int64_t b = ceil_div(n, kBlock);
+  if (b > 16384) b = 16384;
+  return b < 1 ? 1 : b;
+}
+
 }  // namespace ggl
 
 using namespace ggl;
+
+extern "C" size_t ggl_gat_partial_bytes(int64_t n_chunks, int64_t H, int64_t C) {
+  if (n_chunks <= 0) return 0;
+  return (size_t)n_chunks * (size_t)(H * C + 2 * H) * sizeof(float) + 64;
+}
 
 extern "C" int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
                                  const float *er, const float *x, float slope, int64_t H, int64_t C,
                                  float *out, float *rowmax, float *rowden, void *stream) {
   GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
-  GGL_REQUIRE(H > 0 && C > 0, GGL_EINVAL, "H and C must be positive");
+  GGL_REQUIRE(H > 0 && C > 0 && plan->chunk > 0, GGL_EINVAL, "H, C and chunk must be positive");
   const int64_t N = plan->N;
   if (N == 0) return GGL_OK;
   GGL_REQUIRE(er && out && rowmax && rowden, GGL_EINVAL, "NULL pointer");
   GGL_REQUIRE((col && el && x) || plan->E == 0, GGL_EINVAL, "NULL pointer");
-  GatArgs a{};
-  a.rowptr = plan->rowptr; a.col = col; a.el = el; a.er = er; a.x = x; a.slope = slope;
-  a.N = N; a.H = H; a.C = C; a.K = H * C; a.y = out; a.rowmax = rowmax; a.rowden = rowden;
-  a.swizzle = (int)options().xcd_swizzle;
+  GatDims d{};
+  d.slope = slope; d.N = N; d.H = H; d.C = C; d.K = H * C; d.E = plan->E;
+  d.chunk = plan->chunk; d.n_long = plan->n_long; d.n_chunks = plan->n_chunks;
+  float *pacc = nullptr, *pm = nullptr, *pd = nullptr;
+  if (plan->n_long > 0) {
+    GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
+                "plan has long rows but long_rows/chunk_ptr/partial is NULL");
+    pacc = static_cast<float *>(plan->partial);
+    pm = pacc + plan->n_chunks * d.K;
+    pd = pm + plan->n_chunks * H;
+    d.chunk_blocks = ceil_div(plan->n_chunks, kWavesPerBlock);
+  }
   const bool vec4 = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) && !options().force_generic;
+                    ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(pacc) & 15u) == 0) && !options().force_generic;
   const int vec = vec4 ? 4 : 1;
-  a.logL = pow2_log2(ceil_div(a.K, vec));
-  a.nblocks = ceil_div(N, (int64_t)kWavesPerBlock * (kWave >> a.logL));
-  GGL_REQUIRE(a.nblocks < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
-  if (vec4) GGL_LAUNCH((gat_fwd_kernel<4>), a.nblocks, kBlock, as_stream(stream), a);
-  else GGL_LAUNCH((gat_fwd_kernel<1>), a.nblocks, kBlock, as_stream(stream), a);
+  d.logL = pow2_log2(ceil_div(d.K, vec));
+  d.nblocks = ceil_div(N, (int64_t)kWavesPerBlock * (kWave >> d.logL));
+  const int64_t grid = d.chunk_blocks + d.nblocks;
+  GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+  const int32_t *order = options().row_order ? plan->row_order : nullptr;
+  hipStream_t s = as_stream(stream);
+  if (vec4)
+    GGL_LAUNCH((gat_fwd_kernel<4>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+               plan->chunk_ptr, el, er, x, out, rowmax, rowden, pacc, pm, pd, d);
+  else
+    GGL_LAUNCH((gat_fwd_kernel<1>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+               plan->chunk_ptr, el, er, x, out, rowmax, rowden, pacc, pm, pd, d);
   GGL_LAUNCH_CHECK();
+  if (plan->n_long > 0) {
+    GGL_LAUNCH((gat_long_final_kernel), plan->n_long, kBlock, s, plan->long_rows, plan->chunk_ptr,
+               (const float *)pacc, (const float *)pm, (const float *)pd, out, rowmax, rowden, d);
+    GGL_LAUNCH_CHECK();
+  }
   return GGL_OK;
 }
 
-extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *col, const float *el,
-                                     const float *er, const float *x, const float *g,
-                                     const float *out, const float *rowmax, const float *rowden,
-                                     float slope, int64_t H, int64_t C, float *alpha, float *de,
-                                     float *ger, void *stream) {
+extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *col,
+                                     const int32_t *rowidx, const float *el, const float *er,
+                                     const float *x, const float *g, const float *out,
+                                     const float *rowmax, const float *rowden, float slope, int64_t H,
+                                     int64_t C, float *alpha, float *de, float *ger, float *dot_ws,
+                                     void *stream) {
   GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
   GGL_REQUIRE(H > 0 && C > 0, GGL_EINVAL, "H and C must be positive");
-  const int64_t N = plan->N;
+  const int64_t N = plan->N, E = plan->E;
   if (N == 0) return GGL_OK;
-  GGL_REQUIRE(er && g && out && rowmax && rowden && ger, GGL_EINVAL, "NULL pointer");
-  GGL_REQUIRE((col && el && x && alpha && de) || plan->E == 0, GGL_EINVAL, "NULL pointer");
-  GatArgs a{};
-  a.rowptr = plan->rowptr; a.col = col; a.el = el; a.er = er; a.x = x; a.g = g; a.out = out;
-  a.slope = slope; a.N = N; a.H = H; a.C = C; a.K = H * C;
-  a.rowmax = const_cast<float *>(rowmax); a.rowden = const_cast<float *>(rowden);
-  a.alpha = alpha; a.de = de; a.ger = ger;
-  a.logL = pow2_log2(H);
-  a.nblocks = ceil_div(N, (int64_t)kWavesPerBlock * (kWave >> a.logL));
-  GGL_REQUIRE(a.nblocks < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
-  GGL_LAUNCH((gat_bwd_dst_kernel), a.nblocks, kBlock, as_stream(stream), a);
+  GGL_REQUIRE(er && g && out && rowmax && rowden && ger && dot_ws, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE((col && rowidx && el && x && alpha && de) || E == 0, GGL_EINVAL, "NULL pointer");
+  GatDims d{};
+  d.slope = slope; d.N = N; d.H = H; d.C = C; d.K = H * C; d.E = E;
+  hipStream_t s = as_stream(stream);
+  GGL_LAUNCH((gat_rowdot_kernel), grid_for(N * H), kBlock, s, g, out, N * H, C, dot_ws);
   GGL_LAUNCH_CHECK();
-  return GGL_OK;
+  if (E > 0) {
+    GGL_LAUNCH((gat_bwd_edge_kernel), grid_for(E * H), kBlock, s, col, rowidx, el, er, x, g, rowmax,
+               rowden, (const float *)dot_ws, alpha, de, d);
+    GGL_LAUNCH_CHECK();
+  }
+  // ger[i,h] = sum over the row's positions of de: de already lives in sorted positions
+  ggl_segplan_t p = *plan;
+  p.perm = nullptr;
+  return ggl_segment_sum(GGL_F32, de, &p, H, ger, stream);
 }
 
 // Source-major half of the backward: two row reductions on the transposed plan, reading alpha / de

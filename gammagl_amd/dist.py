@@ -41,9 +41,14 @@ class PartitionedGraph:
     """This rank's share of a weighted graph, plus everything the halo exchange needs."""
 
     def __init__(self, edge_index, edge_weight, num_nodes, rank=0, world=1, group=None, eng=None,
-                 bounds=None):
+                 bounds=None, self_halo_from=None):
+        """`self_halo_from` (tests only, world == 1 with an initialised process group): treat the
+        local rows >= that global id as if they lived on a remote rank, so the complete exchange path
+        (send lists, all-to-all-v with itself, halo SpMM, reverse exchange) runs through RCCL on a
+        single GPU."""
         self.eng = eng if eng is not None else _default_engine()
         self.rank, self.world, self.group = rank, world, group
+        self.comm = world > 1 or self_halo_from is not None
         dev = edge_index.device
         src, dst = edge_index[0], edge_index[1]
         self.bounds = bounds or balanced_bounds(dst, num_nodes, world)
@@ -53,7 +58,7 @@ class PartitionedGraph:
         mine = (dst >= lo) & (dst < hi)
         s, d, w = src[mine], dst[mine] - lo, edge_weight[mine]
         self.e_local = int(s.shape[0])
-        is_loc = (s >= lo) & (s < hi)
+        is_loc = (s >= lo) & (s < (hi if self_halo_from is None else int(self_halo_from)))
         # edges whose source row is local
         self.ei_loc = torch.stack([s[is_loc] - lo, d[is_loc]]).contiguous()
         self.w_loc = w[is_loc].contiguous()
@@ -72,7 +77,7 @@ class PartitionedGraph:
         else:
             self.ei_halo = self.w_halo = self.gp_halo = None
         # tell every owner which of its rows we need
-        if world > 1:
+        if self.comm:
             rc = torch.tensor(self.recv_splits, device=dev, dtype=torch.int64)
             sc = torch.empty_like(rc)
             dist.all_to_all_single(sc, rc, group=group)
@@ -113,7 +118,7 @@ class _HaloAggregate(torch.autograd.Function):
         ctx.k_orig = h.shape[1]
         h = _HaloAggregate._pad4(h.contiguous())
         work = recv = None
-        if pg.world > 1:
+        if pg.comm:
             send = h.index_select(0, pg.send_idx)
             recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits)
         out, _ = eng._spmm_fwd("sum", pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, pg.n_local)  # overlaps the exchange
@@ -131,7 +136,7 @@ class _HaloAggregate(torch.autograd.Function):
         eng = pg.eng
         g = _HaloAggregate._pad4(g.contiguous())
         work = gsend = None
-        if pg.world > 1:
+        if pg.comm:
             if pg.n_halo > 0:
                 ghalo, _ = eng._spmm_fwd("sum", pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g, pg.n_halo)
             else:

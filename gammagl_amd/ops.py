@@ -62,7 +62,8 @@ class SegPlan:
 class GraphPlan:
     """CSR (rows = destination) and, lazily, CSC (rows = source) plans of one edge_index."""
 
-    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT")
+    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT",
+                 "_row_of_pos")
 
     def __init__(self, engine, index, n_dst, n_src):
         self.engine = engine
@@ -74,7 +75,7 @@ class GraphPlan:
         self.fwd = engine.seg_plan(index[1], self.N_dst)
         engine._check_range(index[0], self.N_src)
         self.col = engine.gather_i32(index[0], self.fwd.perm)
-        self._bwd = self._colT = self._posT = None
+        self._bwd = self._colT = self._posT = self._row_of_pos = None
 
     @property
     def bwd(self):
@@ -87,6 +88,13 @@ class GraphPlan:
     def colT(self):
         self.bwd  # noqa: B018
         return self._colT
+
+    @property
+    def row_of_pos(self):
+        """destination row of every forward sorted position (int32 [E])."""
+        if self._row_of_pos is None:
+            self._row_of_pos = self.engine.gather_i32(self.index[1], self.fwd.perm)
+        return self._row_of_pos
 
     @property
     def posT(self):
@@ -513,7 +521,11 @@ class Engine:
                 out = torch.empty((N, H, C), dtype=torch.float32, device=dev)
                 rmax = torch.empty((N, H), dtype=torch.float32, device=dev)
                 rden = torch.empty((N, H), dtype=torch.float32, device=dev)
-                cs = gp.fwd.c_struct(None)
+                part = None
+                if gp.fwd.n_long > 0:
+                    part = torch.empty(eng.lib.ggl_gat_partial_bytes(gp.fwd.n_chunks, H, C) + 16,
+                                       dtype=torch.uint8, device=dev)
+                cs = gp.fwd.c_struct(part)
                 eng._check(eng.lib.ggl_gat_fused_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er),
                                                      _ptr(x), float(slope), H, C, _ptr(out),
                                                      _ptr(rmax), _ptr(rden), eng._stream(dev)))
@@ -532,10 +544,12 @@ class Engine:
                 alpha = torch.empty((gp.E, H), dtype=torch.float32, device=dev)
                 de = torch.empty((gp.E, H), dtype=torch.float32, device=dev)
                 ger = torch.empty_like(er)
-                cs = gp.fwd.c_struct(None)
+                dot = torch.empty_like(er)
+                cs = gp.fwd.c_struct(eng._partial(gp.fwd, torch.float32, H, False, dev))
                 eng._check(eng.lib.ggl_gat_fused_bwd_dst(
-                    ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er), _ptr(x), _ptr(g), _ptr(out),
-                    _ptr(rmax), _ptr(rden), ctx.slope, H, C, _ptr(alpha), _ptr(de), _ptr(ger), st))
+                    ctypes.byref(cs), _ptr(gp.col), _ptr(gp.row_of_pos), _ptr(el), _ptr(er), _ptr(x),
+                    _ptr(g), _ptr(out), _ptr(rmax), _ptr(rden), ctx.slope, H, C, _ptr(alpha), _ptr(de),
+                    _ptr(ger), _ptr(dot), st))
                 bwd = gp.bwd
                 gx = torch.empty((gp.N_src, H, C), dtype=torch.float32, device=dev)
                 gel = torch.empty((gp.N_src, H), dtype=torch.float32, device=dev)

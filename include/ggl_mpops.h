@@ -208,19 +208,27 @@ int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *works
  *   m[i,h]   = max_p s;  d[i,h] = sum_p exp(s - m)           (saved for backward)
  *   out[i,h,:] = sum_p exp(s[p,h]-m[i,h]) / (d[i,h] + 1e-16) * x[col[p],h,:]
  * el/er [N,H] f32 (source / destination attention terms), x [N_in,H,C] f32.
- * Backward (two kernels, destination-major then source-major):
- *   ggl_gat_fused_bwd_dst: per destination row recomputes alpha, writes alpha[E,H] and ds[E,H]
- *       (both in forward sorted positions) and ger[N,H] = sum_p ds * lrelu'(.)
+ * Rows longer than plan->chunk are reduced chunk-wise with chunk-local maxima and merged in chunk
+ * order (online-softmax identity); short rows use the formula above verbatim.
+ * Backward (edge-parallel, then source-major):
+ *   ggl_gat_fused_bwd_dst: dot[i,h] = <g_i, out_i>; per (sorted position, head): alpha, de =
+ *       alpha (<g_i, x_j> - dot) lrelu'(.) -> alpha[E,H], de[E,H] (forward sorted positions);
+ *       ger[N,H] = row sums of de (ggl_segment_sum on the forward plan)
  *   ggl_gat_fused_bwd_src: on the transposed plan, gx[j,h,:] = sum_p alpha * g[dst,h,:] and
  *       gel[j,h] = sum_p de, reading alpha/de through posT (transposed position -> forward position)
  * ---------------------------------------------------------------------------------------------- */
 int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
                       const float *er, const float *x, float slope, int64_t H, int64_t C,
                       float *out, float *rowmax, float *rowden, void *stream);
-int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *col, const float *el,
-                          const float *er, const float *x, const float *g, const float *out,
-                          const float *rowmax, const float *rowden, float slope, int64_t H,
-                          int64_t C, float *alpha, float *de, float *ger, void *stream);
+/* plan->partial for ggl_gat_fused_fwd when the plan has long rows (chunk-local softmax partials) */
+size_t ggl_gat_partial_bytes(int64_t n_chunks, int64_t H, int64_t C);
+/* rowidx [E] int32: destination row of every sorted position; dot_ws [N,H] f32 scratch;
+ * plan->partial as for ggl_segment_sum with K = H (the ger reduction) */
+int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *col, const int32_t *rowidx,
+                          const float *el, const float *er, const float *x, const float *g,
+                          const float *out, const float *rowmax, const float *rowden, float slope,
+                          int64_t H, int64_t C, float *alpha, float *de, float *ger, float *dot_ws,
+                          void *stream);
 int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *colT, const int32_t *posT,
                           const float *alpha, const float *de, const float *g, int64_t H,
                           int64_t C, float *gx, float *gel, void *stream);
