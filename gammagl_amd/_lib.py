@@ -44,6 +44,11 @@ SIGNATURES = {
     "ggl_fill_i64": (c_int, [_V, c_int64, c_int64, _V]),
     "ggl_gather_i64_to_i32": (c_int, [_V, _V, c_int64, _V, _V]),
     "ggl_gather_rows_f32": (c_int, [_V, _V, c_int64, c_int64, _V, _V]),
+    "ggl_ind2ptr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ggl_ind2ptr": (c_int, [_V, c_int64, c_int64, _V, _V, c_size_t, _V]),
+    "ggl_ptr2ind": (c_int, [_V, c_int64, c_int64, _V, _V]),
+    "ggl_sort_edges_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ggl_sort_edges": (c_int, [_V, _V, c_int64, c_int64, _V, _V, c_size_t, _V]),
     "ggl_segment_sum": (c_int, [c_int, _V, _P, c_int64, _V, _V]),
     "ggl_segment_mean": (c_int, [c_int, _V, _P, c_int64, _V, _V]),
     "ggl_segment_max": (c_int, [c_int, _V, _P, c_int64, _V, _V, c_int64, _V]),

@@ -398,3 +398,127 @@ extern "C" int ggl_gather_rows_f32(const float *src, const int32_t *perm, int64_
   GGL_LAUNCH_CHECK();
   return GGL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Format conversion entry points: the device-side counterparts of
+// gammagl/ops/sparse ind2ptr / ptr2ind (cpu/convert.cpp:58-128; numpy fallback ops/sparse/__init__.py:
+// 23-41; CUDA: a binary search per output, cuda/convert.cu:41-60,85-104) and of
+// utils/sort_edge_index.py:30-44 (argsort of row * N + col).
+// ------------------------------------------------------------------------------------------------
+namespace ggl {
+
+// ind[p] = r  with ptr[r] <= p < ptr[r+1]
+__global__ __launch_bounds__(kBlock) void ptr2ind_kernel(const int64_t *__restrict__ ptr, int64_t M,
+                                                         int64_t E, int64_t *__restrict__ ind) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += stride) {
+    int64_t lo = 0, hi = M;  // first r with ptr[r+1] > p
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (ptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
+    }
+    ind[p] = lo;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void edge_keys_kernel(const int64_t *__restrict__ major,
+                                                           const int64_t *__restrict__ minor,
+                                                           int64_t E, int64_t N,
+                                                           uint64_t *__restrict__ keys,
+                                                           int32_t *__restrict__ vals) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+    keys[i] = (uint64_t)major[i] * (uint64_t)N + (uint64_t)minor[i];
+    vals[i] = (int32_t)i;
+  }
+}
+
+static inline int key_bits64(int64_t N) {
+  int b = 1;
+  while (b < 31 && ((int64_t)1 << b) < N) ++b;
+  return 2 * b < 64 ? 2 * b : 64;
+}
+
+#ifndef GGL_EMULATE
+static size_t sort64_temp_bytes(int64_t E, int bits) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                  (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)E, 0u,
+                                  (unsigned)bits, (hipStream_t)0);
+  return tmp;
+}
+#endif
+
+}  // namespace ggl
+
+// ptr[M+1] = exclusive prefix of the histogram of ind (ind need not be sorted: the numpy fallback's
+// bincount + cumsum).  For sorted ind this is the binary-search form of cuda/convert.cu:41-60.
+extern "C" size_t ggl_ind2ptr_workspace_bytes(int64_t E, int64_t M) {
+  return ggl_plan_workspace_bytes(E, M) + align_up((size_t)(E > 0 ? E : 1) * 4, 256);
+}
+
+extern "C" int ggl_ind2ptr(const int64_t *ind, int64_t E, int64_t M, int64_t *ptr, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_ind2ptr_workspace_bytes(E, M), GGL_EWORKSPACE,
+              "ind2ptr workspace too small");
+  char *ws = static_cast<char *>(workspace);
+  int32_t *perm = reinterpret_cast<int32_t *>(ws);
+  const size_t off = align_up((size_t)(E > 0 ? E : 1) * 4, 256);
+  int32_t sorted = 0;
+  int64_t max_len = 0;
+  return ggl_plan_build(ind, E, M, perm, ptr, ws + off, workspace_bytes - off, stream, &sorted,
+                        &max_len);
+}
+
+extern "C" int ggl_ptr2ind(const int64_t *ptr, int64_t M, int64_t E, int64_t *ind, void *stream) {
+  GGL_REQUIRE(M >= 0 && E >= 0 && (ptr || M == 0) && (ind || E == 0), GGL_EINVAL, "bad arguments");
+  if (E == 0) return GGL_OK;
+  GGL_LAUNCH((ptr2ind_kernel), grid_for(E), kBlock, as_stream(stream), ptr, M, E, ind);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+// perm[E] = stable argsort of major[i] * N + minor[i]  (sort_edge_index.py:36-39); ties keep the
+// original order, which the reference's (unstable) argsort leaves unspecified.
+extern "C" size_t ggl_sort_edges_workspace_bytes(int64_t E, int64_t N) {
+  size_t b = 2 * align_up((size_t)(E > 0 ? E : 1) * 8, 256) + align_up((size_t)(E > 0 ? E : 1) * 4, 256);
+#ifndef GGL_EMULATE
+  b += align_up(sort64_temp_bytes(E > 0 ? E : 1, key_bits64(N)), 256);
+#endif
+  return b;
+}
+
+extern "C" int ggl_sort_edges(const int64_t *major, const int64_t *minor, int64_t E, int64_t N,
+                              int32_t *perm, void *workspace, size_t workspace_bytes, void *stream) {
+  GGL_REQUIRE(E >= 0 && N >= 0 && E < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), GGL_EINVAL,
+              "bad sizes");
+  if (E == 0) return GGL_OK;
+  GGL_REQUIRE(major && minor && perm, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_sort_edges_workspace_bytes(E, N), GGL_EWORKSPACE,
+              "sort_edges workspace too small");
+  hipStream_t s = as_stream(stream);
+  char *ws = static_cast<char *>(workspace);
+  uint64_t *keys_in = reinterpret_cast<uint64_t *>(ws);
+  size_t off = align_up((size_t)E * 8, 256);
+  uint64_t *keys_out = reinterpret_cast<uint64_t *>(ws + off);
+  off += align_up((size_t)E * 8, 256);
+  int32_t *vals_in = reinterpret_cast<int32_t *>(ws + off);
+  off += align_up((size_t)E * 4, 256);
+  GGL_LAUNCH((edge_keys_kernel), grid_for(E), kBlock, s, major, minor, E, N, keys_in, vals_in);
+  GGL_LAUNCH_CHECK();
+#ifndef GGL_EMULATE
+  const int bits = key_bits64(N);
+  size_t tmp = sort64_temp_bytes(E, bits);
+  GGL_HIP_CHECK(rocprim::radix_sort_pairs(ws + off, tmp, (const uint64_t *)keys_in, keys_out,
+                                          (const int32_t *)vals_in, perm, (size_t)E, 0u,
+                                          (unsigned)bits, s));
+#else
+  std::vector<int32_t> order((size_t)E);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return keys_in[a] < keys_in[b]; });
+  for (int64_t i = 0; i < E; ++i) perm[i] = order[(size_t)i];
+  (void)keys_out;
+#endif
+  return GGL_OK;
+}

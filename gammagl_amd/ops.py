@@ -545,7 +545,8 @@ class Engine:
                 de = torch.empty((gp.E, H), dtype=torch.float32, device=dev)
                 ger = torch.empty_like(er)
                 dot = torch.empty_like(er)
-                cs = gp.fwd.c_struct(eng._partial(gp.fwd, torch.float32, H, False, dev))
+                part_f = eng._partial(gp.fwd, torch.float32, H, False, dev)  # must outlive the launch
+                cs = gp.fwd.c_struct(part_f)
                 eng._check(eng.lib.ggl_gat_fused_bwd_dst(
                     ctypes.byref(cs), _ptr(gp.col), _ptr(gp.row_of_pos), _ptr(el), _ptr(er), _ptr(x),
                     _ptr(g), _ptr(out), _ptr(rmax), _ptr(rden), ctx.slope, H, C, _ptr(alpha), _ptr(de),

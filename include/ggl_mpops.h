@@ -119,6 +119,22 @@ int ggl_gather_rows_f32(const float *src, const int32_t *perm, int64_t E, int64_
                         void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Format conversion: device-side ind2ptr / ptr2ind (gammagl/ops/sparse,
+ * cpu/convert.cpp:58-128, cuda/convert.cu:41-104) and sort_edge_index (utils/sort_edge_index.py:30-44).
+ *   ggl_ind2ptr   : ptr[M+1] = exclusive prefix of the histogram of ind[E] (int64; SYNCHRONOUS:
+ *                   validates 0 <= ind < M like ggl_plan_build)
+ *   ggl_ptr2ind   : ind[p] = r with ptr[r] <= p < ptr[r+1]
+ *   ggl_sort_edges: perm[E] = stable argsort of major[i] * N + minor[i]
+ * ---------------------------------------------------------------------------------------------- */
+size_t ggl_ind2ptr_workspace_bytes(int64_t E, int64_t M);
+int ggl_ind2ptr(const int64_t *ind, int64_t E, int64_t M, int64_t *ptr, void *workspace,
+                size_t workspace_bytes, void *stream);
+int ggl_ptr2ind(const int64_t *ptr, int64_t M, int64_t E, int64_t *ind, void *stream);
+size_t ggl_sort_edges_workspace_bytes(int64_t E, int64_t N);
+int ggl_sort_edges(const int64_t *major, const int64_t *minor, int64_t E, int64_t N, int32_t *perm,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Segment reductions — supersede segment_{sum,mean,max}_{cpu,cuda}_forward
  * (cpu/segment_sum_cpu.cpp:11-60, cpu/segment_mean_cpu.cpp:11-80, cpu/segment_max_cpu.cpp:11-69;
  *  cuda/segment_sum_cuda.cu:33-116, cuda/segment_mean_cuda.cu, cuda/segment_max_cuda.cu).

@@ -389,6 +389,51 @@ def check_edge_cases(eng, dev, oracle):
         eng.c_spmm_sum(torch.tensor([[0, 7], [1, 0]], device=dev), torch.ones(2, device=dev), torch.ones((2, 2), device=dev))
 
 
+def check_convert(eng, dev):
+    """ind2ptr / ptr2ind / sort_edge_index vs the reference's numpy statements
+    (ops/sparse/__init__.py:23-41: bincount + cumsum, repeat(arange, diff); sort_edge_index.py:36-39:
+    argsort(row * N + col))."""
+    from gammagl_amd import sparse
+
+    rng = np.random.default_rng(3)
+    for (M, E) in ((1, 0), (5, 1), (40, 300), (1000, 20000), (7, 5000)):
+        ind = np.sort(rng.integers(0, M, size=E)).astype(np.int64)
+        ptr_ref = np.concatenate(([0], np.cumsum(np.bincount(ind, minlength=M), dtype=np.int64)))
+        ptr = sparse.ind2ptr(to_t(ind, dev), M, eng=eng)
+        assert_same(to_np(ptr), ptr_ref, f"ind2ptr M{M} E{E}")
+        uns = rng.permutation(ind)  # the numpy fallback (bincount) accepts unsorted ind too
+        assert_same(to_np(sparse.ind2ptr(to_t(uns, dev), M, eng=eng)), ptr_ref, "ind2ptr unsorted")
+        ind_ref = np.repeat(np.arange(M, dtype=np.int64), np.diff(ptr_ref))
+        assert_same(to_np(sparse.ptr2ind(ptr, E, eng=eng)), ind_ref[:E], f"ptr2ind M{M} E{E}")
+        assert_same(to_np(sparse.ptr2ind(ptr, None, eng=eng)), ind_ref, "ptr2ind E=None")
+    import pytest
+
+    with pytest.raises(IndexError):
+        sparse.ind2ptr(to_t(np.array([0, 9]), dev), 5, eng=eng)
+    for (N, E) in ((6, 0), (10, 50), (300, 5000)):
+        ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
+        attr = rng.standard_normal((E, 3)).astype(np.float32)
+        for by_row in (True, False):
+            key = ei[1 - int(by_row)] * N + ei[int(by_row)]
+            perm = np.argsort(key, kind="stable")
+            out, a = sparse.sort_edge_index(to_t(ei, dev), to_t(attr, dev), N, by_row, eng=eng)
+            assert_same(to_np(out), ei[:, perm], f"sort_edge_index N{N} by_row={by_row}")
+            assert_same(to_np(a), attr[perm], "sort_edge_index attr")
+        out2 = sparse.sort_edge_index(to_t(ei, dev), eng=eng) if E > 0 else None  # num_nodes inferred
+        if out2 is not None:
+            n2 = int(ei.max()) + 1
+            assert_same(to_np(out2), ei[:, np.argsort(ei[0] * n2 + ei[1], kind="stable")], "inferred N")
+    # FusedGATConv's own preprocessing (fusedgat_conv.py:103-117) reproduced on the device
+    N, E = 50, 400
+    ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
+    s = sparse.sort_edge_index(to_t(ei, dev), num_nodes=N, eng=eng)
+    row_ptr = sparse.ind2ptr(s[0], N, eng=eng)
+    assert int(row_ptr[-1]) == E and bool((row_ptr[1:] >= row_ptr[:-1]).all())
+    s2, permute = sparse.sort_edge_index(s, torch.arange(E, device=dev), N, sort_by_row=False, eng=eng)
+    col_ptr = sparse.ind2ptr(s2[1], N, eng=eng)
+    assert torch.equal(s[:, permute], s2) and int(col_ptr[-1]) == E
+
+
 def check_colsum(eng, dev):
     """bias-gradient kernel: column sums vs an f64 sum; also through BiasAdd's autograd."""
     g = torch.Generator(device="cpu").manual_seed(2)

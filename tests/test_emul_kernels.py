@@ -69,3 +69,7 @@ def test_plan_cache(eng):
 
 def test_colsum_bias_gradient(eng):
     pc.check_colsum(eng, DEV)
+
+
+def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng):
+    pc.check_convert(eng, DEV)

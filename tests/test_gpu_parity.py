@@ -317,3 +317,7 @@ def test_rccl_self_halo_exchange(eng, dev):
             torch.testing.assert_close(p.grad, q.grad, rtol=1e-3, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng, dev):
+    pc.check_convert(eng, dev)
