@@ -112,7 +112,40 @@ def test_balanced_bounds_and_world1():
     torch.testing.assert_close(pg.aggregate(h), eng.c_spmm_sum(ei, w, h))
 
 
+def _bench_worker(rank, world, port, tmp):
+    import json
+    import types
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gammagl_amd.dist import run_distributed_bench
+
+        args = types.SimpleNamespace(seed=0, relabel="random", order="src", hidden=16, layers=3, warmup=1,
+                                     steps=2, workload="tiny")
+        out = run_distributed_bench(args, torch.device("cpu"), rank, world, 400, 6000, 10, 5, eng=_emul_engine())
+        assert out["n_gpus"] == world and out["value"] > 0 and out["scaling"] == "strong"
+        assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+        json.dumps(out)
+        open(os.path.join(tmp, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_body_runs_distributed(tmp_path):
+    """bench.py's body (graph broadcast from rank 0, partition, timed steps, max-over-ranks) on gloo."""
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, __file__, str(r), "2", str(port), str(tmp_path), "bench"])
+             for r in range(2)]
+    assert [p.wait(timeout=300) for p in procs] == [0, 0]
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+
+
 if __name__ == "__main__":
     sys.path.insert(0, REPO)
     sys.path.insert(0, HERE)
-    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    fn = _bench_worker if len(sys.argv) > 5 and sys.argv[5] == "bench" else _worker
+    fn(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
