@@ -64,6 +64,9 @@ SIGNATURES = {
     "ggl_bspmm_grad_w": (c_int, [_V, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
     "ggl_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_colsum_f32": (c_int, [_V, c_int64, c_int64, _V, _V, c_size_t, _V]),
+    "ggl_bias_act_fwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V]),
+    "ggl_bias_act_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ggl_bias_act_bwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V, c_size_t, _V]),
     "ggl_gat_fused_fwd": (c_int, [_P, _V, _V, _V, _V, c_float, c_int64, c_int64, _V, _V, _V, _V]),
     "ggl_gat_partial_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,

@@ -167,9 +167,10 @@ class DistGCN(torch.nn.Module):
     def forward(self, x, pg):
         n = len(self.lin)
         for i in range(n):
-            x = pg.eng.bias_add(pg.aggregate(self.lin[i](x)), self.bias[i])
-            if i < n - 1:
-                x = self.dropout(torch.relu(x))
+            hidden = i < n - 1
+            # + bias, ReLU and dropout of the hidden layers fused into one pass each way (epilogue.hip)
+            x = pg.eng.bias_act(pg.aggregate(self.lin[i](x)), self.bias[i], relu=hidden,
+                                p_drop=self.dropout.p if hidden else 0.0, training=self.training)
         return x
 
 

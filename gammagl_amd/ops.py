@@ -151,6 +151,7 @@ class Engine:
         self.seg_cache = _PlanCache()
         self.graph_cache = _PlanCache()
         self.w_cache = _PlanCache(cap=8)
+        self._rng = {}
         self.stats = {"plans_built": 0, "plan_hits": 0}
         self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk
         self._make_functions()
@@ -574,6 +575,40 @@ class Engine:
                 gb = eng.colsum(g.reshape(g.shape[0], -1)).reshape(ctx.bias_shape)
                 return g, gb
 
+        class BiasAct(torch.autograd.Function):
+            """y = dropout(relu(a + bias)) in one kernel; backward rebuilds the mask from y and reduces
+            the bias gradient in the same pass (csrc/epilogue.hip)."""
+
+            @staticmethod
+            def forward(ctx, a, bias, relu, p_drop):
+                a = a.contiguous()
+                dev = a.device
+                N = int(a.shape[0])
+                K = a.numel() // N if N > 0 else int(math.prod(a.shape[1:]))
+                y = torch.empty_like(a)
+                rng = eng._rng_state(dev) if p_drop > 0 else None
+                b = bias.contiguous().reshape(-1) if bias is not None else None
+                eng._check(eng.lib.ggl_bias_act_fwd(_ptr(a), _ptr(b), N, K, int(relu), float(p_drop),
+                                                    _ptr(rng), _ptr(y), eng._stream(dev)))
+                ctx.cfg = (N, K, int(relu), float(p_drop), None if bias is None else bias.shape)
+                ctx.save_for_backward(y)
+                return y
+
+            @staticmethod
+            def backward(ctx, g):
+                (y,) = ctx.saved_tensors
+                N, K, relu, p_drop, bshape = ctx.cfg
+                g = g.contiguous()
+                dev = g.device
+                ga = torch.empty_like(g)
+                gb = torch.empty(K, dtype=torch.float32, device=dev) if bshape is not None else None
+                wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K)
+                ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+                eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K, relu, p_drop, _ptr(ga), _ptr(gb),
+                                                    _ptr(ws), wsb, eng._stream(dev)))
+                return ga, (gb.reshape(bshape) if gb is not None else None), None, None
+
+        self.BiasAct = BiasAct
         self.BiasAdd = BiasAdd
         self.SegmentSum, self.SegmentMean, self.SegmentMax = SegmentSum, SegmentMean, SegmentMax
         self.SpMMSum, self.SpMMMean, self.SpMMMax = SpMMSum, SpMMMean, SpMMMax
@@ -659,6 +694,28 @@ class Engine:
     def bias_add(self, x, bias):
         """x + bias with the bias gradient computed by ggl_colsum_f32 (gcn_conv.py:105-106)."""
         return self.BiasAdd.apply(x, bias)
+
+    def _rng_state(self, dev):
+        """Device-resident Philox state {seed, offset} for the fused dropout, seeded from torch's RNG."""
+        st = self._rng.get(str(dev))
+        if st is None:
+            seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())  # follows torch.manual_seed
+            st = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+            self._rng[str(dev)] = st
+        return st
+
+    def reseed(self, seed=None):
+        """Forget the fused-dropout RNG state (the next use draws a new seed from torch's generator)."""
+        self._rng.clear()
+        if seed is not None:
+            torch.manual_seed(seed)
+
+    def bias_act(self, a, bias=None, relu=False, p_drop=0.0, training=True):
+        """dropout(relu(a + bias)) — the step after every aggregate (gcn_conv.py:105-106, models/gcn.py:55-59)."""
+        self._dev(a, bias)
+        self._check_f32("a", a)
+        p = float(p_drop) if training else 0.0
+        return self.BiasAct.apply(a, bias, bool(relu), p)
 
     def set_option(self, name, value):
         self._check(self.lib.ggl_set_option(name.encode(), int(value)))

@@ -217,6 +217,21 @@ int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *works
                    size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused epilogue of an aggregate: "+ bias" (gcn_conv.py:105-106), ReLU and
+ * dropout (models/gcn.py:55-59) in one pass each way.
+ *   fwd: y = keep * relu(a + bias) / (1 - p_drop); keep ~ Bernoulli(1 - p_drop) from Philox4x32-10 keyed
+ *        on rng_state = {seed, offset} (device int64[2]; offset is advanced on the stream after the
+ *        launch, so a captured graph draws a new mask per replay).  bias [K] or NULL; p_drop = 0: no RNG.
+ *   bwd: ga = (y > 0) ? g / (1 - p_drop) : 0 when relu or dropout was applied (y == 0 exactly where
+ *        either killed the value), else ga = g;  gbias[K] = column sums of ga (same pass; NULL to skip).
+ * ---------------------------------------------------------------------------------------------- */
+int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, int64_t K, int relu, float p_drop,
+                     int64_t *rng_state, float *y, void *stream);
+size_t ggl_bias_act_bwd_workspace_bytes(int64_t N, int64_t K);
+int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int relu, float p_drop,
+                     float *ga, float *gbias, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused GAT edge-softmax + weighted aggregate: ONE kernel per direction.  Replaces the external
  * dgNN GATConvFuse that FusedGATConv calls (layers/conv/fusedgat_conv.py:70-71,121) and the
  * unfused chain in GATConv.forward (layers/conv/gat_conv.py:103-112 + utils/softmax.py:29-35):

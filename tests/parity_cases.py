@@ -454,6 +454,43 @@ def check_colsum(eng, dev):
     torch.testing.assert_close(b.grad, go.sum(0, keepdim=True), rtol=1e-5, atol=1e-5)
 
 
+def check_bias_act(eng, dev):
+    """fused bias + ReLU + dropout: exact vs torch without dropout; with dropout the mask statistics,
+    the 1/(1-p) scaling, mask consistency between forward and backward, and a fresh mask per call."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (N, K) in ((0, 4), (1, 1), (33, 47), (500, 256), (257, 6)):
+        a = torch.randn(N, K, generator=g).to(dev).requires_grad_(True)
+        b = torch.randn(1, K, generator=g).to(dev).requires_grad_(True)
+        go = torch.randn(N, K, generator=g).to(dev)
+        for relu in (False, True):
+            a.grad = b.grad = None
+            y = eng.bias_act(a, b, relu=relu, p_drop=0.0)
+            ref = a.detach() + b.detach()
+            ref = torch.relu(ref) if relu else ref
+            assert torch.equal(y.detach(), ref), (N, K, relu)
+            if N > 0:
+                y.backward(go)
+                gref = go * (ref > 0) if relu else go
+                assert torch.equal(a.grad, gref)
+                torch.testing.assert_close(b.grad, gref.sum(0, keepdim=True), rtol=1e-5, atol=1e-5)
+    y0 = eng.bias_act(torch.randn(7, 3, generator=g).to(dev), None, relu=True)  # bias=None
+    assert bool((y0 >= 0).all())
+    N, K, p = 4000, 64, 0.5
+    a = (torch.rand(N, K, generator=g) + 0.5).to(dev).requires_grad_(True)  # strictly positive: relu inactive
+    y = eng.bias_act(a, None, relu=True, p_drop=p, training=True)
+    kept = y.detach() != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    torch.testing.assert_close(y.detach()[kept], (a.detach() / (1 - p))[kept])
+    col_frac = kept.float().mean(0)
+    assert float((col_frac - (1 - p)).abs().max()) < 0.05  # no column- or row-structured mask
+    y.backward(torch.ones_like(y))
+    assert torch.equal(a.grad != 0, kept) and torch.allclose(a.grad[kept], torch.tensor(1 / (1 - p), device=dev))
+    y2 = eng.bias_act(a.detach(), None, relu=True, p_drop=p, training=True)
+    assert not torch.equal(y2 != 0, kept), "every call must draw a new mask"
+    assert torch.equal(eng.bias_act(a.detach(), None, relu=True, p_drop=p, training=False), a.detach())
+
+
 def check_plan_cache(eng, dev):
     eng.seg_cache.clear()
     ids = torch.tensor([2, 0, 1, 0, 2, 2], device=dev)

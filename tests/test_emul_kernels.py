@@ -73,3 +73,7 @@ def test_colsum_bias_gradient(eng):
 
 def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng):
     pc.check_convert(eng, DEV)
+
+
+def test_fused_bias_relu_dropout(eng):
+    pc.check_bias_act(eng, DEV)

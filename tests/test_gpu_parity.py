@@ -321,3 +321,7 @@ def test_rccl_self_halo_exchange(eng, dev):
 
 def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng, dev):
     pc.check_convert(eng, dev)
+
+
+def test_fused_bias_relu_dropout(eng, dev):
+    pc.check_bias_act(eng, dev)
