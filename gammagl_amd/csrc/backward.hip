@@ -204,7 +204,7 @@ static inline void colsum_geometry(int64_t N, int64_t K, int *kp, int *groups, i
   *kp = (int)(K < kBlock ? (K > 0 ? K : 1) : kBlock);
   *groups = kBlock / *kp;
   int64_t b = ceil_div(N > 0 ? N : 1, (int64_t)*groups * 64);  // >= 64 rows per group
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;  // stage 2 walks blocks * groups partials per column serially
   if (b < 1) b = 1;
   *blocks = b;
   *rows_per_block = ceil_div(N > 0 ? N : 1, b);

@@ -34,31 +34,53 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint64_t offset, uin
   return U4{c0, c1, c2, c3};
 }
 
-// one thread per group of 4 consecutive elements (flat index 4*v .. 4*v+3)
+// Threads of a block are `groups` groups of `kp` lanes; a lane owns VEC consecutive columns (loaded once
+// from bias), a group walks rows r0 + j, + groups, ...  Random word for vector (r, c): Philox(r * KV + c).
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(const float *__restrict__ a,
                                                               const float *__restrict__ bias,
                                                               const int64_t *__restrict__ rng,
-                                                              float *__restrict__ y, int64_t total,
-                                                              int64_t K, int relu, uint32_t drop_thresh,
-                                                              float scale) {
-  const int64_t nvec = (total + 3) >> 2;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+                                                              float *__restrict__ y, int64_t N, int64_t K,
+                                                              int64_t rows_per_block, int kp, int groups,
+                                                              int relu, uint32_t drop_thresh, float scale) {
+  const int j = threadIdx.x / kp;
+  const int c0 = threadIdx.x - j * kp;
+  if (j >= groups) return;
+  const int64_t KV = (K + VEC - 1) / VEC;  // vectors per row (VEC = 4 only when K % 4 == 0)
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
   const uint64_t seed = drop_thresh ? (uint64_t)rng[0] : 0, offset = drop_thresh ? (uint64_t)rng[1] : 0;
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-    uint32_t r[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    if (drop_thresh) {
-      const U4 u = philox4x32_10((uint64_t)v, offset, seed);
-      r[0] = u.x; r[1] = u.y; r[2] = u.z; r[3] = u.w;
-    }
+  for (int64_t c = c0; c < KV; c += kp) {
+    float b[VEC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t i = 4 * v + j;
-      if (i >= total) break;
-      float t = a[i];
-      if (bias) t = __fadd_rn(t, bias[i % K]);
-      if (relu) t = (t < 0.0f) ? 0.0f : t;  // NaN stays NaN, as torch.relu / clamp_min(0)
-      if (drop_thresh) t = (r[j] >= drop_thresh) ? __fmul_rn(t, scale) : 0.0f;  // keep with prob 1 - p
-      y[i] = t;
+    for (int i = 0; i < VEC; ++i) b[i] = bias ? bias[c * VEC + i] : 0.0f;
+    for (int64_t r = r0 + j; r < r1; r += groups) {
+      float t[VEC];
+      if (VEC == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(a + r * K + c * 4);
+        t[0] = v.x; t[1 % VEC] = v.y; t[2 % VEC] = v.z; t[3 % VEC] = v.w;
+      } else {
+        t[0] = a[r * K + c];
+      }
+      uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      if (drop_thresh) {
+        const U4 u = philox4x32_10((uint64_t)(r * KV + c), offset, seed);
+        rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float v = bias ? __fadd_rn(t[i], b[i]) : t[i];
+        if (relu) v = (v < 0.0f) ? 0.0f : v;  // NaN stays NaN, as torch.relu / clamp_min(0)
+        if (drop_thresh) v = (rw[i] >= drop_thresh) ? __fmul_rn(v, scale) : 0.0f;  // keep with prob 1 - p
+        t[i] = v;
+      }
+      if (VEC == 4) {
+        float4 o;
+        o.x = t[0]; o.y = t[1 % VEC]; o.z = t[2 % VEC]; o.w = t[3 % VEC];
+        *reinterpret_cast<float4 *>(y + r * K + c * 4) = o;
+      } else {
+        y[r * K + c] = t[0];
+      }
     }
   }
 }
@@ -67,7 +89,10 @@ __global__ void rng_advance_kernel(int64_t *rng, int64_t inc) {
   if (blockIdx.x == 0 && threadIdx.x == 0) rng[1] += inc;
 }
 
-// backward + bias-gradient stage 1: same geometry as colsum_stage1_kernel (backward.hip)
+// backward + first stage of the bias gradient.  Same thread geometry as the forward; every lane keeps a
+// running column sum of the ga values it produces and writes it to partial[(block * groups + j), :];
+// ggl_colsum_f32 (backward.hip) then reduces the [P, K] partial matrix.
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__restrict__ g,
                                                               const float *__restrict__ y,
                                                               float *__restrict__ ga, int64_t N,
@@ -75,38 +100,56 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
                                                               int groups, int masked, float scale,
                                                               float *__restrict__ partial) {
   const int j = threadIdx.x / kp;
-  const int k0 = threadIdx.x - j * kp;
+  const int c0 = threadIdx.x - j * kp;
   if (j >= groups) return;
+  const int64_t KV = (K + VEC - 1) / VEC;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
-  for (int64_t k = k0; k < K; k += kp) {
-    float acc = 0.0f;
+  for (int64_t c = c0; c < KV; c += kp) {
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
     for (int64_t r = r0 + j; r < r1; r += groups) {
-      const int64_t i = r * K + k;
-      float v = g[i];
-      if (masked) v = (y[i] > 0.0f) ? __fmul_rn(v, scale) : 0.0f;
-      ga[i] = v;
-      acc = __fadd_rn(acc, v);
+      float gv[VEC], yv[VEC];
+      if (VEC == 4) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(g + r * K + c * 4);
+        gv[0] = a4.x; gv[1 % VEC] = a4.y; gv[2 % VEC] = a4.z; gv[3 % VEC] = a4.w;
+        if (masked) {
+          const float4 b4 = *reinterpret_cast<const float4 *>(y + r * K + c * 4);
+          yv[0] = b4.x; yv[1 % VEC] = b4.y; yv[2 % VEC] = b4.z; yv[3 % VEC] = b4.w;
+        }
+      } else {
+        gv[0] = g[r * K + c];
+        if (masked) yv[0] = y[r * K + c];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        if (masked) gv[i] = (yv[i] > 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
+        acc[i] = __fadd_rn(acc[i], gv[i]);
+      }
+      if (VEC == 4) {
+        float4 o;
+        o.x = gv[0]; o.y = gv[1 % VEC]; o.z = gv[2 % VEC]; o.w = gv[3 % VEC];
+        *reinterpret_cast<float4 *>(ga + r * K + c * 4) = o;
+      } else {
+        ga[r * K + c] = gv[0];
+      }
     }
-    if (partial) partial[((int64_t)blockIdx.x * groups + j) * K + k] = acc;
+    if (partial) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) partial[((int64_t)blockIdx.x * groups + j) * K + c * VEC + i] = acc[i];
+    }
   }
 }
 
-__global__ __launch_bounds__(kBlock) void bias_colsum_stage2_kernel(const float *__restrict__ partial,
-                                                                    int64_t P, int64_t K,
-                                                                    float *__restrict__ out) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  float a = 0.f;
-  for (int64_t p = 0; p < P; ++p) a = __fadd_rn(a, partial[p * K + k]);
-  out[k] = a;
-}
-
-static inline void geometry(int64_t N, int64_t K, int *kp, int *groups, int64_t *blocks, int64_t *rpb) {
-  *kp = (int)(K < kBlock ? (K > 0 ? K : 1) : kBlock);
+// launch geometry shared by both directions: kp lanes x groups rows per block step, `blocks` row ranges
+static inline void geometry(int64_t N, int64_t K, bool vec4, int *kp, int *groups, int64_t *blocks,
+                            int64_t *rpb) {
+  const int64_t KV = vec4 ? K / 4 : K;
+  *kp = (int)(KV < kBlock ? (KV > 0 ? KV : 1) : kBlock);
   *groups = kBlock / *kp;
-  int64_t b = ceil_div(N > 0 ? N : 1, (int64_t)*groups * 16);
-  if (b > 2048) b = 2048;
+  int64_t b = ceil_div(N > 0 ? N : 1, (int64_t)*groups * 8);
+  if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   *blocks = b;
   *rpb = ceil_div(N > 0 ? N : 1, b);
@@ -127,11 +170,17 @@ extern "C" int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, in
   const uint32_t thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
   const float scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
   hipStream_t s = as_stream(stream);
-  const int64_t nvec = (total + 3) / 4;
-  int64_t grid = ceil_div(nvec, kBlock);
-  if (grid > 8192) grid = 8192;
-  GGL_LAUNCH((bias_act_fwd_kernel), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, total, K,
-             relu, thresh, scale);
+  const bool vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15u) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(y) & 15u) == 0);
+  int kp, groups;
+  int64_t grid, rpb;
+  geometry(N, K, vec4, &kp, &groups, &grid, &rpb);
+  if (vec4)
+    GGL_LAUNCH((bias_act_fwd_kernel<4>), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, N, K, rpb,
+               kp, groups, relu, thresh, scale);
+  else
+    GGL_LAUNCH((bias_act_fwd_kernel<1>), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, N, K, rpb,
+               kp, groups, relu, thresh, scale);
   GGL_LAUNCH_CHECK();
   if (thresh) {
     GGL_LAUNCH((rng_advance_kernel), 1, 64, s, rng_state, (int64_t)1);
@@ -140,11 +189,19 @@ extern "C" int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, in
   return GGL_OK;
 }
 
-extern "C" size_t ggl_bias_act_bwd_workspace_bytes(int64_t N, int64_t K) {
+static inline size_t bwd_partial_bytes(int64_t N, int64_t K) {
   int kp, groups;
   int64_t blocks, rpb;
-  geometry(N, K, &kp, &groups, &blocks, &rpb);
-  return (size_t)blocks * (size_t)groups * (size_t)(K > 0 ? K : 1) * sizeof(float);
+  geometry(N, K, false, &kp, &groups, &blocks, &rpb);
+  size_t a = (size_t)blocks * (size_t)groups;
+  geometry(N, K, K % 4 == 0, &kp, &groups, &blocks, &rpb);
+  const size_t b = (size_t)blocks * (size_t)groups;
+  return ((a > b ? a : b) * (size_t)(K > 0 ? K : 1) * sizeof(float) + 255) & ~(size_t)255;
+}
+
+extern "C" size_t ggl_bias_act_bwd_workspace_bytes(int64_t N, int64_t K) {
+  const size_t part = bwd_partial_bytes(N, K);
+  return part + ggl_colsum_workspace_bytes((int64_t)(part / sizeof(float) / (size_t)(K > 0 ? K : 1)), K);
 }
 
 extern "C" int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int relu,
@@ -157,19 +214,26 @@ extern "C" int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64
   GGL_REQUIRE(!masked || y || N == 0, GGL_EINVAL, "y is needed to rebuild the ReLU/dropout mask");
   GGL_REQUIRE(!gbias || (workspace && workspace_bytes >= ggl_bias_act_bwd_workspace_bytes(N, K)),
               GGL_EWORKSPACE, "bias_act_bwd workspace too small");
+  const bool vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(ga) & 15u) == 0) &&
+                    (!masked || (reinterpret_cast<uintptr_t>(y) & 15u) == 0);
   int kp, groups;
   int64_t blocks, rpb;
-  geometry(N, K, &kp, &groups, &blocks, &rpb);
+  geometry(N, K, vec4, &kp, &groups, &blocks, &rpb);
   const float scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
   hipStream_t s = as_stream(stream);
   float *partial = gbias ? static_cast<float *>(workspace) : nullptr;
-  GGL_LAUNCH((bias_act_bwd_kernel), blocks, kBlock, s, g, y, ga, N, K, rpb, kp, groups, masked, scale,
-             partial);
+  if (vec4)
+    GGL_LAUNCH((bias_act_bwd_kernel<4>), blocks, kBlock, s, g, y, ga, N, K, rpb, kp, groups, masked, scale,
+               partial);
+  else
+    GGL_LAUNCH((bias_act_bwd_kernel<1>), blocks, kBlock, s, g, y, ga, N, K, rpb, kp, groups, masked, scale,
+               partial);
   GGL_LAUNCH_CHECK();
-  if (gbias) {
-    GGL_LAUNCH((bias_colsum_stage2_kernel), ceil_div(K, kBlock), kBlock, s, (const float *)partial,
-               blocks * groups, K, gbias);
-    GGL_LAUNCH_CHECK();
+  if (gbias) {  // second stage: column sums of the [P, K] partial matrix
+    const size_t part = bwd_partial_bytes(N, K);
+    return ggl_colsum_f32(partial, blocks * groups, K, gbias, static_cast<char *>(workspace) + part,
+                          workspace_bytes - part, stream);
   }
   return GGL_OK;
 }
