@@ -151,25 +151,66 @@ class _HaloAggregate(torch.autograd.Function):
         return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None
 
 
+class _LinearSideWgrad(torch.autograd.Function):
+    """y = x @ W^T whose WEIGHT gradient (a compute-bound [out, N] x [N, in] GEMM that nothing needs before
+    the optimizer step) is issued on a side HIP stream, so it runs under the next layer's HBM-bound
+    transposed SpMM instead of in front of it.  The input gradient stays on the main stream."""
+
+    @staticmethod
+    def forward(ctx, x, w, side):
+        ctx.save_for_backward(x, w)
+        ctx.side = side
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        side = ctx.side
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if side is None or not g.is_cuda:
+                gw = g.t() @ x
+            else:
+                cur = torch.cuda.current_stream(g.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    gw = g.t() @ x
+                g.record_stream(side)
+                x.record_stream(side)
+                gw.record_stream(cur)  # consumed by the optimizer on the main stream after join()
+        return gx, gw, None
+
+
 class DistGCN(torch.nn.Module):
     """GCNModel(norm='none') on precomputed symmetric-normalised edge weights (models/gcn.py:30-64,
     gcn_conv.py:78-108 with norm='none'), each GCNConv's propagate replaced by the halo aggregate."""
 
-    def __init__(self, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5):
+    def __init__(self, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, overlap_wgrad=True):
         super().__init__()
+        self.overlap_wgrad = overlap_wgrad
         dims = [feature_dim] + [hidden_dim] * (num_layers - 1) + [num_class]
         self.lin = torch.nn.ModuleList([torch.nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
         self.bias = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, b)) for b in dims[1:]])
         for lin in self.lin:
             torch.nn.init.xavier_uniform_(lin.weight)
         self.dropout = torch.nn.Dropout(drop_rate)
+        self.side = None  # side stream for the weight-gradient GEMMs (created on first CUDA use)
+
+    def join(self):
+        """Make the current stream wait for the side-stream weight gradients (call before optimizer.step)."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def forward(self, x, pg):
         n = len(self.lin)
+        if x.is_cuda and self.side is None and self.overlap_wgrad:
+            self.side = torch.cuda.Stream(device=x.device)
         for i in range(n):
             hidden = i < n - 1
+            h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side)
             # + bias, ReLU and dropout of the hidden layers fused into one pass each way (epilogue.hip)
-            x = pg.eng.bias_act(pg.aggregate(self.lin[i](x)), self.bias[i], relu=hidden,
+            x = pg.eng.bias_act(pg.aggregate(h), self.bias[i], relu=hidden,
                                 p_drop=self.dropout.p if hidden else 0.0, training=self.training)
         return x
 
@@ -190,6 +231,7 @@ class DistGCNTrainer:
         logits = self.net(x_local, pg)
         loss = F.cross_entropy(logits[train_local], y_local[train_local], reduction="sum") / n_train_global
         loss.backward()
+        self.net.join()
         if pg.world > 1:  # one flat bucket: 3 small weight matrices + biases
             params = [p for p in self.net.parameters() if p.grad is not None]
             flat = torch.cat([p.grad.reshape(-1) for p in params])

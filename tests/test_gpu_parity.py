@@ -325,3 +325,31 @@ def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng, dev):
 
 def test_fused_bias_relu_dropout(eng, dev):
     pc.check_bias_act(eng, dev)
+
+
+def test_side_stream_weight_gradient_overlap(eng, dev):
+    """DistGCN issues its weight-gradient GEMMs on a side stream; gradients must equal the in-line run."""
+    import torch.nn.functional as F
+
+    from gammagl_amd.dist import DistGCN, PartitionedGraph
+    from gammagl_amd.synth import rmat_graph
+
+    N = 30000
+    ei = rmat_graph(N, 500000, seed=6, device=dev)
+    g = torch.Generator(device=dev).manual_seed(2)
+    w = torch.rand(ei.shape[1], generator=g, device=dev) + 0.1
+    pg = PartitionedGraph(ei, w, N, 0, 1, eng=eng)
+    x = torch.randn(N, 64, generator=g, device=dev)
+    y = torch.randint(0, 7, (N,), generator=g, device=dev)
+    grads = []
+    for overlap in (True, False):
+        torch.manual_seed(0)
+        net = DistGCN(64, 128, 7, 3, drop_rate=0.0, overlap_wgrad=overlap).to(dev)
+        for _ in range(3):  # repeated use of the side stream
+            net.zero_grad(set_to_none=True)
+            F.cross_entropy(net(x, pg), y).backward()
+            net.join()
+        torch.cuda.synchronize()
+        grads.append([p.grad.clone() for p in net.parameters()])
+    for a, b in zip(*grads):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)

@@ -34,6 +34,7 @@ for name, (n, e, f, c, hid, layers) in {"cora": (2708, 10556, 1433, 7, 16, 2), "
         opt.zero_grad(set_to_none=False)
         loss = F.cross_entropy(net(x, pg)[idx], y[idx])
         loss.backward()
+        net.join()  # side-stream weight gradients back into the (captured) main stream
         opt.step()
         loss_buf.copy_(loss.detach())
 
