@@ -64,7 +64,6 @@ struct Options {
   // 0 = natural row order; 1 = length-sorted rows where several rows share a wavefront (balances
   // the lanes of a wave); 2 = also for the wave-per-row kernels (heavy rows first)
   int64_t row_order = 1;
-  int64_t rows_per_block_log2 = -1;  // reserved
 };
 Options &options();
 

@@ -247,7 +247,6 @@ class DistGCNTrainer:
 
 def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls, eng=None):
     """bench.py body for any world size (world == 1 degenerates to no exchange)."""
-    from .layers import calc_gcn_norm
     from .synth import rmat_graph
 
     eng = eng if eng is not None else _default_engine()

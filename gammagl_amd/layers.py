@@ -16,13 +16,10 @@ here); every tlx call they make on this path maps 1:1 onto torch (``tlx.gather``
   the external dgNN GATConvFuse
 * ``GCNModel``        — models/gcn.py:30-64
 """
-import math
-
 import torch
 from torch import nn
 
 from . import engine as _engine
-from . import mpops
 from .mpops import (gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
                     unsorted_segment_sum, use_ext)
 
@@ -240,4 +237,4 @@ class GCNModel(nn.Module):
 
 
 __all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "degree",
-           "calc_gcn_norm", "segment_softmax", "add_self_loops", "mpops", "math"]
+           "calc_gcn_norm", "segment_softmax", "add_self_loops"]

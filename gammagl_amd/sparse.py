@@ -9,8 +9,6 @@ stay on the GPU (rocPRIM radix sort + binary-search kernels in ``csrc/plan.hip``
 reference's, with one strengthening: ties in ``sort_edge_index`` keep their original order (the
 reference's argsort leaves them unspecified).
 """
-import ctypes
-
 import torch
 
 from . import engine as _engine
@@ -66,4 +64,4 @@ def sort_edge_index(edge_index, edge_attr=None, num_nodes=None, sort_by_row=True
     return out, [e.index_select(0, p) for e in edge_attr]
 
 
-__all__ = ["ind2ptr", "ptr2ind", "sort_edge_index", "ctypes"]
+__all__ = ["ind2ptr", "ptr2ind", "sort_edge_index"]
