@@ -244,6 +244,48 @@ class Engine:
         p.uid = self.stats["plans_built"]
         return p
 
+    def plan_from_rowptr(self, rowptr, E, max_len=None):
+        """SegPlan for elements that are ALREADY grouped by segment (CSR: a sampler's block, a sorted edge
+        list): no sort, and no host sync when the caller knows ``max_len`` (e.g. the fan-out)."""
+        dev = self._dev(rowptr)
+        p = SegPlan()
+        p.N, p.E, p.chunk, p.device = int(rowptr.shape[0]) - 1, int(E), self.chunk, dev
+        p.rowptr = rowptr.contiguous().to(torch.int64)
+        p.perm, p.is_sorted = None, True
+        p.max_len = int(max_len) if max_len is not None else (int(p.counts().max()) if p.N > 0 else 0)
+        p.n_long = p.n_chunks = 0
+        p.long_rows = p.chunk_ptr = None
+        if p.max_len > p.chunk:
+            st = self._stream(dev)
+            lwb = self.lib.ggl_plan_long_workspace_bytes(p.N)
+            lws = torch.empty(lwb, dtype=torch.uint8, device=dev)
+            nl, nc = ctypes.c_int64(0), ctypes.c_int64(0)
+            self._check(self.lib.ggl_plan_long_count(_ptr(p.rowptr), p.N, p.chunk, _ptr(lws), lwb, st,
+                                                     ctypes.byref(nl), ctypes.byref(nc)))
+            p.n_long, p.n_chunks = int(nl.value), int(nc.value)
+            p.long_rows = torch.empty(p.n_long, dtype=torch.int32, device=dev)
+            p.chunk_ptr = torch.empty(p.n_long + 1, dtype=torch.int64, device=dev)
+            self._check(self.lib.ggl_plan_long_fill(_ptr(p.rowptr), p.N, p.chunk, p.n_long,
+                                                    _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws), lwb, st))
+        p.row_order = None
+        if p.N > 1:
+            p.row_order = torch.argsort(p.counts(), descending=True, stable=True).to(torch.int32)
+        self.stats["plans_built"] += 1
+        p.uid = self.stats["plans_built"]
+        return p
+
+    def adopt_plan(self, ids, N, plan):
+        """Register a plan built elsewhere (e.g. straight from a sampler's CSR block) for the id tensor
+        the layers will pass to unsorted_segment_*: the call then hits the cache — no sort, no sync."""
+        self.seg_cache.put(ids, (int(N), self.chunk), plan)
+
+    def segment_reduce(self, x, plan, op="sum"):
+        """sum / mean / max of x[E, ...] over an explicit plan (no autograd): the aggregate of a sampled
+        block whose edges are already grouped by destination."""
+        self._dev(x)
+        out, arg = self._segment_fwd(op, x.contiguous(), plan)
+        return out if op != "max" else (out, arg)
+
     def seg_plan(self, ids, N):
         plan = self.seg_cache.get(ids, (int(N), self.chunk))
         if plan is None:

@@ -265,6 +265,21 @@ int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *colT, const
                           int64_t C, float *gx, float *gel, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Uniform neighbour sampling — supersedes ops/sparse sample_adj
+ * (cpu/sample.cpp:10-135).  CSR (rowptr [M+1], col [nnz]) int64; seeds [B] int64 row ids.
+ *   ggl_sample_count: out_deg[i] = deg (fanout < 0) | fanout if deg > 0 (replace) | min(deg, fanout)
+ *   ggl_sample_pick : given out_rowptr = exclusive prefix of out_deg, writes for every seed its sampled
+ *                     positions e_pos (indices into col) and neighbours nbr = col[e_pos]; distinct
+ *                     positions by Floyd's algorithm when !replace (sample.cpp:75-83); Philox4x32-10 on
+ *                     rng_state = {seed, offset} (device int64[2], offset advanced after the launch).
+ * ---------------------------------------------------------------------------------------------- */
+int ggl_sample_count(const int64_t *rowptr, const int64_t *seeds, int64_t B, int64_t fanout, int replace,
+                     int64_t *out_deg, void *stream);
+int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const int64_t *seeds, int64_t B,
+                    int64_t fanout, int replace, const int64_t *out_rowptr, int64_t *rng_state,
+                    int64_t *e_pos, int64_t *nbr, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Tuning knobs (process-wide; also read once from the environment: GGL_UNROLL, GGL_XCD_SWIZZLE,
  * GGL_FORCE_GENERIC, GGL_ROW_ORDER).  For A/B measurements only — results do not depend on them.
  * ---------------------------------------------------------------------------------------------- */

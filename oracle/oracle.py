@@ -277,3 +277,31 @@ def load_ref_ext():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+# ---- neighbour sampling: the deterministic branch of sample_adj, restated in Python ----------------
+def sample_adj_full(rowptr, col, idx):
+    """ops/sparse/cpu/sample.cpp:10-135 with num_neighbors < 0 (no sampling, :39-55): n_id = seeds then
+    new nodes in first-seen order (:24-29,:48-51); every row's (local col, e_id) pairs sorted by local
+    id (:112-118).  Returns (out_rowptr, out_col, out_n_id, out_e_id) as int64 arrays."""
+    rowptr, col, idx = np.asarray(rowptr), np.asarray(col), np.asarray(idx)
+    n_ids = [int(i) for i in idx]
+    n_id_map = {}
+    for n, i in enumerate(n_ids):
+        n_id_map[i] = n          # a seed listed twice maps to its LAST position (operator[] overwrite, :27)
+    out_rowptr = [0]
+    cols = []
+    for n in idx:
+        row = []
+        for e in range(int(rowptr[n]), int(rowptr[n + 1])):
+            c = int(col[e])
+            if c not in n_id_map:
+                n_id_map[c] = len(n_ids)
+                n_ids.append(c)
+            row.append((n_id_map[c], e))
+        row.sort(key=lambda t: t[0])
+        cols.append(row)
+        out_rowptr.append(out_rowptr[-1] + len(row))
+    flat = [t for r in cols for t in r]
+    return (np.array(out_rowptr, np.int64), np.array([t[0] for t in flat], np.int64),
+            np.array(n_ids, np.int64), np.array([t[1] for t in flat], np.int64))

@@ -434,6 +434,81 @@ def check_convert(eng, dev):
     assert torch.equal(s[:, permute], s2) and int(col_ptr[-1]) == E
 
 
+def check_sampler(eng, dev, oracle):
+    """sample_adj / NeighborSampler: the deterministic branch bit-for-bit vs the restated reference
+    (sample.cpp:39-55,104-130); the random branches through the invariants the reference guarantees
+    (distinct positions, min(deg, fanout) per row, columns sorted by local id, seeds first) and a
+    uniformity check of Floyd's algorithm on Philox."""
+    import ctypes
+
+    from gammagl_amd import sampler
+    from gammagl_amd.ops import _ptr
+
+    rng = np.random.default_rng(12)
+    N, E = 300, 4000
+    ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
+    ei[1, :60] = 7  # one heavy row
+    order = np.argsort(ei[1], kind="stable")
+    rowptr = np.concatenate(([0], np.cumsum(np.bincount(ei[1], minlength=N)))).astype(np.int64)
+    col = ei[0][order]
+    rp, cl = to_t(rowptr, dev), to_t(col, dev)
+    perm_nodes = rng.permutation(N)
+    seeds = np.concatenate(([7], perm_nodes[perm_nodes != 7][:63])).astype(np.int64)  # unique, heavy row first
+    idx = to_t(seeds, dev)
+    # (1) no sampling: exact
+    got = sampler.sample_adj(rp, cl, idx, -1, eng=eng)
+    ref = oracle.sample_adj_full(rowptr, col, seeds)
+    for a, b, nm in zip(got, ref, ("rowptr", "col", "n_id", "e_id")):
+        assert_same(to_np(a), b, "sample_adj full " + nm)
+    deg = rowptr[seeds + 1] - rowptr[seeds]
+    for fanout, replace in ((5, False), (25, False), (10, True)):
+        orp, ocol, n_id, e_pos = (to_np(t) for t in sampler.sample_adj(rp, cl, idx, fanout, replace, eng=eng))
+        k = np.diff(orp)
+        want = np.where(deg > 0, fanout, 0) if replace else np.minimum(deg, fanout)
+        assert (k == want).all()
+        assert (n_id[: len(seeds)] == seeds).all() and len(np.unique(n_id)) == len(n_id)
+        assert (n_id[ocol] == col[e_pos]).all()  # local ids map back to the sampled neighbours
+        for i, s in enumerate(seeds):
+            pos = e_pos[orp[i]:orp[i + 1]]
+            assert ((pos >= rowptr[s]) & (pos < rowptr[s + 1])).all()
+            if not replace:
+                assert len(np.unique(pos)) == len(pos)
+                if deg[i] <= fanout:
+                    assert sorted(pos.tolist()) == list(range(rowptr[s], rowptr[s + 1]))
+            assert (np.diff(ocol[orp[i]:orp[i + 1]]) >= 0).all()  # sorted by local id
+    # (2) uniformity of the without-replacement draw on the heavy row (deg 60+, fanout 10)
+    B, f = 4000, 10
+    sd = torch.full((B,), 7, dtype=torch.int64, device=dev)
+    d7 = int(rowptr[8] - rowptr[7])
+    orp = torch.arange(0, (B + 1) * f, f, dtype=torch.int64, device=dev)
+    e_pos = torch.empty(B * f, dtype=torch.int64, device=dev)
+    nbr = torch.empty(B * f, dtype=torch.int64, device=dev)
+    eng._check(eng.lib.ggl_sample_pick(_ptr(rp), _ptr(cl), _ptr(sd), B, f, 0, _ptr(orp), _ptr(eng._rng_state(dev)),
+                                       _ptr(e_pos), _ptr(nbr), eng._stream(dev)))
+    cnt = np.bincount(to_np(e_pos) - rowptr[7], minlength=d7)
+    exp = B * f / d7
+    assert cnt.sum() == B * f and np.abs(cnt - exp).max() < 6 * np.sqrt(exp), (cnt.min(), cnt.max(), exp)
+    assert (to_np(e_pos).reshape(B, f)[0] != to_np(e_pos).reshape(B, f)[1]).any()  # rows draw independently
+    # (3) two-hop NeighborSampler + the aggregate straight from the block's CSR (no sort, no plan sync)
+    ns = sampler.NeighborSampler(to_t(ei, dev), [5, 3], num_nodes=N, eng=eng)
+    batch, n_id, adjs = ns.sample(seeds[:16])
+    assert len(adjs) == 2 and adjs[1].size[1] == 16 and adjs[0].size[1] == adjs[1].size[0]
+    assert adjs[0].size[0] == n_id.shape[0]
+    for adj in adjs:
+        src_l, dst_l = adj.edge_index
+        assert int(src_l.max()) < adj.size[0] and int(dst_l.max()) < adj.size[1]
+        assert bool((to_t(ei, dev)[:, adj.e_id][1] >= 0).all())
+    adj = adjs[0]
+    x = torch.randn(adj.size[0], 12, generator=torch.Generator().manual_seed(0)).to(dev)
+    plan = eng.plan_from_rowptr(adj.rowptr, adj.edge_index.shape[1], max_len=adj.fanout)
+    got = eng.segment_reduce(x[adj.edge_index[0]], plan, "mean")
+    ref = eng.c_segment_mean(x[adj.edge_index[0]], adj.edge_index[1].contiguous(), adj.size[1])
+    assert torch.equal(got, ref)
+    # the global edges the block refers to are real edges between the right nodes
+    g_src, g_dst = to_t(ei, dev)[0][adj.e_id], to_t(ei, dev)[1][adj.e_id]
+    assert torch.equal(n_id[adj.edge_index[0]], g_src)
+
+
 def check_colsum(eng, dev):
     """bias-gradient kernel: column sums vs an f64 sum; also through BiasAdd's autograd."""
     g = torch.Generator(device="cpu").manual_seed(2)

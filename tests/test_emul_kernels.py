@@ -77,3 +77,7 @@ def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng):
 
 def test_fused_bias_relu_dropout(eng):
     pc.check_bias_act(eng, DEV)
+
+
+def test_neighbor_sampler(eng, oracle):
+    pc.check_sampler(eng, DEV, oracle)

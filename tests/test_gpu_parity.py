@@ -353,3 +353,7 @@ def test_side_stream_weight_gradient_overlap(eng, dev):
         grads.append([p.grad.clone() for p in net.parameters()])
     for a, b in zip(*grads):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_neighbor_sampler(eng, dev, oracle):
+    pc.check_sampler(eng, dev, oracle)

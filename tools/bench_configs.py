@@ -93,59 +93,43 @@ if "3" in which:
     eng.seg_cache.clear(); eng.graph_cache.clear(); torch.cuda.empty_cache()
 
 if "4" in which:
+    from gammagl_amd.sampler import NeighborSampler
+
     n, e, f, c = DATASETS["products"]
     ei = rmat_graph(n, e, seed=0, device=dev)
-    plan = eng.seg_plan(ei[1].contiguous(), n)          # CSR by destination = in-neighbour lists
-    rowptr, col = plan.rowptr, eng.gather_i32(ei[0].contiguous(), plan.perm).long()
+    t0 = time.perf_counter()
+    ns = NeighborSampler(ei, [25, 10], num_nodes=n)   # reddit_sage_trainer.py:55-57: sample_lists=[25, 10]
+    torch.cuda.synchronize()
+    print(f"[4] NeighborSampler CSR build on the products-sized graph: {time.perf_counter() - t0:.2f} s", flush=True)
     x = torch.randn(n, f, generator=g, device=dev)
-
-    def sample_block(seeds, fanout):
-        deg = rowptr[seeds + 1] - rowptr[seeds]
-        k = torch.clamp(deg, max=fanout)
-        owner = torch.repeat_interleave(torch.arange(seeds.numel(), device=dev), k)
-        start = torch.cumsum(k, 0) - k
-        pos_in = torch.arange(owner.numel(), device=dev) - start[owner]
-        r = torch.rand(owner.numel(), generator=g, device=dev)
-        off = torch.where(deg[owner] <= fanout, pos_in, (r * deg[owner]).long())
-        src = col[rowptr[seeds][owner] + off]
-        n_id, inv = torch.unique(torch.cat([seeds, src]), return_inverse=True)  # dst nodes first? keep both maps
-        return src, owner, n_id, inv
-
     sage1 = layers.SAGEConv(f, 256, aggr="mean").to(dev)
     sage2 = layers.SAGEConv(256, c, aggr="mean").to(dev)
+    sizes = {}
+
+    def sample_only():
+        seeds = torch.randperm(n, generator=g, device=dev)[:2048]
+        return ns.sample(seeds)
 
     def batch():
-        seeds = torch.randint(0, n, (2048,), generator=g, device=dev)
-        s2, o2, _, _ = sample_block(seeds, 10)                      # hop 2 (outer): seeds <- 10 neighbours
-        l1 = torch.unique(torch.cat([seeds, s2]))                   # nodes of layer 1
-        s1, o1, _, _ = sample_block(l1, 25)                         # hop 1: layer-1 nodes <- 25 neighbours
-        src_nodes, inv = torch.unique(torch.cat([l1, s1]), return_inverse=True)
-        # block 1: N_src = |src_nodes| -> N_dst = |l1|
-        e1 = torch.stack([inv[l1.numel():], torch.searchsorted(l1, l1[o1])])
-        h0 = x[src_nodes]
-        dst_feat = x[l1]
-        h1 = torch.relu(sage1((h0, dst_feat), e1))
-        e2 = torch.stack([torch.searchsorted(l1, s2), o2])
-        pos_seed = torch.searchsorted(l1, seeds)
-        out = sage2((h1, h1[pos_seed]), e2)
-        out.sum().backward()
-        return e1.shape[1], e2.shape[1], src_nodes.numel(), l1.numel()
+        _, n_id, adjs = sample_only()
+        h = x[n_id]                                       # models/graphsage.py:76-82
+        for i, (conv, adj) in enumerate(zip((sage1, sage2), adjs)):
+            h = conv((h, h[: adj.size[1]]), adj.edge_index)
+            if i == 0:
+                h = torch.relu(h)
+        h.sum().backward()
+        sizes.update(b1=adjs[0].edge_index.shape[1], s1=adjs[0].size, b2=adjs[1].edge_index.shape[1], s2=adjs[1].size)
 
-    e1n, e2n, ns, nl = batch()
+    batch()
     b0 = eng.stats["plans_built"]
+    ms_s = timeit(sample_only, reps=10, warm=2)
     ms = timeit(batch, reps=10, warm=2)
-    print(f"[4] SAGE mini-batch (seeds 2048, fanout [25,10]) block1 E={e1n} ({ns}->{nl}), block2 E={e2n} ({nl}->2048): "
-          f"sample + 2x SAGEConv(mean) fwd+bwd = {ms:.2f} ms/batch; plans built per batch = "
-          f"{(eng.stats['plans_built'] - b0) / 12:.1f}")
-    # the aggregate alone on a block-1 sized problem, plan build included (new edge list every batch)
-    srcb = torch.randint(0, ns, (e1n,), generator=g, device=dev)
+    print(f"    seeds 2048, fanout [25,10]: block1 E={sizes['b1']} {sizes['s1']}, block2 E={sizes['b2']} {sizes['s2']}: "
+          f"2-hop sampling {ms_s:.2f} ms, sample + gather + 2x SAGEConv(mean) fwd+bwd {ms:.2f} ms/batch")
+    e1n, (ns_, nl) = sizes["b1"], sizes["s1"]
     dstb = torch.sort(torch.randint(0, nl, (e1n,), generator=g, device=dev)).values
     hb = torch.randn(e1n, 256, generator=g, device=dev)
-
-    def agg_fresh():
-        d = dstb.clone()  # a new tensor = a new plan
-        return eng.c_segment_mean(hb, d, nl)
-
-    ms_fresh = timeit(agg_fresh, reps=20)
+    ms_fresh = timeit(lambda: eng.c_segment_mean(hb, dstb.clone(), nl), reps=20)
     ms_cached = timeit(lambda: eng.c_segment_mean(hb, dstb, nl), reps=20)
-    print(f"    unsorted_segment_mean [E={e1n},256] -> [{nl},256]: {ms_cached:.3f} ms cached plan, {ms_fresh:.3f} ms incl. plan build")
+    print(f"    unsorted_segment_mean [E={e1n},256] -> [{nl},256]: {ms_cached:.3f} ms with the sampler's CSR plan, "
+          f"{ms_fresh:.3f} ms when the plan is rebuilt from the ids (sort + 2 syncs)")
