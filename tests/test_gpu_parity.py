@@ -357,3 +357,47 @@ def test_side_stream_weight_gradient_overlap(eng, dev):
 
 def test_neighbor_sampler(eng, dev, oracle):
     pc.check_sampler(eng, dev, oracle)
+
+
+def test_training_step_captures_into_a_hipgraph(eng, dev):
+    """Cora-sized 2-layer GCN (configs[0] shape): eager and hipGraph-replayed steps give the same loss."""
+    import torch.nn.functional as F
+
+    from gammagl_amd.dist import DistGCN, PartitionedGraph
+    from gammagl_amd.layers import calc_gcn_norm
+    from gammagl_amd.synth import rmat_graph
+    from gammagl_amd.trainer import GraphedStep
+
+    n, f, c = 2708, 1433, 7
+    ei = rmat_graph(n, 10556, seed=0, device=dev)
+    pg = PartitionedGraph(ei, calc_gcn_norm(ei, n).contiguous(), n, 0, 1, eng=eng)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(n, f, generator=g, device=dev)
+    y = torch.randint(0, c, (n,), generator=g, device=dev)
+    idx = torch.arange(0, n, 2, device=dev)
+
+    def make():
+        torch.manual_seed(0)
+        net = DistGCN(f, 16, c, 2, drop_rate=0.0).to(dev)
+        opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=5e-4, capturable=True)
+        loss_buf = torch.zeros((), device=dev)
+
+        def step():
+            opt.zero_grad(set_to_none=False)
+            loss = F.cross_entropy(net(x, pg)[idx], y[idx])
+            loss.backward()
+            net.join()
+            opt.step()
+            loss_buf.copy_(loss.detach())
+            return loss_buf
+
+        return step
+
+    eager = make()
+    for _ in range(3 + 5):
+        le = float(eager())
+    graphed = GraphedStep(make(), warmup=3)
+    for _ in range(5 - 1):  # capture itself does not execute the step's kernels
+        graphed()
+    lg = float(graphed())
+    assert abs(le - lg) <= 1e-4 * abs(le) + 1e-6, (le, lg)
