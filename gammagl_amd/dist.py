@@ -154,12 +154,16 @@ class _HaloAggregate(torch.autograd.Function):
 class _LinearSideWgrad(torch.autograd.Function):
     """y = x @ W^T whose WEIGHT gradient (a compute-bound [out, N] x [N, in] GEMM that nothing needs before
     the optimizer step) is issued on a side HIP stream, so it runs under the next layer's HBM-bound
-    transposed SpMM instead of in front of it.  The input gradient stays on the main stream."""
+    transposed SpMM instead of in front of it.  The input gradient stays on the main stream.
+
+    The side-stream result is NOT returned through autograd: AccumulateGrad would read it on the main
+    stream right away (``grad += gw`` when a .grad already exists) without waiting for the side stream.
+    It is parked in ``sink`` and installed by ``DistGCN.join()`` after the streams are joined."""
 
     @staticmethod
-    def forward(ctx, x, w, side):
+    def forward(ctx, x, w, side, sink):
         ctx.save_for_backward(x, w)
-        ctx.side = side
+        ctx.side, ctx.sink = side, sink
         return x @ w.t()
 
     @staticmethod
@@ -175,11 +179,12 @@ class _LinearSideWgrad(torch.autograd.Function):
                 cur = torch.cuda.current_stream(g.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    gw = g.t() @ x
+                    gws = g.t() @ x
                 g.record_stream(side)
                 x.record_stream(side)
-                gw.record_stream(cur)  # consumed by the optimizer on the main stream after join()
-        return gx, gw, None
+                gws.record_stream(cur)  # consumed on the main stream after join()
+                ctx.sink.append((w, gws))
+        return gx, gw, None, None
 
 
 class DistGCN(torch.nn.Module):
@@ -196,11 +201,19 @@ class DistGCN(torch.nn.Module):
             torch.nn.init.xavier_uniform_(lin.weight)
         self.dropout = torch.nn.Dropout(drop_rate)
         self.side = None  # side stream for the weight-gradient GEMMs (created on first CUDA use)
+        self._sink = []   # (weight, side-stream gradient) pairs waiting for join()
 
     def join(self):
-        """Make the current stream wait for the side-stream weight gradients (call before optimizer.step)."""
+        """Join the side stream and install the weight gradients it produced (call after backward, before
+        anything reads the .grad of a Linear weight)."""
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        for w, gw in self._sink:
+            if w.grad is None:
+                w.grad = gw
+            else:
+                w.grad.add_(gw)
+        self._sink.clear()
 
     def forward(self, x, pg):
         n = len(self.lin)
@@ -208,7 +221,7 @@ class DistGCN(torch.nn.Module):
             self.side = torch.cuda.Stream(device=x.device)
         for i in range(n):
             hidden = i < n - 1
-            h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side)
+            h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink)
             # + bias, ReLU and dropout of the hidden layers fused into one pass each way (epilogue.hip)
             x = pg.eng.bias_act(pg.aggregate(h), self.bias[i], relu=hidden,
                                 p_drop=self.dropout.p if hidden else 0.0, training=self.training)

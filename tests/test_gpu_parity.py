@@ -345,8 +345,8 @@ def test_side_stream_weight_gradient_overlap(eng, dev):
     for overlap in (True, False):
         torch.manual_seed(0)
         net = DistGCN(64, 128, 7, 3, drop_rate=0.0, overlap_wgrad=overlap).to(dev)
-        for _ in range(3):  # repeated use of the side stream
-            net.zero_grad(set_to_none=True)
+        for it in range(4):  # repeated use of the side stream, both .grad modes
+            net.zero_grad(set_to_none=(it % 2 == 0))
             F.cross_entropy(net(x, pg), y).backward()
             net.join()
         torch.cuda.synchronize()
