@@ -82,10 +82,25 @@ def cpu_baseline(hidden, classes, seed):
             orc.spmm_sum_bwd(ein, wn, x.numpy())
     dt = time.perf_counter() - t0
     impl = "reference c_spmm_sum (oracle/_ref)" if kind == "reference" else "oracle C port"
+    # second baseline: the reference's pure-torch formulation of the same aggregate
+    # (mpops/torch.py:16-18,335-342: x[src] * w -> zeros().scatter_add_), all host threads, smaller sample
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    e_t = min(E, 3_000_000)
+    src, dst, wt = ei[0, :e_t], ei[1, :e_t], w[:e_t]
+    t1 = time.perf_counter()
+    for x in feats:
+        for s_, d_ in ((src, dst), (dst, src)):
+            msg = x[s_] * wt.view(-1, 1)
+            torch.zeros_like(x).scatter_add_(0, d_.view(-1, 1).expand_as(msg), msg)
+    dt_t = time.perf_counter() - t1
     return {
         "value": 6 * E / dt, "unit": "edges/s", "cores": 1, "kind": kind,
         "sample": f"R-MAT N={n_s} E={E} (loops incl.), the 6 aggregations of one 3-layer GCN step "
-                  f"(K={widths} fwd + transposed bwd), {impl}, {dt:.1f} s on 1 core of {os.cpu_count()}",
+                  f"(K={widths} fwd + transposed bwd), {impl}, {dt:.1f} s on 1 core of {cores}",
+        "torch_fallback": {"value": 6 * e_t / dt_t, "unit": "edges/s", "cores": cores,
+                           "sample": f"pure-torch mpops formulation (gather * w -> scatter_add_), first {e_t} edges of "
+                                     f"the same sample, {dt_t:.1f} s on {cores} threads"},
     }
 
 
