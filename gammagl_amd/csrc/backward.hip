@@ -62,7 +62,18 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_kernel(const int64_t *ind
     const float *xr = x + (index[e] * H + h) * C;
     const float *gr = g + (index[e + E] * H + h) * C;
     float acc = 0.0f;
-    for (int64_t c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(xr[c], gr[c]));
+    if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(xr) | reinterpret_cast<uintptr_t>(gr)) & 15u) == 0) {
+      for (int64_t c = 0; c < C; c += 4) {  // 16-byte loads; same products added in the same order
+        const float4 a = *reinterpret_cast<const float4 *>(xr + c);
+        const float4 b = *reinterpret_cast<const float4 *>(gr + c);
+        acc = __fadd_rn(acc, __fmul_rn(a.x, b.x));
+        acc = __fadd_rn(acc, __fmul_rn(a.y, b.y));
+        acc = __fadd_rn(acc, __fmul_rn(a.z, b.z));
+        acc = __fadd_rn(acc, __fmul_rn(a.w, b.w));
+      }
+    } else {
+      for (int64_t c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(xr[c], gr[c]));
+    }
     gw[i] = acc;
   }
 }

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void gat_rowdot_kernel(const float *__restr
 }
 
 // one thread per (sorted position p, head h)
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
     const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const float *__restrict__ el,
     const float *__restrict__ er, const float *__restrict__ x, const float *__restrict__ g,
@@ -258,7 +259,15 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
     const float *__restrict__ gi = g + i * K + h * C;
     const float *__restrict__ xj = x + src * K + h * C;
     float da = 0.0f;
-    for (int64_t c = 0; c < C; ++c) da = __fadd_rn(da, __fmul_rn(gi[c], xj[c]));
+    // VEC = 4 (C % 4 == 0): the head's C channels as 16-byte loads — 8 lanes x 16 B per instruction
+    // instead of 64 strided dwords (the scalar form made this kernel 19 ms of a 42 ms GAT step)
+    for (int64_t c = 0; c < C; c += VEC) {
+      float gv[VEC], xv[VEC];
+      F32V<VEC>::load(gi + c, gv);
+      F32V<VEC>::load(xj + c, xv);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) da = __fadd_rn(da, __fmul_rn(gv[q], xv[q]));
+    }
     const float ds = __fmul_rn(al, __fadd_rn(da, -dot[i * H + h]));
     alpha[t] = al;
     de[t] = raw > 0.0f ? ds : __fmul_rn(ds, d.slope);
@@ -350,8 +359,14 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
   GGL_LAUNCH((gat_rowdot_kernel), grid_for(N * H), kBlock, s, g, out, N * H, C, dot_ws);
   GGL_LAUNCH_CHECK();
   if (E > 0) {
-    GGL_LAUNCH((gat_bwd_edge_kernel), grid_for(E * H), kBlock, s, col, rowidx, el, er, x, g, rowmax,
-               rowden, (const float *)dot_ws, alpha, de, d);
+    const bool vec4 = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(g) & 15u) == 0);
+    if (vec4)
+      GGL_LAUNCH((gat_bwd_edge_kernel<4>), grid_for(E * H), kBlock, s, col, rowidx, el, er, x, g, rowmax,
+                 rowden, (const float *)dot_ws, alpha, de, d);
+    else
+      GGL_LAUNCH((gat_bwd_edge_kernel<1>), grid_for(E * H), kBlock, s, col, rowidx, el, er, x, g, rowmax,
+                 rowden, (const float *)dot_ws, alpha, de, d);
     GGL_LAUNCH_CHECK();
   }
   // ger[i,h] = sum over the row's positions of de: de already lives in sorted positions
