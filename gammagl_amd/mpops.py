@@ -75,9 +75,8 @@ def segment_sum(x, segment_ids, num_segments=None):
 def gspmm(index, weight=None, x=None, reduce='sum'):
     """Generalized SpMM: out[dst] = reduce_e weight[e] * x[src] (torch.py:302-351)."""
     eng = _engine()
-    if weight is None:
-        # torch.py:332-333 builds ones([E]) f32; w * x == x exactly, so the kernel skips the multiply
-        weight = None
+    # weight=None: torch.py:332-333 builds ones([E]) f32; w * x == x exactly, so the kernels simply skip
+    # the multiply when no weight pointer is passed
     if reduce == 'sum':
         return eng.c_spmm_sum(index, weight, x)
     elif reduce == 'mean':
