@@ -12,12 +12,14 @@ node of 8 MI355X, one process per GPU over ``torch.distributed`` (backend "nccl"
   (4) after the wait, the SpMM over the edges whose source arrived in the halo buffer, added in.
   backward: transposed halo SpMM -> reverse all-to-all-v, overlapped with the transposed local SpMM,
   then a deterministic segment-sum of the returned rows into the local gradient (no atomics);
+  the exchange is cut into feature-column chunks so that chunk c+1 travels while chunk c is multiplied;
 * weight gradients: one flat all-reduce per step (3 small matrices).
 
 Every output row is still reduced on exactly one GPU by the same kernels as the single-GPU path;
 only the association (local edges first, then halo edges) differs, so results agree with the
 single-GPU run to float rounding (<= 1e-5 relative), not bit for bit.
 """
+import os
 import time
 
 import torch
@@ -25,6 +27,8 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import engine as _default_engine
+
+HALO_CHUNKS = int(os.environ.get("GGL_HALO_CHUNKS", "0"))  # 0 = automatic (4 at K >= 256, 2 at K >= 128)
 
 
 def balanced_bounds(dst, num_nodes, world):
@@ -113,20 +117,37 @@ class _HaloAggregate(torch.autograd.Function):
         return t if k % 4 == 0 else torch.nn.functional.pad(t, (0, (-k) % 4))
 
     @staticmethod
+    def _chunks(K):
+        """Feature-column chunks of the exchange: the all-to-all-v of chunk c+1 runs while the halo SpMM of
+        chunk c computes (RCCL executes the queued collectives in order on its own stream; the compute
+        stream only waits for the chunk it is about to use)."""
+        n = HALO_CHUNKS if HALO_CHUNKS > 0 else (4 if K >= 256 else 2 if K >= 128 else 1)
+        while n > 1 and K % (4 * n) != 0:
+            n -= 1
+        w = K // n
+        return [(i * w, (i + 1) * w) for i in range(n)]
+
+    @staticmethod
     def forward(ctx, h, pg):
         eng = pg.eng
         ctx.k_orig = h.shape[1]
         h = _HaloAggregate._pad4(h.contiguous())
-        work = recv = None
+        works = []
         if pg.comm:
-            send = h.index_select(0, pg.send_idx)
-            recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits)
+            for (c0, c1) in _HaloAggregate._chunks(h.shape[1]):
+                send = h.index_select(0, pg.send_idx) if c1 - c0 == h.shape[1] else \
+                    h[:, c0:c1].index_select(0, pg.send_idx).contiguous()
+                recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits)
+                works.append((c0, c1, recv, work))
         out, _ = eng._spmm_fwd("sum", pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, pg.n_local)  # overlaps the exchange
-        if work is not None:
+        for (c0, c1, recv, work) in works:
             work.wait()
             if pg.n_halo > 0:
                 o2, _ = eng._spmm_fwd("sum", pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, pg.n_local)
-                out.add_(o2)
+                if c1 - c0 == out.shape[1]:
+                    out.add_(o2)
+                else:
+                    out[:, c0:c1].add_(o2)
         ctx.pg = pg
         return out if out.shape[1] == ctx.k_orig else out[:, :ctx.k_orig].contiguous()
 
@@ -135,19 +156,25 @@ class _HaloAggregate(torch.autograd.Function):
         pg = ctx.pg
         eng = pg.eng
         g = _HaloAggregate._pad4(g.contiguous())
-        work = gsend = None
+        works = []
         if pg.comm:
-            if pg.n_halo > 0:
-                ghalo, _ = eng._spmm_fwd("sum", pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g, pg.n_halo)
-            else:
-                ghalo = torch.empty((0,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-            gsend, work = pg._a2a(pg.n_send, ghalo, pg.send_splits, pg.recv_splits)
+            for (c0, c1) in _HaloAggregate._chunks(g.shape[1]):
+                gc = g if c1 - c0 == g.shape[1] else g[:, c0:c1].contiguous()
+                if pg.n_halo > 0:
+                    ghalo, _ = eng._spmm_fwd("sum", pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, gc, pg.n_halo)
+                else:
+                    ghalo = torch.empty((0, c1 - c0), dtype=g.dtype, device=g.device)
+                gsend, work = pg._a2a(pg.n_send, ghalo, pg.send_splits, pg.recv_splits)  # chunk c travels while c+1 computes
+                works.append((c0, c1, gsend, work))
         gh, _ = eng._spmm_fwd("sum", pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, pg.n_local)  # overlaps
-        if work is not None:
+        for (c0, c1, gsend, work) in works:
             work.wait()
             if pg.n_send > 0:
                 back, _ = eng._segment_fwd("sum", gsend, pg.send_plan)  # deterministic scatter-add
-                gh.add_(back)
+                if c1 - c0 == gh.shape[1]:
+                    gh.add_(back)
+                else:
+                    gh[:, c0:c1].add_(back)
         return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None
 
 

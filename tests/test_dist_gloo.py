@@ -64,6 +64,20 @@ def _worker(rank, world, port, tmp):
         full.backward(go)
         torch.testing.assert_close(out.detach(), full.detach()[pg.lo:pg.hi], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(hl.grad, hf.grad[pg.lo:pg.hi], rtol=1e-5, atol=1e-5)
+        # wide features: the exchange is pipelined in 4 (K = 256) / 2 (K = 136) column chunks
+        from gammagl_amd.dist import _HaloAggregate
+        assert len(_HaloAggregate._chunks(256)) == 4 and len(_HaloAggregate._chunks(136)) == 2
+        for K in (256, 136, 47):
+            hk = torch.randn(N, K, generator=torch.Generator().manual_seed(K))
+            gk = torch.randn(N, K, generator=torch.Generator().manual_seed(K + 1))
+            a = hk[pg.lo:pg.hi].clone().requires_grad_(True)
+            b = hk.clone().requires_grad_(True)
+            ya = pg.aggregate(a)
+            ya.backward(gk[pg.lo:pg.hi])
+            yb = eng.c_spmm_sum(ei, w, b)
+            yb.backward(gk)
+            torch.testing.assert_close(ya.detach(), yb.detach()[pg.lo:pg.hi], rtol=1e-5, atol=1e-4)
+            torch.testing.assert_close(a.grad, b.grad[pg.lo:pg.hi], rtol=1e-5, atol=1e-4)
         # one training step (dropout off) vs the world-size-1 run of the same code
         n_train = int(train.sum())
         tr = DistGCNTrainer(pg, F, Hd, C, num_layers=3, drop_rate=0.0, seed=7, device="cpu")
