@@ -25,9 +25,19 @@ from .mpops import (gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa:
 
 
 def degree(index, num_nodes, dtype=torch.float32):
-    """utils/degree.py:10-40: unsorted_segment_sum(ones[E], index, N) (K = 1)."""
-    one = torch.ones((index.shape[0],), dtype=dtype, device=index.device)
-    return unsorted_segment_sum(one, index, num_nodes)
+    """utils/degree.py:10-40: unsorted_segment_sum(ones[E], index, N) (K = 1).
+
+    The sum of ones per segment is the segment's element count, which the cached plan of ``index`` already
+    holds as rowptr differences — no kernel, no pass over E.  Float dtypes clamp at
+    the value where the reference's ``+= 1`` accumulation in that dtype stops growing (2^24 for f32)."""
+    if not index.is_cuda or index.dim() != 1 or index.dtype != torch.int64:
+        one = torch.ones((index.shape[0],), dtype=dtype, device=index.device)
+        return unsorted_segment_sum(one, index, num_nodes)
+    cnt = _engine().seg_plan(index, num_nodes).counts()
+    sat = {torch.float32: 1 << 24, torch.float16: 2048, torch.bfloat16: 256}.get(dtype)
+    if sat is not None:
+        cnt = cnt.clamp(max=sat)
+    return cnt.to(dtype)
 
 
 def calc_gcn_norm(edge_index, num_nodes, edge_weight=None):

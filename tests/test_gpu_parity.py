@@ -401,3 +401,19 @@ def test_training_step_captures_into_a_hipgraph(eng, dev):
         graphed()
     lg = float(graphed())
     assert abs(le - lg) <= 1e-4 * abs(le) + 1e-6, (le, lg)
+
+
+def test_degree_from_plan_equals_segment_sum_of_ones(eng, dev):
+    """layers.degree reads the counts off the cached plan; it must equal the op it stands for
+    (utils/degree.py:30-40: unsorted_segment_sum(ones, index, N)), incl. the reference's int64 case."""
+    from gammagl_amd import layers, mpops
+    from gammagl_amd.synth import rmat_graph
+
+    ei = rmat_graph(5000, 80000, seed=8, device=dev)
+    for ids in (ei[0], ei[1]):
+        for dt in (torch.float32, torch.int64, torch.float16):
+            ref = mpops.unsorted_segment_sum(torch.ones(ids.shape[0], dtype=dt, device=dev), ids, 5000)
+            got = layers.degree(ids, 5000, dtype=dt)
+            assert got.dtype == dt and torch.equal(got, ref), dt
+    row = torch.tensor([0, 1, 0, 2, 0], device=dev)  # tests/utils/test_degree.py:5-9
+    assert layers.degree(row, 3, dtype=torch.int64).tolist() == [3, 1, 1]
