@@ -4,8 +4,8 @@
 Same flow and flags as the reference trainer (examples/gcn/gcn_trainer.py:51-142): add self-loops once,
 GCNModel(feature_dim, hidden_dim, num_class, drop_rate, num_layers, norm), Adam(lr, weight_decay=l2_coef),
 softmax cross-entropy on the train nodes, accuracy on val/test.  Datasets cannot be downloaded here, so
-without --data it trains on a seeded Cora-sized synthetic graph whose labels are recoverable from the
-features; --data points at an .npz with x, y, edge_index, train_idx, val_idx, test_idx.
+without --data it trains on a seeded Cora-sized homophilous synthetic graph (labels recoverable from
+features + neighbourhood); --data points at an .npz with x, y, edge_index, train_idx, val_idx, test_idx.
 
     python examples/gcn_trainer_amd.py --n_epoch 50 --hidden_dim 16
 """
@@ -19,7 +19,6 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gammagl_amd.layers import GCNModel, add_self_loops  # noqa: E402
-from gammagl_amd.synth import rmat_graph  # noqa: E402
 
 
 def load(args, dev):
@@ -28,11 +27,20 @@ def load(args, dev):
         t = lambda k, dt: torch.as_tensor(d[k], dtype=dt, device=dev)  # noqa: E731
         return (t("x", torch.float32), t("y", torch.int64), t("edge_index", torch.int64), t("train_idx", torch.int64),
                 t("val_idx", torch.int64), t("test_idx", torch.int64))
-    n, f, c = 2708, 1433, 7
+    n, f, c = 2708, 1433, 7   # Cora's node / feature / class counts
     g = torch.Generator(device=dev).manual_seed(0)
-    ei = rmat_graph(n, 10556, seed=0, device=dev, self_loops=False)
     y = torch.randint(0, c, (n,), generator=g, device=dev)
-    x = torch.randn(n, f, generator=g, device=dev) + 1.5 * F.one_hot(y, f).float()
+    # homophilous graph: ~2 edges per node, 85 % of them inside the node's class (symmetrised below)
+    src = torch.arange(n, device=dev).repeat_interleave(2)
+    same = torch.rand(src.shape[0], generator=g, device=dev) < 0.85
+    order = torch.argsort(y * n + torch.arange(n, device=dev))           # nodes grouped by class
+    start = torch.searchsorted(y[order].contiguous(), torch.arange(c + 1, device=dev))
+    r = torch.rand(src.shape[0], generator=g, device=dev)
+    in_class = order[(start[y[src]] + (r * (start[y[src] + 1] - start[y[src]])).long()).clamp(max=n - 1)]
+    anywhere = torch.randint(0, n, (src.shape[0],), generator=g, device=dev)
+    dst = torch.where(same, in_class, anywhere)
+    ei = torch.cat([torch.stack([src, dst]), torch.stack([dst, src])], dim=1)
+    x = torch.randn(n, f, generator=g, device=dev) + 0.5 * F.one_hot(y, f).float()
     perm = torch.randperm(n, generator=g, device=dev)
     return x, y, ei, perm[:140], perm[140:640], perm[640:1640]
 
