@@ -89,6 +89,32 @@ template <> struct VecIO<float, 4> {
   }
 };
 
+// 16-byte accesses for the 16-bit float storage types (8 elements) and for f64 (2 elements)
+template <> struct VecIO<uint16_t, 8> {
+  static __device__ __forceinline__ void load(const uint16_t *__restrict__ p, uint16_t (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4 *>(p);
+    v[0] = (uint16_t)t.x; v[1] = (uint16_t)(t.x >> 16); v[2] = (uint16_t)t.y; v[3] = (uint16_t)(t.y >> 16);
+    v[4] = (uint16_t)t.z; v[5] = (uint16_t)(t.z >> 16); v[6] = (uint16_t)t.w; v[7] = (uint16_t)(t.w >> 16);
+  }
+  static __device__ __forceinline__ void store(uint16_t *__restrict__ p, const uint16_t (&v)[8]) {
+    uint4 t;
+    t.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); t.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+    t.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16); t.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
+    *reinterpret_cast<uint4 *>(p) = t;
+  }
+};
+template <> struct VecIO<double, 2> {
+  static __device__ __forceinline__ void load(const double *__restrict__ p, double (&v)[2]) {
+    const double2 t = *reinterpret_cast<const double2 *>(p);
+    v[0] = t.x; v[1] = t.y;
+  }
+  static __device__ __forceinline__ void store(double *__restrict__ p, const double (&v)[2]) {
+    double2 t;
+    t.x = v[0]; t.y = v[1];
+    *reinterpret_cast<double2 *>(p) = t;
+  }
+};
+
 // ---- reduce sorted positions [beg, end) of `row` for the VEC features starting at kk -------------
 template <typename T, int VEC, int OP, int MODE, int IDX, int U>
 __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, const ReduceDims &d,
@@ -437,13 +463,25 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
   return launch_typed<float, 1, OP, MODE, kStatic>(a, stream);
 }
 
+// 16-byte vector path usable: K a multiple of the vector width and every base pointer 16-byte aligned
+static bool wide_ok(const ReduceArgs &a, int vec) {
+  return !options().force_generic && a.K % vec == 0 && aligned16(a.x) && aligned16(a.out) &&
+         (!a.partial || aligned16(a.partial));
+}
+
 template <int OP>
 static int launch_seg(int dtype, const ReduceArgs &a, hipStream_t stream) {
   switch (dtype) {
     case GGL_F32: return launch_f32<OP, MODE_SEG>(a, stream);
-    case GGL_F64: return launch_typed<double, 1, OP, MODE_SEG, false>(a, stream);
-    case GGL_F16: return launch_typed<f16_t, 1, OP, MODE_SEG, false>(a, stream);
-    case GGL_BF16: return launch_typed<bf16_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_F64:
+      if (wide_ok(a, 2)) return launch_typed<double, 2, OP, MODE_SEG, false>(a, stream);
+      return launch_typed<double, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_F16:
+      if (wide_ok(a, 8)) return launch_typed<f16_t, 8, OP, MODE_SEG, false>(a, stream);
+      return launch_typed<f16_t, 1, OP, MODE_SEG, false>(a, stream);
+    case GGL_BF16:
+      if (wide_ok(a, 8)) return launch_typed<bf16_t, 8, OP, MODE_SEG, false>(a, stream);
+      return launch_typed<bf16_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_U8: return launch_typed<uint8_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_I8: return launch_typed<int8_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_I16: return launch_typed<int16_t, 1, OP, MODE_SEG, false>(a, stream);

@@ -50,6 +50,8 @@ template <typename T> static inline T __builtin_amdgcn_readfirstlane(T v) { retu
 
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
+struct double2 { double x, y; };
+struct uint4 { uint32_t x, y, z, w; };
 
 namespace ggl_emul {
 template <typename F> static inline void launch(int64_t grid, int64_t block, F &&body) {
