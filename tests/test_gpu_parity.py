@@ -112,6 +112,40 @@ def test_mpops_surface_matches_reference_names(eng, dev):
         mpops.gspmm(index, None, torch.ones(5, 8, device=dev), "prod")
 
 
+def test_torch_ops_dispatch_to_hip(eng, dev, oracle):
+    """torch.ops.gammagl_amd.* (torch_ops.py): HIP kernels for CUDA tensors, autograd through the
+    dispatcher, schema / fake-tensor / autograd-registration checks, no CPU kernel."""
+    from gammagl_amd import torch_ops
+
+    ops = torch_ops.ops
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, 300, (2, 5000), generator=g)
+    x = torch.randn(5000, 20, generator=g)
+    w = torch.rand(5000, generator=g)
+    xn = torch.randn(300, 32, generator=g)
+    eid, xd, wd, xnd = ei.to(dev), x.to(dev), w.to(dev), xn.to(dev).requires_grad_()
+    np.testing.assert_array_equal(ops.segment_sum(xd, eid[1], 300).cpu().numpy(),
+                                  oracle.segment_sum(x.numpy(), ei[1].numpy(), 300))
+    out, arg = ops.segment_max(xd, eid[1], 300)
+    ro, ra = oracle.segment_max(x.numpy(), ei[1].numpy(), 300)
+    np.testing.assert_array_equal(out.cpu().numpy(), ro)
+    np.testing.assert_array_equal(arg.cpu().numpy(), ra)
+    y = ops.spmm_sum(eid, wd, xnd)
+    gy = torch.randn(300, 32, generator=g)
+    y.backward(gy.to(dev))
+    ref = oracle.spmm_sum_fwd(ei.numpy(), w.numpy(), xn.numpy())
+    refg = oracle.spmm_sum_bwd(ei.numpy(), w.numpy(), gy.numpy())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(xnd.grad.cpu().numpy(), refg, rtol=1e-5, atol=1e-5)
+    assert torch.equal(y.detach(), eng.c_spmm_sum(eid, wd, xnd.detach()))  # same kernel either way
+    with pytest.raises(NotImplementedError, match="CPU"):
+        ops.segment_sum(x, ei[1], 300)
+    utils = ("test_schema", "test_faketensor", "test_autograd_registration")
+    torch.library.opcheck(ops.segment_sum.default, (xd.clone().requires_grad_(), eid[1], 300), test_utils=utils)
+    torch.library.opcheck(ops.spmm_sum.default, (eid, wd, xnd.detach().requires_grad_()), test_utils=utils)
+    torch.library.opcheck(ops.segment_max.default, (xd, eid[1], 300), test_utils=utils[:2])
+
+
 def test_layers_fused_equals_unfused(eng, dev):
     """GCNConv via gspmm == MessagePassing's gather/scale/segment_sum route; FusedGATConv == GATConv."""
     from gammagl_amd import layers
