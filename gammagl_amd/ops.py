@@ -32,7 +32,9 @@ _DTYPE_CODE = {
 }
 _FLOAT_DTYPES = (torch.float16, torch.bfloat16, torch.float32, torch.float64)
 
-DEFAULT_CHUNK = int(os.environ.get("GGL_LONG_ROW", "4096"))
+DEFAULT_CHUNK = int(os.environ.get("GGL_LONG_ROW", "0"))  # 0 = automatic, see Engine.auto_chunk
+MAX_CHUNK, MIN_CHUNK = 4096, 256
+RESIDENT_WAVES = 256 * 32  # MI355X: 256 CUs x 32 wavefronts in flight
 
 
 def _ptr(t):
@@ -45,13 +47,16 @@ class SegPlan:
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
                  "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid")
 
-    def c_struct(self, partial=None, perm_override=None):
+    def c_struct(self, partial=None, perm_override=None, unsplit=False):
+        """`unsplit`: present the plan without its long-row table, every row walked in one piece."""
         perm = self.perm if perm_override is None else perm_override
+        n_long = 0 if unsplit else self.n_long
         return SegPlanC(
             rowptr=self.rowptr.data_ptr(), perm=(perm.data_ptr() if perm is not None else None),
-            long_rows=(self.long_rows.data_ptr() if self.n_long else None),
-            chunk_ptr=(self.chunk_ptr.data_ptr() if self.n_long else None),
-            n_long=self.n_long, n_chunks=self.n_chunks, chunk=self.chunk,
+            long_rows=(self.long_rows.data_ptr() if n_long else None),
+            chunk_ptr=(self.chunk_ptr.data_ptr() if n_long else None),
+            n_long=n_long, n_chunks=(self.n_chunks if n_long else 0),
+            chunk=((1 << 62) if unsplit else self.chunk),
             partial=(partial.data_ptr() if partial is not None else None), N=self.N, E=self.E,
             row_order=(self.row_order.data_ptr() if self.row_order is not None else None))
 
@@ -153,7 +158,7 @@ class Engine:
         self.w_cache = _PlanCache(cap=8)
         self._rng = {}
         self.stats = {"plans_built": 0, "plan_hits": 0}
-        self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk
+        self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk; 0 = auto_chunk(E)
         self._make_functions()
 
     # ---- plumbing ----------------------------------------------------------------------------
@@ -202,6 +207,19 @@ class Engine:
         if int(lo) < 0 or int(hi) >= n:
             raise IndexError(f"node id out of range [0, {n})")
 
+    @staticmethod
+    def auto_chunk(E):
+        """Long-row threshold for a plan of E elements.  One wavefront walks a row (or a chunk of a long
+        row) serially, so the longest unsplit walk is the critical path of a launch: 4096 elements is
+        best when the launch is many waves deep (products-sized: E / 4096 >> resident waves) but on an
+        arxiv-sized graph it leaves the chip waiting for a few hubs (measured K=256 SpMM-sum 0.685 ms at
+        4096 vs 0.284 ms at 256, profiles/r1_arxiv_chunk_sweep.txt).  Rule: the largest power of two
+        <= E / RESIDENT_WAVES, clamped to [256, 4096]."""
+        c = MAX_CHUNK
+        while c > MIN_CHUNK and c * RESIDENT_WAVES > E:
+            c >>= 1
+        return c
+
     def build_plan(self, ids, N, chunk=None):
         """Sort `ids` (int64 [E]) into a SegPlan.  Synchronous; run once per edge list."""
         dev = self._dev(ids)
@@ -209,7 +227,7 @@ class Engine:
         if ids.dtype != torch.int64:
             ids = ids.to(torch.int64)
         E, N = int(ids.shape[0]), int(N)
-        chunk = int(chunk or self.chunk)
+        chunk = int(chunk or self.chunk or self.auto_chunk(E))
         st = self._stream(dev)
         p = SegPlan()
         p.N, p.E, p.chunk, p.device = N, E, chunk, dev
@@ -249,7 +267,7 @@ class Engine:
         list): no sort, and no host sync when the caller knows ``max_len`` (e.g. the fan-out)."""
         dev = self._dev(rowptr)
         p = SegPlan()
-        p.N, p.E, p.chunk, p.device = int(rowptr.shape[0]) - 1, int(E), self.chunk, dev
+        p.N, p.E, p.chunk, p.device = int(rowptr.shape[0]) - 1, int(E), int(self.chunk or self.auto_chunk(E)), dev
         p.rowptr = rowptr.contiguous().to(torch.int64)
         p.perm, p.is_sorted = None, True
         p.max_len = int(max_len) if max_len is not None else (int(p.counts().max()) if p.N > 0 else 0)
@@ -334,8 +352,12 @@ class Engine:
         out = torch.empty((plan.N,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
         st = self._stream(dev)
         code = self._code(x)
-        part = self._partial(plan, x.dtype, K, op == "max", dev)
-        cs = plan.c_struct(part)
+        # f16 / bf16 sums accumulate in the storage type (segment_sum_cpu.cpp:47-56): the result depends on
+        # the serial order well beyond rounding (a running f16 sum of ones sticks at 2048), so combining
+        # chunk partials would not reproduce the reference: those rows are always walked in one piece
+        unsplit = op != "max" and x.dtype in (torch.float16, torch.bfloat16)
+        part = None if unsplit else self._partial(plan, x.dtype, K, op == "max", dev)
+        cs = plan.c_struct(part, unsplit=unsplit)
         if op == "sum":
             self._check(self.lib.ggl_segment_sum(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
             return out, None
