@@ -27,6 +27,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import engine as _default_engine
+from .dense import wgrad
 
 HALO_CHUNKS = int(os.environ.get("GGL_HALO_CHUNKS", "0"))  # 0 = automatic (4 at K >= 256, 2 at K >= 128)
 
@@ -200,13 +201,14 @@ class _LinearSideWgrad(torch.autograd.Function):
         gx = g @ w if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
+            g = g.contiguous()
             if side is None or not g.is_cuda:
-                gw = g.t() @ x
+                gw = wgrad(g, x)
             else:
                 cur = torch.cuda.current_stream(g.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    gws = g.t() @ x
+                    gws = wgrad(g, x)
                 g.record_stream(side)
                 x.record_stream(side)
                 gws.record_stream(cur)  # consumed on the main stream after join()

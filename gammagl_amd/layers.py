@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from . import engine as _engine
+from .dense import Linear
 from .mpops import (gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
                     unsorted_segment_sum, use_ext)
 
@@ -110,7 +111,7 @@ class GCNConv(MessagePassing):
             raise ValueError('Invalid norm value. Must be either "none", "both", "right" or "left".'
                              ' But got "{}".'.format(norm))
         self._norm = norm
-        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+        self.linear = Linear(in_channels, out_channels, bias=False)
         nn.init.xavier_uniform_(self.linear.weight)
         self.bias = nn.Parameter(torch.zeros(1, out_channels)) if add_bias else None
 
@@ -146,11 +147,11 @@ class SAGEConv(MessagePassing):
         super().__init__()
         self.aggr = aggr
         self.act = activation
-        self.fc_neigh = nn.Linear(in_channels, out_channels, bias=False)
+        self.fc_neigh = Linear(in_channels, out_channels, bias=False)
         if aggr != 'gcn':
-            self.fc_self = nn.Linear(in_channels, out_channels, bias=False)
+            self.fc_self = Linear(in_channels, out_channels, bias=False)
         if aggr == 'pool':
-            self.pool = nn.Linear(in_channels, in_channels, bias=False)
+            self.pool = Linear(in_channels, in_channels, bias=False)
         self.bias = nn.Parameter(torch.zeros(1, out_channels)) if add_bias else None
 
     def forward(self, feat, edge):
