@@ -34,6 +34,25 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint64_t offset, uin
   return U4{c0, c1, c2, c3};
 }
 
+template <int VEC> __device__ __forceinline__ void ldv(const float *__restrict__ p, float (&t)[VEC]) {
+  if (VEC == 4) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    t[0] = v.x; t[1 % VEC] = v.y; t[2 % VEC] = v.z; t[3 % VEC] = v.w;
+  } else {
+    t[0] = p[0];
+  }
+}
+template <int VEC> __device__ __forceinline__ void stv(float *__restrict__ p, const float (&t)[VEC]) {
+  if (VEC == 4) {
+    float4 o;
+    o.x = t[0]; o.y = t[1 % VEC]; o.z = t[2 % VEC]; o.w = t[3 % VEC];
+    *reinterpret_cast<float4 *>(p) = o;
+  } else {
+    p[0] = t[0];
+  }
+}
+constexpr int kRowUnroll = 4;  // rows in flight per lane: the loads of 4 rows are issued before any is used
+
 // Threads of a block are `groups` groups of `kp` lanes; a lane owns VEC consecutive columns (loaded once
 // from bias), a group walks rows r0 + j, + groups, ...  Random word for vector (r, c): Philox(r * KV + c).
 template <int VEC>
@@ -54,14 +73,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(const float *__res
     float b[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) b[i] = bias ? bias[c * VEC + i] : 0.0f;
-    for (int64_t r = r0 + j; r < r1; r += groups) {
-      float t[VEC];
-      if (VEC == 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(a + r * K + c * 4);
-        t[0] = v.x; t[1 % VEC] = v.y; t[2 % VEC] = v.z; t[3 % VEC] = v.w;
-      } else {
-        t[0] = a[r * K + c];
-      }
+    auto finish = [&](int64_t r, float (&t)[VEC]) {
       uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
       if (drop_thresh) {
         const U4 u = philox4x32_10((uint64_t)(r * KV + c), offset, seed);
@@ -74,13 +86,20 @@ __global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(const float *__res
         if (drop_thresh) v = (rw[i] >= drop_thresh) ? __fmul_rn(v, scale) : 0.0f;  // keep with prob 1 - p
         t[i] = v;
       }
-      if (VEC == 4) {
-        float4 o;
-        o.x = t[0]; o.y = t[1 % VEC]; o.z = t[2 % VEC]; o.w = t[3 % VEC];
-        *reinterpret_cast<float4 *>(y + r * K + c * 4) = o;
-      } else {
-        y[r * K + c] = t[0];
-      }
+      stv<VEC>(y + r * K + c * VEC, t);
+    };
+    int64_t r = r0 + j;
+    for (; r + (int64_t)(kRowUnroll - 1) * groups < r1; r += (int64_t)kRowUnroll * groups) {
+      float t[kRowUnroll][VEC];
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) ldv<VEC>(a + (r + (int64_t)u * groups) * K + c * VEC, t[u]);
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) finish(r + (int64_t)u * groups, t[u]);
+    }
+    for (; r < r1; r += groups) {
+      float t[VEC];
+      ldv<VEC>(a + r * K + c * VEC, t);
+      finish(r, t);
     }
   }
 }
@@ -109,31 +128,32 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-    for (int64_t r = r0 + j; r < r1; r += groups) {
-      float gv[VEC], yv[VEC];
-      if (VEC == 4) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(g + r * K + c * 4);
-        gv[0] = a4.x; gv[1 % VEC] = a4.y; gv[2 % VEC] = a4.z; gv[3 % VEC] = a4.w;
-        if (masked) {
-          const float4 b4 = *reinterpret_cast<const float4 *>(y + r * K + c * 4);
-          yv[0] = b4.x; yv[1 % VEC] = b4.y; yv[2 % VEC] = b4.z; yv[3 % VEC] = b4.w;
-        }
-      } else {
-        gv[0] = g[r * K + c];
-        if (masked) yv[0] = y[r * K + c];
-      }
+    auto finish = [&](int64_t r, float (&gv)[VEC], const float (&yv)[VEC]) {
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         if (masked) gv[i] = (yv[i] > 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
-        acc[i] = __fadd_rn(acc[i], gv[i]);
+        acc[i] = __fadd_rn(acc[i], gv[i]);  // rows in ascending order, unrolled or not
       }
-      if (VEC == 4) {
-        float4 o;
-        o.x = gv[0]; o.y = gv[1 % VEC]; o.z = gv[2 % VEC]; o.w = gv[3 % VEC];
-        *reinterpret_cast<float4 *>(ga + r * K + c * 4) = o;
-      } else {
-        ga[r * K + c] = gv[0];
+      stv<VEC>(ga + r * K + c * VEC, gv);
+    };
+    int64_t r = r0 + j;
+    for (; r + (int64_t)(kRowUnroll - 1) * groups < r1; r += (int64_t)kRowUnroll * groups) {
+      float gv[kRowUnroll][VEC], yv[kRowUnroll][VEC];
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        ldv<VEC>(g + (r + (int64_t)u * groups) * K + c * VEC, gv[u]);
+        if (masked) ldv<VEC>(y + (r + (int64_t)u * groups) * K + c * VEC, yv[u]);
+        else yv[u][0] = 0.0f;
       }
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) finish(r + (int64_t)u * groups, gv[u], yv[u]);
+    }
+    for (; r < r1; r += groups) {
+      float gv[VEC], yv[VEC];
+      ldv<VEC>(g + r * K + c * VEC, gv);
+      if (masked) ldv<VEC>(y + r * K + c * VEC, yv);
+      else yv[0] = 0.0f;
+      finish(r, gv, yv);
     }
     if (partial) {
 #pragma unroll
