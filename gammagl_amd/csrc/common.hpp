@@ -56,6 +56,7 @@ void set_error(const char *fmt, ...);
 
 struct Options {
   int64_t unroll = 4;        // neighbour loads in flight per lane in the f32 fast path (4 or 8)
+  int64_t unroll_narrow = 16; // ... and where a row owns <= 4 lanes (K <= 16 floats): 4 or 16
   // 1 = give each XCD a contiguous range of row blocks (private-L2 locality).  OFF by default: measured
   // on MI355X (profiles/kbench_r1.txt) it changes nothing on a randomly ordered graph and is 4x SLOWER
   // on a degree-ordered one (one XCD inherits all the hub rows); round-robin is the load balancer.

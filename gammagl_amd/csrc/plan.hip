@@ -39,6 +39,7 @@ Options &options() {
   static Options o = [] {
     Options t;
     t.unroll = env_i64("GGL_UNROLL", t.unroll);
+    t.unroll_narrow = env_i64("GGL_UNROLL_NARROW", t.unroll_narrow);
     t.xcd_swizzle = env_i64("GGL_XCD_SWIZZLE", t.xcd_swizzle);
     t.force_generic = env_i64("GGL_FORCE_GENERIC", t.force_generic);
     t.row_order = env_i64("GGL_ROW_ORDER", t.row_order);
@@ -218,6 +219,7 @@ extern "C" int ggl_device_info(int *cus_host, int *wave_host, char *arch_host, i
 extern "C" int ggl_set_option(const char *name, int64_t value) {
   Options &o = options();
   if (!strcmp(name, "unroll")) o.unroll = value;
+  else if (!strcmp(name, "unroll_narrow")) o.unroll_narrow = value;
   else if (!strcmp(name, "xcd_swizzle")) o.xcd_swizzle = value;
   else if (!strcmp(name, "force_generic")) o.force_generic = value;
   else if (!strcmp(name, "row_order")) o.row_order = value;
@@ -228,6 +230,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
 extern "C" int64_t ggl_get_option(const char *name) {
   Options &o = options();
   if (!strcmp(name, "unroll")) return o.unroll;
+  if (!strcmp(name, "unroll_narrow")) return o.unroll_narrow;
   if (!strcmp(name, "xcd_swizzle")) return o.xcd_swizzle;
   if (!strcmp(name, "force_generic")) return o.force_generic;
   if (!strcmp(name, "row_order")) return o.row_order;

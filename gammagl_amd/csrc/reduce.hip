@@ -411,6 +411,12 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
       GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 4>), grid,
                  kBlock, stream, GGL_RR_ARGS);
     }
+  } else if (OP != OP_MAX && d.logL <= 2 && options().unroll_narrow > 4) {
+    // narrow rows (<= 4 lanes per row, K <= 16 floats): a lane moves 16 bytes per element, so the walk is
+    // latency-bound; 16 elements in flight per lane instead of 4 (Reddit-sized segment_sum: K = 1
+    // 1.73 -> 1.23 ms, K = 8 2.56 -> 2.12 ms, profiles/r1_smallk_probe.txt).  Not for max: its int64
+    // argmax registers make the deeper unroll slower (2.79 -> 3.27 ms).
+    GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 16>), grid, kBlock, stream, GGL_RR_ARGS);
   } else {
     GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 4>), grid, kBlock, stream, GGL_RR_ARGS);
   }

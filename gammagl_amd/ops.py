@@ -627,7 +627,7 @@ class Engine:
                 bwd = gp.bwd
                 gx = torch.empty((gp.N_src, H, C), dtype=torch.float32, device=dev)
                 gel = torch.empty((gp.N_src, H), dtype=torch.float32, device=dev)
-                part = eng._partial(bwd, torch.float32, H * C, False, dev)
+                part = eng._partial(bwd, torch.float32, H * C + H, False, dev)  # gx and gel partials of long rows
                 csT = bwd.c_struct(part)
                 eng._check(eng.lib.ggl_gat_fused_bwd_src(ctypes.byref(csT), _ptr(gp.colT), _ptr(gp.posT),
                                                          _ptr(alpha), _ptr(de), _ptr(g), H, C,

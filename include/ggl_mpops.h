@@ -245,8 +245,9 @@ int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int r
  *   ggl_gat_fused_bwd_dst: dot[i,h] = <g_i, out_i>; per (sorted position, head): alpha, de =
  *       alpha (<g_i, x_j> - dot) lrelu'(.) -> alpha[E,H], de[E,H] (forward sorted positions);
  *       ger[N,H] = row sums of de (ggl_segment_sum on the forward plan)
- *   ggl_gat_fused_bwd_src: on the transposed plan, gx[j,h,:] = sum_p alpha * g[dst,h,:] and
- *       gel[j,h] = sum_p de, reading alpha/de through posT (transposed position -> forward position)
+ *   ggl_gat_fused_bwd_src: ONE walk of the transposed plan: gx[j,h,:] = sum_p alpha * g[dst,h,:] and
+ *       gel[j,h] = sum_p de, reading alpha/de through posT (transposed position -> forward position);
+ *       planT->partial = ggl_partial_bytes(GGL_F32, n_chunks, H*C + H, 0) bytes when it has long rows
  * ---------------------------------------------------------------------------------------------- */
 int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
                       const float *er, const float *x, float slope, int64_t H, int64_t C,
