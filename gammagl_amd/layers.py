@@ -247,5 +247,29 @@ class GCNModel(nn.Module):
         return self.conv[-1](x, edge_index, edge_weight, num_nodes)
 
 
-__all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "degree",
+class GraphSAGESampleModel(nn.Module):
+    """models/graphsage.py:35-83 (GraphSAGE_Sample_Model): SAGEConv(mean) per sampled hop; the target
+    nodes of a block are the first size[1] rows of its input ("target nodes are always placed first")."""
+
+    def __init__(self, in_feat, hid_feat, out_feat, drop_rate=0.0, num_layers=2):
+        super().__init__()
+        self.dropout = nn.Dropout(drop_rate)
+        if num_layers == 1:
+            self.convs = nn.ModuleList([SAGEConv(in_feat, out_feat)])
+        else:
+            convs = [SAGEConv(in_feat, hid_feat, torch.relu)]
+            convs += [SAGEConv(hid_feat, hid_feat, torch.relu) for _ in range(num_layers - 2)]
+            convs += [SAGEConv(hid_feat, out_feat)]
+            self.convs = nn.ModuleList(convs)
+
+    def forward(self, x, adjs):
+        adjs = adjs if isinstance(adjs, (list, tuple)) else [adjs]
+        for i, (conv, adj) in enumerate(zip(self.convs, adjs)):
+            x = conv((x, x[: adj.size[1]]), adj.edge_index)
+            if i != len(self.convs) - 1:
+                x = self.dropout(x)
+        return x
+
+
+__all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "GraphSAGESampleModel", "degree",
            "calc_gcn_norm", "segment_softmax", "add_self_loops"]

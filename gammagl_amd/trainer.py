@@ -4,7 +4,7 @@ Adam with weight decay) — in plain torch around the gammagl_amd layers."""
 import torch
 import torch.nn.functional as F
 
-from .layers import GCNModel
+from .layers import GCNModel, GraphSAGESampleModel
 
 
 class GCNTrainer:
@@ -54,3 +54,44 @@ class GraphedStep:
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+class SAGETrainer:
+    """Neighbour-sampled GraphSAGE training (examples/graphsage/reddit_sage_trainer.py:45-105): per batch,
+    sample the blocks on the device (NeighborSampler), gather the input rows, SAGEConv(mean) per hop,
+    softmax cross-entropy on the seed nodes, Adam.
+
+    Multi-GPU (BASELINE config 4): the aggregate does not shard — every rank is a replica
+    that samples its OWN seeds from the replicated graph; the only exchange is one flat all-reduce of the
+    weight gradients per step (`group` = a torch.distributed process group; RCCL on the GPUs)."""
+
+    def __init__(self, sampler, in_feat, hid_feat, num_class, num_layers=2, drop_rate=0.0, lr=0.005, seed=0,
+                 device="cuda", group=None, world=1):
+        self.sampler, self.group, self.world = sampler, group, int(world)
+        torch.manual_seed(seed)  # identical initial weights on every replica
+        self.net = GraphSAGESampleModel(in_feat, hid_feat, num_class, drop_rate, num_layers).to(device)
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr)
+
+    def step(self, x, y, seeds):
+        """One optimizer step on this rank's `seeds`; the gradient is the mean over ALL ranks' seeds when
+        every rank passes the same number of seeds."""
+        import torch.distributed as dist
+
+        self.net.train()
+        self.opt.zero_grad(set_to_none=True)
+        dst, n_id, adjs = self.sampler.sample(seeds)
+        logits = self.net(x[n_id], adjs)
+        loss = F.cross_entropy(logits, y[dst])
+        loss.backward()
+        if self.world > 1:
+            params = [p for p in self.net.parameters() if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat, group=self.group)
+            flat.div_(self.world)
+            o = 0
+            for p in params:
+                n = p.grad.numel()
+                p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                o += n
+        self.opt.step()
+        return loss.detach()

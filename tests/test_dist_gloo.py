@@ -158,8 +158,65 @@ def test_bench_body_runs_distributed(tmp_path):
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
 
 
+def _sage_worker(rank, world, port, tmp):
+    """BASELINE config 4's multi-GPU mode: replicas that sample their own seeds + one gradient all-reduce."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gammagl_amd
+        from gammagl_amd import torch_ops
+
+        eng = _emul_engine()
+        gammagl_amd._engine = eng                      # test-only: the layers' mpops calls land on the
+        torch_ops.register_backend(lambda: eng, "CPU")  # host-emulated kernels in this subprocess
+        from gammagl_amd.sampler import NeighborSampler
+        from gammagl_amd.trainer import SAGETrainer
+
+        N, F, Hd, C, ei, x, y, _ = _problem(2)
+        ns = NeighborSampler(ei, [-1, -1], num_nodes=N, eng=eng)   # full neighbourhoods: deterministic blocks
+        seeds_all = torch.randperm(N, generator=torch.Generator().manual_seed(11))[: 16 * world]
+        mine = seeds_all[rank * 16:(rank + 1) * 16]
+        tr = SAGETrainer(ns, F, Hd, C, num_layers=2, seed=5, device="cpu", group=None, world=world)
+        l0 = tr.step(x, y, mine)
+        # the same step in one process on the union of the seeds: mean of equal-sized means == mean
+        ref = SAGETrainer(ns, F, Hd, C, num_layers=2, seed=5, device="cpu", world=1)
+        l_ref = ref.step(x, y, seeds_all)
+        lsum = l0.clone().reshape(1)
+        dist.all_reduce(lsum)
+        torch.testing.assert_close(lsum[0] / world, l_ref, rtol=1e-5, atol=1e-6)
+        for p, q in zip(tr.net.parameters(), ref.net.parameters()):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-4, atol=1e-6)
+        # sampled fan-outs: every replica draws its own blocks, the weights stay identical everywhere
+        ns2 = NeighborSampler(ei, [5, 3], num_nodes=N, eng=eng)
+        eng.reseed(100 + rank)
+        tr2 = SAGETrainer(ns2, F, Hd, C, num_layers=2, seed=6, device="cpu", world=world)
+        for it in range(3):
+            sd = torch.randperm(N, generator=torch.Generator().manual_seed(20 + 7 * rank + it))[:24]
+            assert torch.isfinite(tr2.step(x, y, sd))
+        flat = torch.cat([p.detach().reshape(-1) for p in tr2.net.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        for other in gathered:
+            assert torch.equal(other, flat)
+        open(os.path.join(tmp, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sage_minibatch_replicas_with_gradient_allreduce(tmp_path):
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, __file__, str(r), "2", str(port), str(tmp_path), "sage"])
+             for r in range(2)]
+    assert [p.wait(timeout=300) for p in procs] == [0, 0]
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+
+
 if __name__ == "__main__":
     sys.path.insert(0, REPO)
     sys.path.insert(0, HERE)
-    fn = _bench_worker if len(sys.argv) > 5 and sys.argv[5] == "bench" else _worker
+    mode = sys.argv[5] if len(sys.argv) > 5 else ""
+    fn = {"bench": _bench_worker, "sage": _sage_worker}.get(mode, _worker)
     fn(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
