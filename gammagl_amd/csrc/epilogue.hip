@@ -14,26 +14,6 @@
 
 namespace ggl {
 
-struct U4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint64_t offset, uint64_t seed) {
-  uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return U4{c0, c1, c2, c3};
-}
-
 template <int VEC> __device__ __forceinline__ void ldv(const float *__restrict__ p, float (&t)[VEC]) {
   if (VEC == 4) {
     const float4 v = *reinterpret_cast<const float4 *>(p);
@@ -175,6 +155,12 @@ static inline void geometry(int64_t N, int64_t K, bool vec4, int *kp, int *group
   *rpb = ceil_div(N > 0 ? N : 1, b);
 }
 
+int rng_advance(int64_t *rng_state, void *stream) {
+  GGL_LAUNCH((rng_advance_kernel), 1, 64, as_stream(stream), rng_state, (int64_t)1);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
 }  // namespace ggl
 
 using namespace ggl;
@@ -202,10 +188,7 @@ extern "C" int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, in
     GGL_LAUNCH((bias_act_fwd_kernel<1>), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, N, K, rpb,
                kp, groups, relu, thresh, scale);
   GGL_LAUNCH_CHECK();
-  if (thresh) {
-    GGL_LAUNCH((rng_advance_kernel), 1, 64, s, rng_state, (int64_t)1);
-    GGL_LAUNCH_CHECK();
-  }
+  if (thresh) return rng_advance(rng_state, stream);
   return GGL_OK;
 }
 

@@ -30,8 +30,11 @@ enum Mode {
   MODE_SPMM = 1,       // value = w * x[col[p],:]
   MODE_BSPMM = 2,      // value = w[.,h] * x[col[p],h,:],    h = k / C
   MODE_MEANBWD = 3,    // value = g[col[p],:] / count[col[p]] * w       (spmm_mean_cpu.cpp:95-101)
-  MODE_MAXBWD = 4      // value = w * g[col[p],k] if argsrc[col[p],k] == row (spmm_max_cpu.cpp:88-93)
+  MODE_MAXBWD = 4,     // value = w * g[col[p],k] if argsrc[col[p],k] == row (spmm_max_cpu.cpp:88-93)
+  MODE_SPMM_EPI = 5    // MODE_SPMM + the layer epilogue applied to the finished row before its only store:
+                       // y = dropout(relu(sum + bias))  (gcn_conv.py:105-106, models/gcn.py:55-59)
 };
+constexpr bool spmm_like(int mode) { return mode == MODE_SPMM || mode == MODE_SPMM_EPI; }
 
 // How positions map to element / weight indices, fixed at compile time for the hot f32 kernels so
 // the inner loop carries no pointer tests:
@@ -54,6 +57,12 @@ struct ReduceDims {
   int logL;
   int swizzle;
   int w_by_pos;
+  // MODE_SPMM_EPI: same mask as ggl_bias_act_fwd draws for the same (rng state, N, K) — Philox word of
+  // vector (row, k / epi_vec), component k % epi_vec
+  int epi_relu;
+  int epi_vec;
+  uint32_t epi_thresh;
+  float epi_scale;
 };
 
 template <typename S> struct RPtrs {
@@ -64,6 +73,8 @@ template <typename S> struct RPtrs {
   const int64_t *__restrict__ rowptr;
   const int64_t *__restrict__ aux_rowptr;
   const int64_t *__restrict__ aux_arg;
+  const float *__restrict__ epi_bias;
+  const int64_t *__restrict__ epi_rng;
 };
 
 // ---- VEC-wide loads / stores of storage elements ------------------------------------------------
@@ -151,7 +162,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       A v = TT<T>::load(raw[i]);
-      if (MODE == MODE_SPMM || MODE == MODE_BSPMM) {
+      if (spmm_like(MODE) || MODE == MODE_BSPMM) {
         if (has_w) v = (A)__fmul_rn(wv, (float)v);
       } else if (MODE == MODE_MEANBWD) {
         const int64_t cnt = q.aux_rowptr[xrow + 1] - q.aux_rowptr[xrow];
@@ -206,11 +217,29 @@ __device__ __forceinline__ void init_acc(typename TT<T>::A (&acc)[VEC], int64_t 
 
 // mean / store epilogue of a finished row
 template <typename T, int VEC, int OP, int MODE>
-__device__ __forceinline__ void finish_row(typename TT<T>::S *__restrict__ out,
+__device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, const ReduceDims &d,
+                                           typename TT<T>::S *__restrict__ out,
                                            int64_t *__restrict__ argout, int64_t K, int64_t row,
                                            int64_t len, int64_t kk, typename TT<T>::A (&acc)[VEC],
                                            const int64_t (&arg)[VEC]) {
   using S = typename TT<T>::S;
+  if (MODE == MODE_SPMM_EPI) {
+    uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    const int64_t ev = d.epi_vec;
+    if (d.epi_thresh) {
+      const int64_t KV = (K + ev - 1) / ev;
+      const U4 u = philox4x32_10((uint64_t)(row * KV + kk / ev), (uint64_t)q.epi_rng[1], (uint64_t)q.epi_rng[0]);
+      rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float v = (float)acc[i];
+      if (q.epi_bias) v = __fadd_rn(v, q.epi_bias[kk + i]);
+      if (d.epi_relu) v = (v < 0.0f) ? 0.0f : v;
+      if (d.epi_thresh) v = (rw[(kk + i) % ev] >= d.epi_thresh) ? __fmul_rn(v, d.epi_scale) : 0.0f;
+      acc[i] = (typename TT<T>::A)v;
+    }
+  }
   if (OP == OP_MEAN) {
     if (MODE == MODE_SEG) {
       // segment_mean_cpu.cpp:67-76: count lives in x's dtype; divide only where count > 1
@@ -240,8 +269,9 @@ __device__ __forceinline__ void finish_row(typename TT<T>::S *__restrict__ out,
 #define GGL_RPTR_PARAMS(S)                                                                         \
   const S *__restrict__ x, const int32_t *__restrict__ perm, const int32_t *__restrict__ col,      \
       const float *__restrict__ w, const int64_t *__restrict__ rowptr,                             \
-      const int64_t *__restrict__ aux_rowptr, const int64_t *__restrict__ aux_arg
-#define GGL_RPTR_PACK(S) RPtrs<S> q{x, perm, col, w, rowptr, aux_rowptr, aux_arg}
+      const int64_t *__restrict__ aux_rowptr, const int64_t *__restrict__ aux_arg,                 \
+      const float *__restrict__ epi_bias, const int64_t *__restrict__ epi_rng
+#define GGL_RPTR_PACK(S) RPtrs<S> q{x, perm, col, w, rowptr, aux_rowptr, aux_arg, epi_bias, epi_rng}
 
 // ---- the one launch: chunks of long rows first, then every row with len <= chunk -----------------
 // Blocks [0, chunk_blocks) each reduce 4 chunks of long rows (one wavefront per chunk) into the
@@ -319,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
     int64_t arg[VEC];
     init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
     reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
-    finish_row<T, VEC, OP, MODE>(out, argout, d.K, row, len, kk, acc, arg);
+    finish_row<T, VEC, OP, MODE>(q, d, out, argout, d.K, row, len, kk, acc, arg);
   }
 }
 
@@ -331,8 +361,13 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
                                                             const int64_t *__restrict__ partial_arg,
                                                             typename TT<T>::S *__restrict__ out,
                                                             int64_t *__restrict__ argout,
+                                                            const float *__restrict__ epi_bias,
+                                                            const int64_t *__restrict__ epi_rng,
                                                             const ReduceDims d) {
   using A = typename TT<T>::A;
+  RPtrs<typename TT<T>::S> q{};
+  q.epi_bias = epi_bias;
+  q.epi_rng = epi_rng;
   const int64_t j = blockIdx.x;  // one block per long row
   const int64_t row = long_rows[j];
   const int64_t c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
@@ -352,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
         acc[0] = TT<T>::add(acc[0], v);
       }
     }
-    finish_row<T, 1, OP, MODE>(out, argout, d.K, row, len, k, acc, arg);
+    finish_row<T, 1, OP, MODE>(q, d, out, argout, d.K, row, len, k, acc, arg);
   }
 }
 
@@ -378,6 +413,11 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   int64_t n_long, n_chunks;
   void *partial;
   int64_t *partial_arg;
+  const float *epi_bias;   // MODE_SPMM_EPI
+  const int64_t *epi_rng;
+  int epi_relu;
+  uint32_t epi_thresh;
+  float epi_scale;
 };
 
 static inline int pow2_ceil_log2(int64_t v) {
@@ -387,7 +427,7 @@ static inline int pow2_ceil_log2(int64_t v) {
 }
 
 #define GGL_RPTR_ARGS(S)                                                                           \
-  static_cast<const S *>(a.x), a.perm, a.col, a.w, a.rowptr, a.aux_rowptr, a.aux_arg
+  static_cast<const S *>(a.x), a.perm, a.col, a.w, a.rowptr, a.aux_rowptr, a.aux_arg, a.epi_bias, a.epi_rng
 
 template <typename T, int VEC, int OP, int MODE, int IDX>
 static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
@@ -403,7 +443,7 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
 #define GGL_RR_ARGS GGL_RPTR_ARGS(S), order, a.long_rows, a.chunk_ptr, static_cast<S *>(a.partial), a.partial_arg, out, a.arg, d
   if (uniform) {
     // the f32 wave-per-row kernels; U = 8 only for the dominant SpMM-sum (A/B knob)
-    if (std::is_same<T, float>::value && VEC == 4 && OP == OP_SUM && MODE == MODE_SPMM &&
+    if (std::is_same<T, float>::value && VEC == 4 && OP == OP_SUM && spmm_like(MODE) &&
         options().unroll >= 8) {
       GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 8>), grid,
                  kBlock, stream, GGL_RR_ARGS);
@@ -425,7 +465,7 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
   if (a.n_long > 0) {
     GGL_LAUNCH((long_final_kernel<T, OP, MODE>), a.n_long, kBlock, stream, a.rowptr, a.long_rows,
                a.chunk_ptr, static_cast<const S *>(a.partial), (const int64_t *)a.partial_arg, out,
-               a.arg, d);
+               a.arg, a.epi_bias, a.epi_rng, d);
     GGL_LAUNCH_CHECK();
   }
   return GGL_OK;
@@ -437,6 +477,8 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   ReduceDims d{};
   d.N = a.N; d.K = a.K; d.E = a.E; d.arg_fill = a.arg_fill; d.chunk = a.chunk; d.H = a.H; d.C = a.C;
   d.n_long = a.n_long; d.n_chunks = a.n_chunks; d.w_by_pos = a.w_by_pos;
+  d.epi_relu = a.epi_relu; d.epi_thresh = a.epi_thresh; d.epi_scale = a.epi_scale;
+  d.epi_vec = (a.K % 4 == 0) ? 4 : 1;
   const int64_t kv = ceil_div(a.K, VEC);
   d.logL = pow2_ceil_log2(kv < kWave ? kv : kWave);
   if (d.logL > 6) d.logL = 6;
@@ -461,7 +503,7 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <int OP, int MODE>
 static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
-  constexpr bool kStatic = (MODE == MODE_SEG || MODE == MODE_SPMM);
+  constexpr bool kStatic = (MODE == MODE_SEG || spmm_like(MODE));
   const bool vec4 = !options().force_generic && (a.K % 4 == 0) && aligned16(a.x) &&
                     aligned16(a.out) && (!a.partial || aligned16(a.partial)) &&
                     (MODE != MODE_BSPMM || a.C % 4 == 0);
@@ -604,6 +646,28 @@ extern "C" int ggl_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const
   int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
   if (rc) return rc;
   return launch_f32<OP_SUM, MODE_SPMM>(a, as_stream(stream));
+}
+
+// out = dropout(relu(A x + bias)) with the epilogue applied to each finished row in registers: what
+// ggl_spmm_sum followed by ggl_bias_act_fwd computes (same rounded operations, same dropout mask for the
+// same rng state), minus one write and one read of [N, K].
+extern "C" int ggl_spmm_sum_bias_act(const ggl_segplan_t *plan, const int32_t *col, const float *w,
+                                     int w_by_pos, const float *x, int64_t K, const float *bias, int relu,
+                                     float p_drop, int64_t *rng_state, float *out, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
+  if (rc) return rc;
+  GGL_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, GGL_EINVAL, "p_drop must be in [0, 1)");
+  GGL_REQUIRE(p_drop == 0.0f || rng_state, GGL_EINVAL, "dropout needs an rng_state");
+  a.epi_bias = bias;
+  a.epi_rng = rng_state;
+  a.epi_relu = relu ? 1 : 0;
+  a.epi_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  a.epi_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  rc = launch_f32<OP_SUM, MODE_SPMM_EPI>(a, as_stream(stream));
+  if (rc) return rc;
+  if (a.epi_thresh && plan->N > 0 && K > 0) return rng_advance(rng_state, stream);
+  return GGL_OK;
 }
 
 extern "C" int ggl_spmm_mean(const ggl_segplan_t *plan, const int32_t *col, const float *w,

@@ -251,9 +251,15 @@ class DistGCN(torch.nn.Module):
         for i in range(n):
             hidden = i < n - 1
             h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink)
-            # + bias, ReLU and dropout of the hidden layers fused into one pass each way (epilogue.hip)
-            x = pg.eng.bias_act(pg.aggregate(h), self.bias[i], relu=hidden,
-                                p_drop=self.dropout.p if hidden else 0.0, training=self.training)
+            p = self.dropout.p if hidden else 0.0
+            if not pg.comm and h.shape[1] % 4 == 0:
+                # no halo to add afterwards: + bias, ReLU and dropout ride on the SpMM's only store
+                x = pg.eng.spmm_bias_act(pg.gp_loc, pg.w_loc, h, self.bias[i], relu=hidden, p_drop=p,
+                                         training=self.training)
+            else:
+                # + bias, ReLU and dropout of the hidden layers fused into one pass each way (epilogue.hip)
+                x = pg.eng.bias_act(pg.aggregate(h), self.bias[i], relu=hidden, p_drop=p,
+                                    training=self.training)
         return x
 
 

@@ -680,6 +680,50 @@ class Engine:
                                                     _ptr(ws), wsb, eng._stream(dev)))
                 return ga, (gb.reshape(bshape) if gb is not None else None), None, None
 
+        class SpMMSumBiasAct(torch.autograd.Function):
+            """y = dropout(relu(A x + bias)) in ONE kernel: the epilogue is applied to each finished row of
+            the SpMM in registers (reduce.hip MODE_SPMM_EPI); backward = bias_act_bwd, transposed SpMM."""
+
+            @staticmethod
+            def forward(ctx, gp, w, x, bias, relu, p_drop):
+                dev = x.device
+                K = int(x.shape[1])
+                plan = gp.fwd
+                y = torch.empty((gp.N_dst, K), dtype=torch.float32, device=dev)
+                part = eng._partial(plan, torch.float32, K, False, dev)
+                cs = plan.c_struct(part)
+                ww, w_by_pos = w, 0
+                if w is not None and plan.perm is not None:
+                    ww, w_by_pos = eng._sorted_weights(plan, w)
+                rng = eng._rng_state(dev) if p_drop > 0 else None
+                b = bias.contiguous().reshape(-1) if bias is not None else None
+                eng._check(eng.lib.ggl_spmm_sum_bias_act(ctypes.byref(cs), _ptr(gp.col), _ptr(ww), w_by_pos,
+                                                         _ptr(x), K, _ptr(b), int(relu), float(p_drop),
+                                                         _ptr(rng), _ptr(y), eng._stream(dev)))
+                ctx.gp, ctx.w = gp, w
+                ctx.cfg = (int(gp.N_dst), K, int(relu), float(p_drop), None if bias is None else bias.shape)
+                ctx.save_for_backward(y)
+                return y
+
+            @staticmethod
+            def backward(ctx, g):
+                (y,) = ctx.saved_tensors
+                N, K, relu, p_drop, bshape = ctx.cfg
+                g = g.contiguous()
+                dev = g.device
+                ga = torch.empty_like(g)
+                gb = torch.empty(K, dtype=torch.float32, device=dev) if bshape is not None else None
+                wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K)
+                ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+                eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K, relu, p_drop, _ptr(ga), _ptr(gb),
+                                                    _ptr(ws), wsb, eng._stream(dev)))
+                gp = ctx.gp
+                gx = None
+                if ctx.needs_input_grad[2]:
+                    gx, _ = eng._spmm_fwd("sum", gp.bwd, gp.colT, ctx.w, ga, gp.N_src)
+                return None, None, gx, (gb.reshape(bshape) if gb is not None else None), None, None
+
+        self.SpMMSumBiasAct = SpMMSumBiasAct
         self.BiasAct = BiasAct
         self.BiasAdd = BiasAdd
         self.SegmentSum, self.SegmentMean, self.SegmentMax = SegmentSum, SegmentMean, SegmentMax
@@ -788,6 +832,17 @@ class Engine:
         self._check_f32("a", a)
         p = float(p_drop) if training else 0.0
         return self.BiasAct.apply(a, bias, bool(relu), p)
+
+    def spmm_bias_act(self, gp, weight, x, bias=None, relu=False, p_drop=0.0, training=True):
+        """dropout(relu(A x + bias)) for a GraphPlan `gp` (what GCNConv + the model's ReLU/dropout compute,
+        gcn_conv.py:78-108, models/gcn.py:55-59).  One kernel when the feature width is a multiple of 4
+        (16-byte rows); otherwise the SpMM and the epilogue kernel run back to back — same values."""
+        self._dev(x, weight, bias)
+        self._check_f32("x", x)
+        p = float(p_drop) if training else 0.0
+        if x.dim() == 2 and x.shape[1] % 4 == 0:
+            return self.SpMMSumBiasAct.apply(gp, weight, x.contiguous(), bias, bool(relu), p)
+        return self.BiasAct.apply(self.SpMMSum.apply(gp, weight, x.contiguous()), bias, bool(relu), p)
 
     def set_option(self, name, value):
         self._check(self.lib.ggl_set_option(name.encode(), int(value)))

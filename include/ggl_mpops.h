@@ -227,6 +227,13 @@ int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *works
  * ---------------------------------------------------------------------------------------------- */
 int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, int64_t K, int relu, float p_drop,
                      int64_t *rng_state, float *y, void *stream);
+/* ggl_spmm_sum with that forward epilogue applied to every finished row before its only store:
+ * out = dropout(relu(A x + bias)).  Identical (values and dropout mask) to ggl_spmm_sum followed by
+ * ggl_bias_act_fwd on the same rng_state; the backward is ggl_bias_act_bwd(g, out) then the transposed
+ * ggl_spmm_sum. */
+int ggl_spmm_sum_bias_act(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                          const float *x, int64_t K, const float *bias, int relu, float p_drop,
+                          int64_t *rng_state, float *out, void *stream);
 size_t ggl_bias_act_bwd_workspace_bytes(int64_t N, int64_t K);
 int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int relu, float p_drop,
                      float *ga, float *gbias, void *workspace, size_t workspace_bytes, void *stream);

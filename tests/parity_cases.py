@@ -566,6 +566,52 @@ def check_bias_act(eng, dev):
     assert torch.equal(eng.bias_act(a.detach(), None, relu=True, p_drop=p, training=False), a.detach())
 
 
+def check_spmm_bias_act(eng, dev):
+    """SpMM with the layer epilogue applied in its store (ggl_spmm_sum_bias_act) == SpMM, then the epilogue
+    kernel, replayed on the same RNG state: values, dropout mask and every gradient bit for bit — short
+    rows, chunked hub rows (epilogue in long_final_kernel), wave-per-row and narrow widths, K % 4 != 0."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    old = eng.chunk
+    try:
+        for chunk in (0, 8):
+            eng.chunk = chunk
+            eng.graph_cache.clear(); eng.seg_cache.clear()
+            for (N, E, K) in ((40, 600, 8), (64, 900, 64), (50, 700, 256), (30, 300, 47), (5, 0, 4)):
+                ei = torch.randint(0, N, (2, E), generator=g)
+                if E:
+                    ei[1, : E // 3] = 3  # a hub row (chunked when chunk = 8)
+                ei = ei.to(dev)
+                w = torch.rand(E, generator=g).to(dev)
+                gp = eng.graph_plan(ei, N)
+                go = torch.randn(N, K, generator=g).to(dev)
+                for (relu, p) in ((False, 0.0), (True, 0.0), (True, 0.5), (False, 0.3)):
+                    xa = torch.randn(N, K, generator=g).to(dev).requires_grad_(True)
+                    ba = torch.randn(1, K, generator=g).to(dev).requires_grad_(True)
+                    xb, bb = xa.detach().clone().requires_grad_(True), ba.detach().clone().requires_grad_(True)
+                    st = eng._rng_state(dev).clone()
+                    ya = eng.spmm_bias_act(gp, w, xa, ba, relu=relu, p_drop=p, training=True)
+                    eng._rng_state(dev).copy_(st)   # replay the same mask for the two-kernel form
+                    yb = eng.bias_act(eng.spmm(gp, w, xb), bb, relu=relu, p_drop=p, training=True)
+                    assert torch.equal(ya, yb), (chunk, N, E, K, relu, p)
+                    if N * K:
+                        ya.backward(go)
+                        yb.backward(go)
+                        assert torch.equal(xa.grad, xb.grad) and torch.equal(ba.grad, bb.grad)
+                    if p > 0 and E:
+                        assert bool((ya == 0).any()) and bool((ya != 0).any())
+        # no bias, no weights
+        eng.chunk = old
+        ei = torch.randint(0, 20, (2, 100), generator=g).to(dev)
+        gp = eng.graph_plan(ei, 20)
+        x = torch.randn(20, 12, generator=g).to(dev)
+        assert torch.equal(eng.spmm_bias_act(gp, None, x, None, relu=True), torch.relu(eng.spmm(gp, None, x)))
+        assert torch.equal(eng.spmm_bias_act(gp, None, x, None, relu=True, p_drop=0.9, training=False),
+                           torch.relu(eng.spmm(gp, None, x)))
+    finally:
+        eng.chunk = old
+        eng.graph_cache.clear(); eng.seg_cache.clear()
+
+
 def check_plan_cache(eng, dev):
     eng.seg_cache.clear()
     ids = torch.tensor([2, 0, 1, 0, 2, 2], device=dev)

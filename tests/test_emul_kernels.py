@@ -47,6 +47,10 @@ def test_gcn_and_gat_layer_golden(eng, golden):
     pc.check_layers_golden(eng, DEV, golden)
 
 
+def test_spmm_with_fused_epilogue(eng):
+    pc.check_spmm_bias_act(eng, DEV)
+
+
 def test_random_vs_oracle(eng, oracle):
     pc.check_random_vs_oracle(eng, DEV, oracle)
 

@@ -83,6 +83,10 @@ def test_edge_cases_and_errors(eng, dev, oracle):
     pc.check_edge_cases(eng, dev, oracle)
 
 
+def test_spmm_with_fused_epilogue(eng, dev):
+    pc.check_spmm_bias_act(eng, dev)
+
+
 def test_plan_cache(eng, dev):
     pc.check_plan_cache(eng, dev)
 
