@@ -205,10 +205,19 @@ __global__ __launch_bounds__(kBlock) void colsum_stage2_kernel(const float *__re
                                                                float *__restrict__ out) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
-  float a = 0.f;
-  for (int64_t p = 0; p < P; ++p) a = __fadd_rn(a, partial[p * K + k]);
-  out[k] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains, combined in a fixed order
+  int64_t p = 0;
+  for (; p + 4 <= P; p += 4) {
+    a0 = __fadd_rn(a0, partial[p * K + k]);
+    a1 = __fadd_rn(a1, partial[(p + 1) * K + k]);
+    a2 = __fadd_rn(a2, partial[(p + 2) * K + k]);
+    a3 = __fadd_rn(a3, partial[(p + 3) * K + k]);
+  }
+  for (; p < P; ++p) a0 = __fadd_rn(a0, partial[p * K + k]);
+  out[k] = __fadd_rn(__fadd_rn(a0, a1), __fadd_rn(a2, a3));
 }
+
+constexpr int64_t kColsumSerial = 64;  // partial rows the last stage may walk serially per column
 
 static inline void colsum_geometry(int64_t N, int64_t K, int *kp, int *groups, int64_t *blocks,
                                    int64_t *rows_per_block) {
@@ -225,7 +234,11 @@ extern "C" size_t ggl_colsum_workspace_bytes(int64_t N, int64_t K) {
   int kp, groups;
   int64_t blocks, rpb;
   colsum_geometry(N, K, &kp, &groups, &blocks, &rpb);
-  return (size_t)blocks * (size_t)groups * (size_t)(K > 0 ? K : 1) * sizeof(float);
+  const int64_t P = blocks * groups;
+  size_t b = (size_t)P * (size_t)(K > 0 ? K : 1) * sizeof(float);
+  b = (b + 255) & ~(size_t)255;
+  if (P > kColsumSerial && P * 4 <= N) b += ggl_colsum_workspace_bytes(P, K);  // partials reduced the same way
+  return b;
 }
 
 extern "C" int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *workspace,
@@ -242,8 +255,13 @@ extern "C" int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, 
   float *partial = static_cast<float *>(workspace);
   GGL_LAUNCH((colsum_stage1_kernel), blocks, kBlock, s, g, N, K, rpb, kp, groups, partial);
   GGL_LAUNCH_CHECK();
-  GGL_LAUNCH((colsum_stage2_kernel), ceil_div(K, kBlock), kBlock, s, (const float *)partial,
-             blocks * groups, K, out);
+  const int64_t P = blocks * groups;
+  if (P > kColsumSerial && P * 4 <= N) {  // still many partial rows: reduce them with the same two stages
+    size_t off = ((size_t)P * (size_t)K * sizeof(float) + 255) & ~(size_t)255;
+    return ggl_colsum_f32(partial, P, K, out, static_cast<char *>(workspace) + off, workspace_bytes - off,
+                          stream);
+  }
+  GGL_LAUNCH((colsum_stage2_kernel), ceil_div(K, kBlock), kBlock, s, (const float *)partial, P, K, out);
   GGL_LAUNCH_CHECK();
   return GGL_OK;
 }

@@ -512,7 +512,7 @@ def check_sampler(eng, dev, oracle):
 def check_colsum(eng, dev):
     """bias-gradient kernel: column sums vs an f64 sum; also through BiasAdd's autograd."""
     g = torch.Generator(device="cpu").manual_seed(2)
-    for (N, K) in ((0, 5), (1, 1), (7, 3), (1000, 47), (5000, 256), (3000, 300), (70000, 16)):
+    for (N, K) in ((0, 5), (1, 1), (7, 3), (1000, 47), (5000, 256), (3000, 300), (70000, 16), (300000, 4)):  # the last two reduce their partials recursively
         x = torch.randn(N, K, generator=g).to(dev)
         got = eng.colsum(x)
         ref = x.double().sum(0)
