@@ -117,3 +117,48 @@ def test_gspmm_fuzz(oracle, prob):
     finally:
         eng.chunk = old
         eng.seg_cache.clear(); eng.graph_cache.clear(); eng.w_cache.clear()
+
+
+@st.composite
+def gat_problems(draw):
+    N = draw(st.integers(1, 30))
+    E = draw(st.integers(0, 250))
+    H = draw(st.sampled_from([1, 2, 3, 4, 8]))
+    C = draw(st.sampled_from([1, 3, 4, 8, 16, 64]))
+    chunk = draw(st.sampled_from([1, 3, 16, 4096]))
+    kind = draw(st.sampled_from(["uniform", "sorted", "hub", "single"]))
+    scale = draw(st.sampled_from([0.1, 1.0, 20.0]))   # large logits: the online max moves a lot
+    seed = draw(st.integers(0, 2**31 - 1))
+    return N, E, H, C, chunk, kind, scale, seed
+
+
+@settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck))
+@given(gat_problems())
+def test_gat_fused_fuzz(oracle, prob):
+    """One-walk online-softmax forward + edge-parallel / transposed-walk backward vs the oracle's three-pass
+    restatement of gat_conv.py:103-112: short rows, chunked hubs on either side, empty rows, big logits."""
+    eng = engine()
+    N, E, H, C, chunk, kind, scale, seed = prob
+    rng = np.random.default_rng(seed)
+    index = np.stack([make_ids(rng, N, E, "hub" if kind == "single" else "uniform"),
+                      make_ids(rng, N, E, kind)]).astype(np.int64)
+    el = (rng.standard_normal((N, H)) * scale).astype(np.float32)
+    er = (rng.standard_normal((N, H)) * scale).astype(np.float32)
+    x = rng.standard_normal((N, H, C)).astype(np.float32)
+    go = rng.standard_normal((N, H, C)).astype(np.float32)
+    old = eng.chunk
+    eng.chunk = chunk
+    eng.seg_cache.clear(); eng.graph_cache.clear()
+    try:
+        elt, ert, xt = (pc.to_t(a, DEV).requires_grad_(True) for a in (el, er, x))
+        y = eng.gat_fused(pc.to_t(index, DEV), elt, ert, xt, 0.2)
+        oy = oracle.gat_fwd(index, el, er, x, 0.2)
+        np.testing.assert_allclose(pc.to_np(y), oy, rtol=2e-5, atol=2e-6)
+        y.backward(pc.to_t(go, DEV))
+        gel, ger, gx = oracle.gat_bwd(index, el, er, x, go, 0.2)
+        np.testing.assert_allclose(pc.to_np(xt.grad), gx, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(pc.to_np(elt.grad), gel, rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(pc.to_np(ert.grad), ger, rtol=2e-4, atol=5e-5)
+    finally:
+        eng.chunk = old
+        eng.seg_cache.clear(); eng.graph_cache.clear()
