@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SegPlanC(ctypes.Structure):

@@ -19,13 +19,14 @@
 // a chunk-local max (m_c, d_c = sum exp(s - m_c), acc_c = sum exp(s - m_c) x); gat_long_final_kernel
 // merges them in chunk order: m = max m_c, d = sum d_c e^{m_c - m}, out = sum acc_c e^{m_c - m} / (d + 1e-16).
 //
-// Backward: everything per edge is independent once the row statistics are known, so it is
-// edge-parallel (balanced regardless of the degree distribution):
-//   gat_rowdot_kernel : dot[i,h] = <g[i,h,:], out[i,h,:]>            (= sum_p alpha_p dalpha_p)
-//   gat_bwd_edge_kernel: one thread per (sorted position p, head h): alpha, dalpha = <g_i, x_j>,
-//                        de = alpha (dalpha - dot) LeakyReLU'(.)  -> alpha[E,H], de[E,H]
-//   ger = ggl_segment_sum(de) on the forward plan, gel / gx = row reductions on the transposed plan
-//   (ggl_segment_sum, ggl_bspmm_sum through posT).
+// Backward: two walks, one per side.
+//   gat_bwd_dst_kernel (forward plan, lane = head of a destination row or of a hub chunk): row dot
+//     <g_i, out_i>, alpha, de = alpha (<g_i, x_j> - dot) LeakyReLU'(.) -> alpha[E,H], de[E,H], and
+//     ger[i,h] = sum_p de in the same walk;
+//   gat_bwd_src_kernel (transposed plan): gx[j,h,:] = sum alpha g[dst,h,:] and gel[j,h] = sum de, reading
+//     alpha / de through posT.
+// (The first version was edge-parallel on the destination side — a row-dot kernel, one thread per
+// (position, head), then ggl_segment_sum for ger — and ran bspmm + segment_sum on the source side.)
 // Roofline: HBM; algorithmic bytes per edge = 4*H*C (feature row) + 4 (col) + 4*H (el row).
 #include "common.hpp"
 
@@ -41,6 +42,7 @@ struct GatDims {
   float slope;
   int64_t N, H, C, K, E;
   int64_t chunk, n_long, n_chunks, chunk_blocks, nblocks;
+  int64_t es;  // element stride of alpha / de: 1 = two [E,H] arrays, 2 = interleaved [E,H,2] (one 64-byte line per edge)
   int logL;
 };
 
@@ -206,48 +208,125 @@ __global__ __launch_bounds__(kBlock) void gat_long_final_kernel(
   }
 }
 
-// dot[i,h] = <g[i,h,:], out[i,h,:]>
-__global__ __launch_bounds__(kBlock) void gat_rowdot_kernel(const float *__restrict__ g,
-                                                            const float *__restrict__ out, int64_t NH,
-                                                            int64_t C, float *__restrict__ dot) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NH; i += stride) {
-    float a = 0.0f;
-    for (int64_t c = 0; c < C; ++c) a = __fadd_rn(a, __fmul_rn(g[i * C + c], out[i * C + c]));
-    dot[i] = a;
+// Destination-major half of the backward in ONE walk of the forward plan.  A work item is a short row or
+// one chunk of a long row; a group of 2^logL >= H lanes owns it, lane = head.  Per head the lane computes
+// dot_i = <g_i, out_i> once, then walks the item's positions in order:
+//   alpha_p = exp(s_p - m_i) / (den_i + 1e-16),  dalpha_p = <g_i[h,:], x_j[h,:]>,
+//   de_p = alpha_p (dalpha_p - dot_i) LeakyReLU'(raw_p)          -> alpha[E,H], de[E,H] (sorted positions)
+//   ger[i,h] = sum_p de_p  (in position order; chunk partials are combined in chunk order afterwards)
+// CREG > 0: C is known at compile time and g_i[h,:] lives in registers; 0 = any C, g_i re-read (cached).
+// Replaces three launches (row dots, an edge-parallel alpha/de kernel, segment_sum(de) for ger: 0.3 + 5.7
+// + 2.7 ms on the Reddit-sized graph) with the same rounded operations in the same order.
+template <int VEC, int CREG>
+__global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ er,
+    const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ out,
+    const float *__restrict__ rowmax, const float *__restrict__ rowden, float *__restrict__ alpha,
+    float *__restrict__ de, float *__restrict__ ger, float *__restrict__ pger, const GatDims d) {
+  const int64_t H = d.H, K = d.K;
+  const int64_t C = CREG > 0 ? (int64_t)CREG : d.C;
+  const int LG = 1 << d.logL;
+  const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> d.logL;
+  const int li = threadIdx.x & (LG - 1);
+  if (item >= d.n_chunks + d.N) return;
+  const bool is_chunk = item < d.n_chunks;
+  int64_t row, beg, end;
+  if (is_chunk) {  // chunks carry the lowest item ids: the hub work is dispatched first
+    int64_t lo = 0, hi = d.n_long - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (chunk_ptr[mid] <= item) lo = mid; else hi = mid - 1;
+    }
+    row = long_rows[lo];
+    beg = rowptr[row] + (item - chunk_ptr[lo]) * d.chunk;
+    const int64_t rend = rowptr[row + 1];
+    end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
+  } else {
+    const int64_t slot = item - d.n_chunks;
+    row = row_order ? (int64_t)row_order[slot] : slot;
+    beg = rowptr[row];
+    end = rowptr[row + 1];
+    if (end - beg > d.chunk) return;  // long row: its chunks are separate items
+  }
+  for (int64_t h = li; h < H; h += LG) {
+    const float *__restrict__ gi = g + row * K + h * C;
+    const float *__restrict__ oi = out + row * K + h * C;
+    float gr[CREG > 0 ? CREG : 1];
+    float dot = 0.0f;
+    if (CREG > 0) {
+#pragma unroll
+      for (int c = 0; c < (CREG > 0 ? CREG : 1); ++c) {
+        gr[c] = gi[c];
+        dot = __fadd_rn(dot, __fmul_rn(gr[c], oi[c]));
+      }
+    } else {
+      for (int64_t c = 0; c < C; ++c) dot = __fadd_rn(dot, __fmul_rn(gi[c], oi[c]));
+    }
+    const float er_i = er[row * H + h];
+    const float m = rowmax[row * H + h];
+    const float inv = __fadd_rn(rowden[row * H + h], 1e-16f);
+    float gsum = 0.0f;
+    auto edge = [&](int64_t p, int64_t src, float elv, const float *__restrict__ xj) {
+      const float raw = __fadd_rn(elv, er_i);
+      const float al = __fdiv_rn(GGL_EXPF(__fadd_rn(lrelu(raw, d.slope), -m)), inv);
+      float da = 0.0f;
+      if (CREG > 0) {
+#pragma unroll
+        for (int c = 0; c < (CREG > 0 ? CREG : 1); c += VEC) {
+          float xv[VEC];
+          F32V<VEC>::load(xj + c, xv);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) da = __fadd_rn(da, __fmul_rn(gr[(c + q) % (CREG > 0 ? CREG : 1)], xv[q]));
+        }
+      } else {
+        for (int64_t c = 0; c < C; c += VEC) {
+          float gv[VEC], xv[VEC];
+          F32V<VEC>::load(gi + c, gv);
+          F32V<VEC>::load(xj + c, xv);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) da = __fadd_rn(da, __fmul_rn(gv[q], xv[q]));
+        }
+      }
+      const float ds = __fmul_rn(al, __fadd_rn(da, -dot));
+      const float dv = raw > 0.0f ? ds : __fmul_rn(ds, d.slope);
+      alpha[(p * H + h) * d.es] = al;
+      de[(p * H + h) * d.es] = dv;
+      gsum = __fadd_rn(gsum, dv);
+      (void)src;
+    };
+    int64_t p = beg;
+    for (; p + 4 <= end; p += 4) {
+      int64_t sj[4];
+      float ev[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sj[u] = col[p + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ev[u] = el[sj[u] * H + h];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) edge(p + u, sj[u], ev[u], x + sj[u] * K + h * C);
+    }
+    for (; p < end; ++p) {
+      const int64_t s0 = col[p];
+      edge(p, s0, el[s0 * H + h], x + s0 * K + h * C);
+    }
+    if (is_chunk) pger[item * H + h] = gsum;
+    else ger[row * H + h] = gsum;
   }
 }
 
-// one thread per (sorted position p, head h)
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(
-    const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const float *__restrict__ el,
-    const float *__restrict__ er, const float *__restrict__ x, const float *__restrict__ g,
-    const float *__restrict__ rowmax, const float *__restrict__ rowden, const float *__restrict__ dot,
-    float *__restrict__ alpha, float *__restrict__ de, const GatDims d) {
+__global__ __launch_bounds__(kBlock) void gat_bwd_dst_final_kernel(const int32_t *__restrict__ long_rows,
+                                                                   const int64_t *__restrict__ chunk_ptr,
+                                                                   const float *__restrict__ pger,
+                                                                   float *__restrict__ ger, int64_t n_long,
+                                                                   int64_t H) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t H = d.H, C = d.C, K = d.K;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < d.E * H; t += stride) {
-    const int64_t p = t / H, h = t - p * H;
-    const int64_t i = rowidx[p], src = col[p];
-    const float raw = __fadd_rn(el[src * H + h], er[i * H + h]);
-    const float s = lrelu(raw, d.slope);
-    const float al = __fdiv_rn(GGL_EXPF(__fadd_rn(s, -rowmax[i * H + h])), __fadd_rn(rowden[i * H + h], 1e-16f));
-    const float *__restrict__ gi = g + i * K + h * C;
-    const float *__restrict__ xj = x + src * K + h * C;
-    float da = 0.0f;
-    // VEC = 4 (C % 4 == 0): the head's C channels as 16-byte loads — 8 lanes x 16 B per instruction
-    // instead of 64 strided dwords (the scalar form made this kernel 19 ms of a 42 ms GAT step)
-    for (int64_t c = 0; c < C; c += VEC) {
-      float gv[VEC], xv[VEC];
-      F32V<VEC>::load(gi + c, gv);
-      F32V<VEC>::load(xj + c, xv);
-#pragma unroll
-      for (int q = 0; q < VEC; ++q) da = __fadd_rn(da, __fmul_rn(gv[q], xv[q]));
-    }
-    const float ds = __fmul_rn(al, __fadd_rn(da, -dot[i * H + h]));
-    alpha[t] = al;
-    de[t] = raw > 0.0f ? ds : __fmul_rn(ds, d.slope);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_long * H; t += stride) {
+    const int64_t j = t / H, h = t - j * H;
+    float a = 0.0f;
+    for (int64_t c = chunk_ptr[j]; c < chunk_ptr[j + 1]; ++c) a = __fadd_rn(a, pger[c * H + h]);
+    ger[(int64_t)long_rows[j] * H + h] = a;
   }
 }
 
@@ -261,7 +340,7 @@ template <int VEC>
 __device__ __forceinline__ void gat_src_walk(const int32_t *__restrict__ colT, const int32_t *__restrict__ posT,
                                              const float *__restrict__ alpha, const float *__restrict__ de,
                                              const float *__restrict__ g, int64_t H, int64_t K, int64_t h,
-                                             int64_t kk, bool lead, int64_t beg, int64_t end,
+                                             int64_t es, int64_t kk, bool lead, int64_t beg, int64_t end,
                                              float (&acc)[VEC], float &gl) {
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
@@ -276,8 +355,8 @@ __device__ __forceinline__ void gat_src_walk(const int32_t *__restrict__ colT, c
     for (int u = 0; u < 4; ++u) F32V<VEC>::load(g + r[u] * K + kk, v[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      a[u] = alpha[e[u] * H + h];
-      dv[u] = lead ? de[e[u] * H + h] : 0.0f;
+      a[u] = alpha[(e[u] * H + h) * es];
+      dv[u] = lead ? de[(e[u] * H + h) * es] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -290,10 +369,10 @@ __device__ __forceinline__ void gat_src_walk(const int32_t *__restrict__ colT, c
     const int64_t r0 = colT[q], e0 = posT[q];
     float v0[VEC];
     F32V<VEC>::load(g + r0 * K + kk, v0);
-    const float a0 = alpha[e0 * H + h];
+    const float a0 = alpha[(e0 * H + h) * es];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(a0, v0[i]));
-    if (lead) gl = __fadd_rn(gl, de[e0 * H + h]);
+    if (lead) gl = __fadd_rn(gl, de[(e0 * H + h) * es]);
   }
 }
 
@@ -323,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
       const int64_t h = kk / d.C;
       const bool lead = (kk == h * d.C);
       float acc[VEC], gl;
-      gat_src_walk<VEC>(colT, posT, alpha, de, g, H, K, h, kk, lead, beg, end, acc, gl);
+      gat_src_walk<VEC>(colT, posT, alpha, de, g, H, K, h, d.es, kk, lead, beg, end, acc, gl);
       F32V<VEC>::store(pacc + cid * K + kk, acc);
       if (lead) pgel[cid * H + h] = gl;
     }
@@ -341,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
     const int64_t h = kk / d.C;
     const bool lead = (kk == h * d.C);
     float acc[VEC], gl;
-    gat_src_walk<VEC>(colT, posT, alpha, de, g, H, K, h, kk, lead, beg, end, acc, gl);
+    gat_src_walk<VEC>(colT, posT, alpha, de, g, H, K, h, d.es, kk, lead, beg, end, acc, gl);
     F32V<VEC>::store(gx + row * K + kk, acc);
     if (lead) gel[row * H + h] = gl;
   }
@@ -441,32 +520,46 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
                                      const float *rowmax, const float *rowden, float slope, int64_t H,
                                      int64_t C, float *alpha, float *de, float *ger, float *dot_ws,
                                      void *stream) {
+  (void)rowidx; (void)dot_ws;  // needed by the first (edge-parallel) version; accepted, unused
   GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
-  GGL_REQUIRE(H > 0 && C > 0, GGL_EINVAL, "H and C must be positive");
+  GGL_REQUIRE(H > 0 && C > 0 && plan->chunk > 0, GGL_EINVAL, "H, C and chunk must be positive");
   const int64_t N = plan->N, E = plan->E;
   if (N == 0) return GGL_OK;
-  GGL_REQUIRE(er && g && out && rowmax && rowden && ger && dot_ws, GGL_EINVAL, "NULL pointer");
-  GGL_REQUIRE((col && rowidx && el && x && alpha && de) || E == 0, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE(er && g && out && rowmax && rowden && ger, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE((col && el && x && alpha && de) || E == 0, GGL_EINVAL, "NULL pointer");
   GatDims d{};
   d.slope = slope; d.N = N; d.H = H; d.C = C; d.K = H * C; d.E = E;
+  d.es = (de == alpha + 1) ? 2 : 1;  // de == alpha + 1: one interleaved [E,H,2] buffer
+  d.chunk = plan->chunk; d.n_long = plan->n_long; d.n_chunks = plan->n_long > 0 ? plan->n_chunks : 0;
+  float *pger = nullptr;
+  if (plan->n_long > 0) {
+    GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
+                "plan has long rows but long_rows/chunk_ptr/partial is NULL");
+    pger = static_cast<float *>(plan->partial);
+  }
+  d.logL = pow2_log2(H);  // lanes per work item: the next power of two >= H, at most 64
+  const int64_t items = d.n_chunks + N;
+  const int64_t grid = ceil_div(items << d.logL, (int64_t)kBlock);
+  GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+  const int32_t *order = options().row_order ? plan->row_order : nullptr;
   hipStream_t s = as_stream(stream);
-  GGL_LAUNCH((gat_rowdot_kernel), grid_for(N * H), kBlock, s, g, out, N * H, C, dot_ws);
+  const bool vec4 = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) && !options().force_generic;
+#define GGL_GAT_DST(V, CR)                                                                              \
+  GGL_LAUNCH((gat_bwd_dst_kernel<V, CR>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,    \
+             plan->chunk_ptr, el, er, x, g, out, rowmax, rowden, alpha, de, ger, pger, d)
+  if (vec4 && C == 8) GGL_GAT_DST(4, 8);
+  else if (vec4 && C == 16) GGL_GAT_DST(4, 16);
+  else if (vec4) GGL_GAT_DST(4, 0);
+  else GGL_GAT_DST(1, 0);
+#undef GGL_GAT_DST
   GGL_LAUNCH_CHECK();
-  if (E > 0) {
-    const bool vec4 = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(g) & 15u) == 0);
-    if (vec4)
-      GGL_LAUNCH((gat_bwd_edge_kernel<4>), grid_for(E * H), kBlock, s, col, rowidx, el, er, x, g, rowmax,
-                 rowden, (const float *)dot_ws, alpha, de, d);
-    else
-      GGL_LAUNCH((gat_bwd_edge_kernel<1>), grid_for(E * H), kBlock, s, col, rowidx, el, er, x, g, rowmax,
-                 rowden, (const float *)dot_ws, alpha, de, d);
+  if (plan->n_long > 0) {
+    GGL_LAUNCH((gat_bwd_dst_final_kernel), grid_for(plan->n_long * H), kBlock, s, plan->long_rows,
+               plan->chunk_ptr, (const float *)pger, ger, plan->n_long, H);
     GGL_LAUNCH_CHECK();
   }
-  // ger[i,h] = sum over the row's positions of de: de already lives in sorted positions
-  ggl_segplan_t p = *plan;
-  p.perm = nullptr;
-  return ggl_segment_sum(GGL_F32, de, &p, H, ger, stream);
+  return GGL_OK;
 }
 
 // Source-major half of the backward (gat_bwd_src_kernel above).  planT->partial must hold
@@ -483,6 +576,7 @@ extern "C" int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *
   GGL_REQUIRE((colT && posT && alpha && de && g) || planT->E == 0, GGL_EINVAL, "NULL pointer");
   GatDims d{};
   d.N = N; d.H = H; d.C = C; d.K = H * C; d.E = planT->E;
+  d.es = (de == alpha + 1) ? 2 : 1;
   d.chunk = planT->chunk; d.n_long = planT->n_long; d.n_chunks = planT->n_chunks;
   float *pacc = nullptr, *pgel = nullptr;
   if (planT->n_long > 0) {

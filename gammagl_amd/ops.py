@@ -614,23 +614,23 @@ class Engine:
                 dev = g.device
                 H, C = int(x.shape[1]), int(x.shape[2])
                 st = eng._stream(dev)
-                alpha = torch.empty((gp.E, H), dtype=torch.float32, device=dev)
-                de = torch.empty((gp.E, H), dtype=torch.float32, device=dev)
+                # alpha and de interleaved [E, H, 2]: the source-side walk fetches both with one 64-byte line
+                ad = torch.empty((max(gp.E, 1), H, 2), dtype=torch.float32, device=dev)
+                alpha, de = ad.data_ptr(), ad.data_ptr() + 4
                 ger = torch.empty_like(er)
-                dot = torch.empty_like(er)
                 part_f = eng._partial(gp.fwd, torch.float32, H, False, dev)  # must outlive the launch
                 cs = gp.fwd.c_struct(part_f)
                 eng._check(eng.lib.ggl_gat_fused_bwd_dst(
-                    ctypes.byref(cs), _ptr(gp.col), _ptr(gp.row_of_pos), _ptr(el), _ptr(er), _ptr(x),
-                    _ptr(g), _ptr(out), _ptr(rmax), _ptr(rden), ctx.slope, H, C, _ptr(alpha), _ptr(de),
-                    _ptr(ger), _ptr(dot), st))
+                    ctypes.byref(cs), _ptr(gp.col), None, _ptr(el), _ptr(er), _ptr(x),
+                    _ptr(g), _ptr(out), _ptr(rmax), _ptr(rden), ctx.slope, H, C, alpha, de,
+                    _ptr(ger), None, st))
                 bwd = gp.bwd
                 gx = torch.empty((gp.N_src, H, C), dtype=torch.float32, device=dev)
                 gel = torch.empty((gp.N_src, H), dtype=torch.float32, device=dev)
                 part = eng._partial(bwd, torch.float32, H * C + H, False, dev)  # gx and gel partials of long rows
                 csT = bwd.c_struct(part)
                 eng._check(eng.lib.ggl_gat_fused_bwd_src(ctypes.byref(csT), _ptr(gp.colT), _ptr(gp.posT),
-                                                         _ptr(alpha), _ptr(de), _ptr(g), H, C,
+                                                         alpha, de, _ptr(g), H, C,
                                                          _ptr(gx), _ptr(gel), st))
                 return None, gel, ger, gx, None
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GGL_ABI_VERSION 2
+#define GGL_ABI_VERSION 3
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
 enum {
@@ -249,9 +249,9 @@ int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int r
  * Rows longer than plan->chunk are reduced chunk-wise with chunk-local maxima and merged in chunk
  * order (online-softmax identity); short rows use the formula above verbatim.
  * Backward (edge-parallel, then source-major):
- *   ggl_gat_fused_bwd_dst: dot[i,h] = <g_i, out_i>; per (sorted position, head): alpha, de =
- *       alpha (<g_i, x_j> - dot) lrelu'(.) -> alpha[E,H], de[E,H] (forward sorted positions);
- *       ger[N,H] = row sums of de (ggl_segment_sum on the forward plan)
+ *   ggl_gat_fused_bwd_dst: ONE walk of the forward plan (lane = head of a row / of a hub chunk):
+ *       dot[i,h] = <g_i, out_i>; per (sorted position, head): alpha, de = alpha (<g_i, x_j> - dot)
+ *       lrelu'(.) -> alpha[E,H], de[E,H] (forward sorted positions); ger[N,H] = row sums of de
  *   ggl_gat_fused_bwd_src: ONE walk of the transposed plan: gx[j,h,:] = sum_p alpha * g[dst,h,:] and
  *       gel[j,h] = sum_p de, reading alpha/de through posT (transposed position -> forward position);
  *       planT->partial = ggl_partial_bytes(GGL_F32, n_chunks, H*C + H, 0) bytes when it has long rows
@@ -261,8 +261,10 @@ int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float
                       float *out, float *rowmax, float *rowden, void *stream);
 /* plan->partial for ggl_gat_fused_fwd when the plan has long rows (chunk-local softmax partials) */
 size_t ggl_gat_partial_bytes(int64_t n_chunks, int64_t H, int64_t C);
-/* rowidx [E] int32: destination row of every sorted position; dot_ws [N,H] f32 scratch;
- * plan->partial as for ggl_segment_sum with K = H (the ger reduction) */
+/* alpha / de: two [E,H] f32 arrays, or ONE interleaved [E,H,2] buffer passed as (base, base + 1) — then
+ * an edge's alpha and de share a 64-byte line for the source-side walk (same convention in
+ * ggl_gat_fused_bwd_src).  rowidx, dot_ws: unused since ABI 3 (may be NULL); plan->partial = ggl_partial_bytes(GGL_F32, n_chunks,
+ * H, 0) bytes when the plan has long rows (ger partials of the hub chunks) */
 int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *col, const int32_t *rowidx,
                           const float *el, const float *er, const float *x, const float *g,
                           const float *out, const float *rowmax, const float *rowden, float slope,

@@ -324,12 +324,55 @@ def _check_gat(eng, dev, oracle, index, N, H, C, rng):
     np.testing.assert_allclose(to_np(ert.grad), ger, rtol=1e-4, atol=2e-5)
 
 
+def _check_gat_separate_buffers(eng, dev, index, N, H, C, rng):
+    """C-ABI convention check: alpha / de as two [E,H] arrays give the same gradients as the interleaved
+    [E,H,2] buffer the Engine passes (ggl_gat_fused_bwd_dst / _src accept both)."""
+    import ctypes
+
+    from gammagl_amd.ops import _ptr
+
+    it = to_t(index, dev)
+    el, er = (to_t(rng.standard_normal((N, H)).astype(np.float32), dev).requires_grad_(True) for _ in range(2))
+    x = to_t(rng.standard_normal((N, H, C)).astype(np.float32), dev).requires_grad_(True)
+    go = to_t(rng.standard_normal((N, H, C)).astype(np.float32), dev)
+    y = eng.gat_fused(it, el, er, x, 0.2)
+    y.backward(go)
+    gp = eng.graph_plan(it, N)
+    E = gp.E
+    st = eng._stream(dev)
+    out, rmax, rden = (torch.empty(s_, dtype=torch.float32, device=dev) for s_ in ((N, H, C), (N, H), (N, H)))
+    part = None
+    if gp.fwd.n_long > 0:
+        part = torch.empty(eng.lib.ggl_gat_partial_bytes(gp.fwd.n_chunks, H, C) + 16, dtype=torch.uint8, device=dev)
+    cs = gp.fwd.c_struct(part)
+    eld, erd, xd = el.detach(), er.detach(), x.detach()
+    eng._check(eng.lib.ggl_gat_fused_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(eld), _ptr(erd), _ptr(xd), 0.2, H, C,
+                                         _ptr(out), _ptr(rmax), _ptr(rden), st))
+    alpha = torch.empty((max(E, 1), H), dtype=torch.float32, device=dev)
+    de = torch.empty((max(E, 1), H), dtype=torch.float32, device=dev)
+    ger = torch.empty((N, H), dtype=torch.float32, device=dev)
+    pf = eng._partial(gp.fwd, torch.float32, H, False, dev)
+    cs = gp.fwd.c_struct(pf)
+    eng._check(eng.lib.ggl_gat_fused_bwd_dst(ctypes.byref(cs), _ptr(gp.col), None, _ptr(eld), _ptr(erd), _ptr(xd),
+                                             _ptr(go), _ptr(out), _ptr(rmax), _ptr(rden), 0.2, H, C, _ptr(alpha),
+                                             _ptr(de), _ptr(ger), None, st))
+    gx = torch.empty((N, H, C), dtype=torch.float32, device=dev)
+    gel = torch.empty((N, H), dtype=torch.float32, device=dev)
+    pb = eng._partial(gp.bwd, torch.float32, H * C + H, False, dev)
+    csT = gp.bwd.c_struct(pb)
+    eng._check(eng.lib.ggl_gat_fused_bwd_src(ctypes.byref(csT), _ptr(gp.colT), _ptr(gp.posT), _ptr(alpha), _ptr(de),
+                                             _ptr(go), H, C, _ptr(gx), _ptr(gel), st))
+    assert torch.equal(out, y.detach())
+    assert torch.equal(ger, er.grad) and torch.equal(gel, el.grad) and torch.equal(gx, x.grad)
+
+
 def check_gat_random(eng, dev, oracle):
     rng = np.random.default_rng(9)
     for (N, E, H, C) in ((30, 200, 8, 8), (64, 700, 4, 16), (17, 90, 1, 5), (40, 300, 3, 7), (25, 250, 8, 64)):
         index = _rand_graph(rng, N, E)
         index[1, :5] = N - 1
         _check_gat(eng, dev, oracle, index, N, H, C, rng)
+        _check_gat_separate_buffers(eng, dev, index, N, H, C, rng)
     # isolated destination rows: out = 0, no NaN (den = 0 + 1e-16)
     index = np.array([[0, 1, 2], [1, 1, 1]], dtype=np.int64)
     x = rng.standard_normal((4, 2, 4)).astype(np.float32)
