@@ -68,10 +68,10 @@ SIGNATURES = {
     "ggl_bias_act_fwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V]),
     "ggl_bias_act_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_bias_act_bwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V, c_size_t, _V]),
-    "ggl_gat_fused_fwd": (c_int, [_P, _V, _V, _V, _V, c_float, c_int64, c_int64, _V, _V, _V, _V]),
+    "ggl_gat_fused_fwd": (c_int, [_P, _V, _V, _V, _V, c_float, c_int64, c_int64, c_float, _V, _V, _V, _V, _V]),
     "ggl_gat_partial_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,
-                                      _V, _V, _V, _V, _V]),
+                                      c_float, _V, _V, _V, _V, _V, _V]),
     "ggl_gat_fused_bwd_src": (c_int, [_P, _V, _V, _V, _V, _V, c_int64, c_int64, _V, _V, _V]),
     "ggl_sample_count": (c_int, [_V, _V, c_int64, c_int64, c_int, _V, _V]),
     "ggl_sample_pick": (c_int, [_V, _V, _V, c_int64, c_int64, c_int, _V, _V, _V, _V, _V]),

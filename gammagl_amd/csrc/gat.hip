@@ -42,11 +42,20 @@ struct GatDims {
   float slope;
   int64_t N, H, C, K, E;
   int64_t chunk, n_long, n_chunks, chunk_blocks, nblocks;
+  uint32_t drop_thresh;  // attention dropout (gat_conv.py:104, GATConvFuse's last argument): keep when
+  float drop_scale;      // Philox(p * H + h).x >= drop_thresh, kept alphas scaled by 1 / (1 - p)
   int64_t es;  // element stride of alpha / de: 1 = two [E,H] arrays, 2 = interleaved [E,H,2] (one 64-byte line per edge)
   int logL;
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : __fmul_rn(v, slope); }
+
+__device__ __forceinline__ uint32_t pick_word(const U4 &u, int c) {
+  return c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
+}
+__device__ __forceinline__ uint32_t drop_word(int64_t p, int64_t H, int64_t h, uint64_t offset, uint64_t seed) {
+  return pick_word(philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed), (int)(p & 3));
+}
 
 template <int VEC> struct F32V {
   static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[VEC]) {
@@ -79,16 +88,23 @@ template <> struct F32V<4> {
 // once.  The in-tree chain (softmax.py:29-35) makes three passes (max, sum, weighted sum); the one-walk
 // form differs from it only in rounding (a few ulp per rescale; the parity bar for float reductions is
 // 1e-5 relative and is tested against the oracle's three-pass restatement).  Four feature rows in flight.
-template <int VEC>
+// DROP: attention dropout — the softmax statistics (m, den) see every edge, the weighted sum only the
+// kept ones, scaled by 1/(1-p): out = sum_p keep_p alpha_p x_p / (1-p), alpha = softmax over ALL edges.
+// Random word of (position p, head h): component p & 3 of Philox4x32-10((p >> 2) * H + h) — one draw
+// serves four consecutive positions of a head, and the walks below are aligned to multiples of 4 so the
+// unrolled body makes one draw per four edges (a draw per edge doubled the forward: 4.1 -> 9.4 ms).
+template <int VEC, bool DROP>
 __device__ __forceinline__ void gat_online(const int32_t *__restrict__ col, const float *__restrict__ el,
                                            const float *__restrict__ x, float er_i, float slope, int64_t H,
                                            int64_t K, int64_t h, int64_t kk, int64_t beg, int64_t end,
+                                           const GatDims &d, const int64_t *__restrict__ rng,
                                            float &m, float &den, float (&acc)[VEC]) {
   m = -FLT_MAX;  // unsorted_segment_max: lowest() fill, strict <
   den = 0.0f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-  auto absorb = [&](float s, const float (&v)[VEC]) {
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  auto absorb = [&](uint32_t word, float s, const float (&v)[VEC]) {
     if (m < s) {  // new maximum: bring the running sums to the new reference point
       const float sc = GGL_EXPF(__fadd_rn(m, -s));  // m = -FLT_MAX on the first element: exp(-inf) = 0
       den = __fmul_rn(den, sc);
@@ -98,13 +114,26 @@ __device__ __forceinline__ void gat_online(const int32_t *__restrict__ col, cons
     }
     const float e = GGL_EXPF(__fadd_rn(s, -m));
     den = __fadd_rn(den, e);
+    float ek = e;
+    if (DROP) ek = (word >= d.drop_thresh) ? __fmul_rn(e, d.drop_scale) : 0.0f;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(v[i], e));
+    for (int i = 0; i < VEC; ++i) acc[i] = __fadd_rn(acc[i], __fmul_rn(v[i], ek));
+  };
+  auto single = [&](int64_t q) {
+    const int64_t c0 = col[q];
+    float v0[VEC];
+    F32V<VEC>::load(x + c0 * K + kk, v0);
+    absorb(DROP ? drop_word(q, H, h, offset, seed) : 0u, lrelu(__fadd_rn(el[c0 * H + h], er_i), slope), v0);
   };
   int64_t p = beg;
+  if (DROP) {  // walk up to a multiple of 4 so that each unrolled group shares one draw
+    for (; p < end && (p & 3) != 0; ++p) single(p);
+  }
   for (; p + 4 <= end; p += 4) {
     int64_t c[4];
     float v[4][VEC], s[4];
+    U4 rw{0u, 0u, 0u, 0u};
+    if (DROP) rw = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
 #pragma unroll
     for (int u = 0; u < 4; ++u) c[u] = col[p + u];
 #pragma unroll
@@ -112,24 +141,19 @@ __device__ __forceinline__ void gat_online(const int32_t *__restrict__ col, cons
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[u] = lrelu(__fadd_rn(el[c[u] * H + h], er_i), slope);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) absorb(s[u], v[u]);
+    for (int u = 0; u < 4; ++u) absorb(pick_word(rw, u), s[u], v[u]);
   }
-  for (; p < end; ++p) {
-    const int64_t c0 = col[p];
-    float v0[VEC];
-    F32V<VEC>::load(x + c0 * K + kk, v0);
-    absorb(lrelu(__fadd_rn(el[c0 * H + h], er_i), slope), v0);
-  }
+  for (; p < end; ++p) single(p);
 }
 
-template <int VEC>
+template <int VEC, bool DROP>
 __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
     const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ er,
     const float *__restrict__ x, float *__restrict__ y, float *__restrict__ rowmax,
     float *__restrict__ rowden, float *__restrict__ pacc, float *__restrict__ pm,
-    float *__restrict__ pd, const GatDims d) {
+    float *__restrict__ pd, const int64_t *__restrict__ rng, const GatDims d) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int64_t H = d.H, K = d.K;
@@ -149,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
       const int64_t h = kk / d.C;
       const float er_i = er[row * H + h];
       float m, dsum, acc[VEC];
-      gat_online<VEC>(col, el, x, er_i, d.slope, H, K, h, kk, beg, end, m, dsum, acc);
+      gat_online<VEC, DROP>(col, el, x, er_i, d.slope, H, K, h, kk, beg, end, d, rng, m, dsum, acc);
       F32V<VEC>::store(pacc + cid * K + kk, acc);
       if (kk == h * d.C) {
         pm[cid * H + h] = m;
@@ -170,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
     const int64_t h = kk / d.C;
     const float er_i = er[row * H + h];
     float m, dsum, acc[VEC];
-    gat_online<VEC>(col, el, x, er_i, d.slope, H, K, h, kk, beg, end, m, dsum, acc);
+    gat_online<VEC, DROP>(col, el, x, er_i, d.slope, H, K, h, kk, beg, end, d, rng, m, dsum, acc);
     const float inv = __fadd_rn(dsum, 1e-16f);  // softmax.py:35: exp / (sum + 1e-16)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = __fdiv_rn(acc[i], inv);
@@ -224,9 +248,11 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(
     const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ er,
     const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ out,
     const float *__restrict__ rowmax, const float *__restrict__ rowden, float *__restrict__ alpha,
-    float *__restrict__ de, float *__restrict__ ger, float *__restrict__ pger, const GatDims d) {
+    float *__restrict__ de, float *__restrict__ ger, float *__restrict__ pger,
+    const int64_t *__restrict__ rng, const GatDims d) {
   const int64_t H = d.H, K = d.K;
   const int64_t C = CREG > 0 ? (int64_t)CREG : d.C;
+  const uint64_t seed = d.drop_thresh ? (uint64_t)rng[0] : 0, offset = d.drop_thresh ? (uint64_t)rng[1] : 0;
   const int LG = 1 << d.logL;
   const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> d.logL;
   const int li = threadIdx.x & (LG - 1);
@@ -268,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(
     const float m = rowmax[row * H + h];
     const float inv = __fadd_rn(rowden[row * H + h], 1e-16f);
     float gsum = 0.0f;
-    auto edge = [&](int64_t p, int64_t src, float elv, const float *__restrict__ xj) {
+    auto edge = [&](int64_t p, uint32_t word, float elv, const float *__restrict__ xj) {
       const float raw = __fadd_rn(elv, er_i);
       const float al = __fdiv_rn(GGL_EXPF(__fadd_rn(lrelu(raw, d.slope), -m)), inv);
       float da = 0.0f;
@@ -289,28 +315,39 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(
           for (int q = 0; q < VEC; ++q) da = __fadd_rn(da, __fmul_rn(gv[q], xv[q]));
         }
       }
+      float alk = al;  // the weight the edge carried forward: alpha, or keep * alpha / (1 - p)
+      if (d.drop_thresh) {  // same draw as the forward (same seed, offset, index)
+        const bool keep = word >= d.drop_thresh;
+        alk = keep ? __fmul_rn(al, d.drop_scale) : 0.0f;
+        da = keep ? __fmul_rn(da, d.drop_scale) : 0.0f;  // d out / d alpha_p = keep/(1-p) <g_i, x_j>
+      }
       const float ds = __fmul_rn(al, __fadd_rn(da, -dot));
       const float dv = raw > 0.0f ? ds : __fmul_rn(ds, d.slope);
-      alpha[(p * H + h) * d.es] = al;
+      alpha[(p * H + h) * d.es] = alk;
       de[(p * H + h) * d.es] = dv;
       gsum = __fadd_rn(gsum, dv);
-      (void)src;
+    };
+    auto single = [&](int64_t q) {
+      const int64_t s0 = col[q];
+      edge(q, d.drop_thresh ? drop_word(q, H, h, offset, seed) : 0u, el[s0 * H + h], x + s0 * K + h * C);
     };
     int64_t p = beg;
+    if (d.drop_thresh) {
+      for (; p < end && (p & 3) != 0; ++p) single(p);
+    }
     for (; p + 4 <= end; p += 4) {
       int64_t sj[4];
       float ev[4];
+      U4 rw{0u, 0u, 0u, 0u};
+      if (d.drop_thresh) rw = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
 #pragma unroll
       for (int u = 0; u < 4; ++u) sj[u] = col[p + u];
 #pragma unroll
       for (int u = 0; u < 4; ++u) ev[u] = el[sj[u] * H + h];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) edge(p + u, sj[u], ev[u], x + sj[u] * K + h * C);
+      for (int u = 0; u < 4; ++u) edge(p + u, pick_word(rw, u), ev[u], x + sj[u] * K + h * C);
     }
-    for (; p < end; ++p) {
-      const int64_t s0 = col[p];
-      edge(p, s0, el[s0 * H + h], x + s0 * K + h * C);
-    }
+    for (; p < end; ++p) single(p);
     if (is_chunk) pger[item * H + h] = gsum;
     else ger[row * H + h] = gsum;
   }
@@ -468,9 +505,18 @@ extern "C" size_t ggl_gat_partial_bytes(int64_t n_chunks, int64_t H, int64_t C) 
   return (size_t)n_chunks * (size_t)(H * C + 2 * H) * sizeof(float) + 64;
 }
 
+static int set_dropout(GatDims &d, float p_drop, const int64_t *rng) {
+  GGL_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, GGL_EINVAL, "p_drop must be in [0, 1)");
+  GGL_REQUIRE(p_drop == 0.0f || rng, GGL_EINVAL, "attention dropout needs an rng_state");
+  d.drop_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  d.drop_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  return GGL_OK;
+}
+
 extern "C" int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
                                  const float *er, const float *x, float slope, int64_t H, int64_t C,
-                                 float *out, float *rowmax, float *rowden, void *stream) {
+                                 float p_drop, int64_t *rng_state, float *out, float *rowmax,
+                                 float *rowden, void *stream) {
   GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
   GGL_REQUIRE(H > 0 && C > 0 && plan->chunk > 0, GGL_EINVAL, "H, C and chunk must be positive");
   const int64_t N = plan->N;
@@ -480,6 +526,8 @@ extern "C" int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, 
   GatDims d{};
   d.slope = slope; d.N = N; d.H = H; d.C = C; d.K = H * C; d.E = plan->E;
   d.chunk = plan->chunk; d.n_long = plan->n_long; d.n_chunks = plan->n_chunks;
+  int rcd = set_dropout(d, p_drop, rng_state);
+  if (rcd) return rcd;
   float *pacc = nullptr, *pm = nullptr, *pd = nullptr;
   if (plan->n_long > 0) {
     GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
@@ -499,18 +547,21 @@ extern "C" int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, 
   GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
   const int32_t *order = options().row_order ? plan->row_order : nullptr;
   hipStream_t s = as_stream(stream);
-  if (vec4)
-    GGL_LAUNCH((gat_fwd_kernel<4>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
-               plan->chunk_ptr, el, er, x, out, rowmax, rowden, pacc, pm, pd, d);
-  else
-    GGL_LAUNCH((gat_fwd_kernel<1>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
-               plan->chunk_ptr, el, er, x, out, rowmax, rowden, pacc, pm, pd, d);
+#define GGL_GAT_FWD(V, DR)                                                                              \
+  GGL_LAUNCH((gat_fwd_kernel<V, DR>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,       \
+             plan->chunk_ptr, el, er, x, out, rowmax, rowden, pacc, pm, pd, (const int64_t *)rng_state, d)
+  if (vec4 && d.drop_thresh) GGL_GAT_FWD(4, true);
+  else if (vec4) GGL_GAT_FWD(4, false);
+  else if (d.drop_thresh) GGL_GAT_FWD(1, true);
+  else GGL_GAT_FWD(1, false);
+#undef GGL_GAT_FWD
   GGL_LAUNCH_CHECK();
   if (plan->n_long > 0) {
     GGL_LAUNCH((gat_long_final_kernel), plan->n_long, kBlock, s, plan->long_rows, plan->chunk_ptr,
                (const float *)pacc, (const float *)pm, (const float *)pd, out, rowmax, rowden, d);
     GGL_LAUNCH_CHECK();
   }
+  if (d.drop_thresh) return rng_advance(rng_state, stream);  // the next call draws a new mask
   return GGL_OK;
 }
 
@@ -518,8 +569,8 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
                                      const int32_t *rowidx, const float *el, const float *er,
                                      const float *x, const float *g, const float *out,
                                      const float *rowmax, const float *rowden, float slope, int64_t H,
-                                     int64_t C, float *alpha, float *de, float *ger, float *dot_ws,
-                                     void *stream) {
+                                     int64_t C, float p_drop, const int64_t *rng_used, float *alpha,
+                                     float *de, float *ger, float *dot_ws, void *stream) {
   (void)rowidx; (void)dot_ws;  // needed by the first (edge-parallel) version; accepted, unused
   GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
   GGL_REQUIRE(H > 0 && C > 0 && plan->chunk > 0, GGL_EINVAL, "H, C and chunk must be positive");
@@ -531,6 +582,8 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
   d.slope = slope; d.N = N; d.H = H; d.C = C; d.K = H * C; d.E = E;
   d.es = (de == alpha + 1) ? 2 : 1;  // de == alpha + 1: one interleaved [E,H,2] buffer
   d.chunk = plan->chunk; d.n_long = plan->n_long; d.n_chunks = plan->n_long > 0 ? plan->n_chunks : 0;
+  int rcd = set_dropout(d, p_drop, rng_used);
+  if (rcd) return rcd;
   float *pger = nullptr;
   if (plan->n_long > 0) {
     GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
@@ -547,7 +600,7 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
                     ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) && !options().force_generic;
 #define GGL_GAT_DST(V, CR)                                                                              \
   GGL_LAUNCH((gat_bwd_dst_kernel<V, CR>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,    \
-             plan->chunk_ptr, el, er, x, g, out, rowmax, rowden, alpha, de, ger, pger, d)
+             plan->chunk_ptr, el, er, x, g, out, rowmax, rowden, alpha, de, ger, pger, rng_used, d)
   if (vec4 && C == 8) GGL_GAT_DST(4, 8);
   else if (vec4 && C == 16) GGL_GAT_DST(4, 16);
   else if (vec4) GGL_GAT_DST(4, 0);

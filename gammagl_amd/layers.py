@@ -181,10 +181,13 @@ class SAGEConv(MessagePassing):
 
 
 class GATConv(MessagePassing):
-    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, add_bias=True):
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, dropout_rate=0.,
+                 add_bias=True):
         super().__init__()
         self.heads, self.out_channels, self.concat = heads, out_channels, concat
         self.negative_slope = negative_slope
+        self.dropout_rate = dropout_rate
+        self.dropout = nn.Dropout(dropout_rate)   # on the attention coefficients (gat_conv.py:90,104)
         self.w = nn.Parameter(torch.empty(in_channels, out_channels * heads))
         self.att = nn.Parameter(torch.empty(1, heads, out_channels * 2))
         nn.init.trunc_normal_(self.w, std=0.05)
@@ -205,7 +208,7 @@ class GATConv(MessagePassing):
         feat = torch.cat((x[node_src], x[node_dst]), dim=-1)
         e = (feat * self.att).sum(dim=-1)
         e = torch.nn.functional.leaky_relu(e, self.negative_slope)
-        alpha = segment_softmax(e, node_dst, num_nodes)
+        alpha = self.dropout(segment_softmax(e, node_dst, num_nodes))
         x = self.propagate(x, edge_index, num_nodes=num_nodes, edge_weight=alpha)
         return self._finish(x)
 
@@ -218,7 +221,8 @@ class FusedGATConv(GATConv):
         C = self.out_channels
         el = (x * self.att[:, :, :C]).sum(dim=-1)   # source term  a_src . x_j
         er = (x * self.att[:, :, C:]).sum(dim=-1)   # destination term a_dst . x_i
-        x = _engine().gat_fused(edge_index, el, er, x, self.negative_slope, num_nodes=num_nodes)
+        x = _engine().gat_fused(edge_index, el, er, x, self.negative_slope, num_nodes=num_nodes,
+                                dropout_rate=self.dropout_rate, training=self.training)
         return self._finish(x)
 
 

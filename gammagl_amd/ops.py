@@ -588,7 +588,7 @@ class Engine:
             """edge-softmax + aggregate in one kernel (gat_conv.py:103-112 + softmax.py:29-35)."""
 
             @staticmethod
-            def forward(ctx, gp, el, er, x, slope):
+            def forward(ctx, gp, el, er, x, slope, p_drop=0.0):
                 dev = x.device
                 N, H, C = gp.N_dst, int(x.shape[1]), int(x.shape[2])
                 out = torch.empty((N, H, C), dtype=torch.float32, device=dev)
@@ -599,10 +599,14 @@ class Engine:
                     part = torch.empty(eng.lib.ggl_gat_partial_bytes(gp.fwd.n_chunks, H, C) + 16,
                                        dtype=torch.uint8, device=dev)
                 cs = gp.fwd.c_struct(part)
+                rng = rng_used = None
+                if p_drop > 0:
+                    rng = eng._rng_state(dev)
+                    rng_used = rng.clone()  # the {seed, offset} this launch reads; the backward redraws the mask
                 eng._check(eng.lib.ggl_gat_fused_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er),
-                                                     _ptr(x), float(slope), H, C, _ptr(out),
-                                                     _ptr(rmax), _ptr(rden), eng._stream(dev)))
-                ctx.gp, ctx.slope = gp, float(slope)
+                                                     _ptr(x), float(slope), H, C, float(p_drop), _ptr(rng),
+                                                     _ptr(out), _ptr(rmax), _ptr(rden), eng._stream(dev)))
+                ctx.gp, ctx.slope, ctx.p_drop, ctx.rng_used = gp, float(slope), float(p_drop), rng_used
                 ctx.save_for_backward(el, er, x, out, rmax, rden)
                 return out
 
@@ -622,8 +626,8 @@ class Engine:
                 cs = gp.fwd.c_struct(part_f)
                 eng._check(eng.lib.ggl_gat_fused_bwd_dst(
                     ctypes.byref(cs), _ptr(gp.col), None, _ptr(el), _ptr(er), _ptr(x),
-                    _ptr(g), _ptr(out), _ptr(rmax), _ptr(rden), ctx.slope, H, C, alpha, de,
-                    _ptr(ger), None, st))
+                    _ptr(g), _ptr(out), _ptr(rmax), _ptr(rden), ctx.slope, H, C, ctx.p_drop,
+                    _ptr(ctx.rng_used), alpha, de, _ptr(ger), None, st))
                 bwd = gp.bwd
                 gx = torch.empty((gp.N_src, H, C), dtype=torch.float32, device=dev)
                 gel = torch.empty((gp.N_src, H), dtype=torch.float32, device=dev)
@@ -632,7 +636,7 @@ class Engine:
                 eng._check(eng.lib.ggl_gat_fused_bwd_src(ctypes.byref(csT), _ptr(gp.colT), _ptr(gp.posT),
                                                          alpha, de, _ptr(g), H, C,
                                                          _ptr(gx), _ptr(gel), st))
-                return None, gel, ger, gx, None
+                return None, gel, ger, gx, None, None
 
         class BiasAdd(torch.autograd.Function):
             """out = x + bias (bias broadcast over rows); d bias = column sums of the gradient."""
@@ -779,15 +783,19 @@ class Engine:
             raise RuntimeError("bspmm expects weight of shape [num_edges, heads]")
         return self.BSpMMSum.apply(gp, weight, x)
 
-    def gat_fused(self, index, el, er, x, negative_slope=0.2, num_nodes=None):
-        """out[i,h,:] = sum_{j->i} softmax_i(LeakyReLU(el[j,h] + er[i,h])) * x[j,h,:]."""
+    def gat_fused(self, index, el, er, x, negative_slope=0.2, num_nodes=None, dropout_rate=0.0, training=True):
+        """out[i,h,:] = sum_{j->i} dropout(softmax_i(LeakyReLU(el[j,h] + er[i,h]))) * x[j,h,:]
+        (dropout on the attention coefficients as gat_conv.py:104 / GATConvFuse(..., dropout_rate))."""
         self._dev(index, el, er, x)
         for n, t in (("el", el), ("er", er), ("x", x)):
             self._check_f32(n, t)
         n = x.shape[0] if num_nodes is None else num_nodes
         gp = index if isinstance(index, GraphPlan) else self.graph_plan(index, n, x.shape[0])
+        p = float(dropout_rate) if training else 0.0
+        if not 0.0 <= p < 1.0:
+            raise ValueError("dropout_rate must be in [0, 1)")
         return self.GATFused.apply(gp, el.contiguous(), er.contiguous(), x.contiguous(),
-                                   negative_slope)
+                                   negative_slope, p)
 
     # rectangular / explicit-plan variants used by the harness and the multi-GPU layer
     def spmm(self, gp, weight, x, reduce="sum"):

@@ -11,7 +11,7 @@ points (+ the fused GAT op and the fused epilogue) are dispatcher ops:
     torch.ops.gammagl_amd.spmm_mean(index, weight, x)     -> Tensor          c_spmm_mean
     torch.ops.gammagl_amd.spmm_max(index, weight, x)      -> Tensor          c_spmm_max
     torch.ops.gammagl_amd.bspmm_sum(index, weight, x)     -> Tensor          c_bspmm_sum
-    torch.ops.gammagl_amd.gat_fused(index, el, er, x, negative_slope, num_nodes) -> Tensor
+    torch.ops.gammagl_amd.gat_fused(index, el, er, x, negative_slope, num_nodes, dropout_rate) -> Tensor
     torch.ops.gammagl_amd.bias_act(a, bias, relu, p_drop) -> Tensor
 
 Kernels are registered for the ``CUDA`` (= HIP on ROCm) and ``AutogradCUDA`` dispatch keys only: a CPU
@@ -35,7 +35,7 @@ _SCHEMAS = {
     "spmm_max": "(Tensor index, Tensor? weight, Tensor x) -> Tensor",
     "bspmm_sum": "(Tensor index, Tensor weight, Tensor x) -> Tensor",
     "gat_fused": "(Tensor index, Tensor el, Tensor er, Tensor x, float negative_slope=0.2, "
-                 "int? num_nodes=None) -> Tensor",
+                 "int? num_nodes=None, float dropout_rate=0.0) -> Tensor",
     "bias_act": "(Tensor a, Tensor? bias, bool relu, float p_drop) -> Tensor",
 }
 
@@ -55,8 +55,8 @@ def _kernels(get_engine):
         "spmm_mean": lambda index, weight, x: get_engine().c_spmm_mean(index, weight, x),
         "spmm_max": lambda index, weight, x: get_engine().c_spmm_max(index, weight, x),
         "bspmm_sum": lambda index, weight, x: get_engine().c_bspmm_sum(index, weight, x),
-        "gat_fused": lambda index, el, er, x, negative_slope=0.2, num_nodes=None:
-            get_engine().gat_fused(index, el, er, x, negative_slope, num_nodes),
+        "gat_fused": lambda index, el, er, x, negative_slope=0.2, num_nodes=None, dropout_rate=0.0:
+            get_engine().gat_fused(index, el, er, x, negative_slope, num_nodes, dropout_rate, True),
         "bias_act": lambda a, bias, relu, p_drop: get_engine().bias_act(a, bias, relu, p_drop, True),
     }
 
@@ -89,7 +89,7 @@ def _register_fakes():
     def like_x(index, weight, x):
         return torch.empty_like(x)  # gspmm.cpp:16 — out = zeros_like(x): square
 
-    def gat(index, el, er, x, negative_slope=0.2, num_nodes=None):
+    def gat(index, el, er, x, negative_slope=0.2, num_nodes=None, dropout_rate=0.0):
         n = x.shape[0] if num_nodes is None else num_nodes
         return x.new_empty((n,) + tuple(x.shape[1:]))
 

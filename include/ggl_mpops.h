@@ -256,9 +256,15 @@ int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int r
  *       gel[j,h] = sum_p de, reading alpha/de through posT (transposed position -> forward position);
  *       planT->partial = ggl_partial_bytes(GGL_F32, n_chunks, H*C + H, 0) bytes when it has long rows
  * ---------------------------------------------------------------------------------------------- */
+/* p_drop > 0: attention dropout (gat_conv.py:104 `dropout(segment_softmax(.))`, GATConvFuse's last
+ * argument): edge (p, h) is kept when word p & 3 of Philox4x32-10(rng_state; (p >> 2) * H + h) >= p_drop * 2^32
+ * and then weighs
+ * alpha / (1 - p_drop); the softmax itself runs over all edges.  rng_state = device int64 {seed, offset},
+ * offset advanced after the launch; the backward needs the values the forward READ (rng_used). */
 int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
                       const float *er, const float *x, float slope, int64_t H, int64_t C,
-                      float *out, float *rowmax, float *rowden, void *stream);
+                      float p_drop, int64_t *rng_state, float *out, float *rowmax, float *rowden,
+                      void *stream);
 /* plan->partial for ggl_gat_fused_fwd when the plan has long rows (chunk-local softmax partials) */
 size_t ggl_gat_partial_bytes(int64_t n_chunks, int64_t H, int64_t C);
 /* alpha / de: two [E,H] f32 arrays, or ONE interleaved [E,H,2] buffer passed as (base, base + 1) — then
@@ -268,8 +274,8 @@ size_t ggl_gat_partial_bytes(int64_t n_chunks, int64_t H, int64_t C);
 int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *col, const int32_t *rowidx,
                           const float *el, const float *er, const float *x, const float *g,
                           const float *out, const float *rowmax, const float *rowden, float slope,
-                          int64_t H, int64_t C, float *alpha, float *de, float *ger, float *dot_ws,
-                          void *stream);
+                          int64_t H, int64_t C, float p_drop, const int64_t *rng_used, float *alpha,
+                          float *de, float *ger, float *dot_ws, void *stream);
 int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *colT, const int32_t *posT,
                           const float *alpha, const float *de, const float *g, int64_t H,
                           int64_t C, float *gx, float *gel, void *stream);

@@ -347,15 +347,15 @@ def _check_gat_separate_buffers(eng, dev, index, N, H, C, rng):
     cs = gp.fwd.c_struct(part)
     eld, erd, xd = el.detach(), er.detach(), x.detach()
     eng._check(eng.lib.ggl_gat_fused_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(eld), _ptr(erd), _ptr(xd), 0.2, H, C,
-                                         _ptr(out), _ptr(rmax), _ptr(rden), st))
+                                         0.0, None, _ptr(out), _ptr(rmax), _ptr(rden), st))
     alpha = torch.empty((max(E, 1), H), dtype=torch.float32, device=dev)
     de = torch.empty((max(E, 1), H), dtype=torch.float32, device=dev)
     ger = torch.empty((N, H), dtype=torch.float32, device=dev)
     pf = eng._partial(gp.fwd, torch.float32, H, False, dev)
     cs = gp.fwd.c_struct(pf)
     eng._check(eng.lib.ggl_gat_fused_bwd_dst(ctypes.byref(cs), _ptr(gp.col), None, _ptr(eld), _ptr(erd), _ptr(xd),
-                                             _ptr(go), _ptr(out), _ptr(rmax), _ptr(rden), 0.2, H, C, _ptr(alpha),
-                                             _ptr(de), _ptr(ger), None, st))
+                                             _ptr(go), _ptr(out), _ptr(rmax), _ptr(rden), 0.2, H, C, 0.0, None,
+                                             _ptr(alpha), _ptr(de), _ptr(ger), None, st))
     gx = torch.empty((N, H, C), dtype=torch.float32, device=dev)
     gel = torch.empty((N, H), dtype=torch.float32, device=dev)
     pb = eng._partial(gp.bwd, torch.float32, H * C + H, False, dev)
@@ -364,6 +364,85 @@ def _check_gat_separate_buffers(eng, dev, index, N, H, C, rng):
                                              _ptr(go), H, C, _ptr(gx), _ptr(gel), st))
     assert torch.equal(out, y.detach())
     assert torch.equal(ger, er.grad) and torch.equal(gel, el.grad) and torch.equal(gx, x.grad)
+
+
+def philox4x32_10(index, offset, seed):
+    """numpy restatement of the device generator (csrc/common.hpp): the four words of Philox4x32-10 with
+    counter (index, offset) and key seed — used to rebuild the attention-dropout mask on the host."""
+    index = np.asarray(index, dtype=np.uint64)
+    m32 = np.uint64(0xFFFFFFFF)
+    c0, c1 = index & m32, index >> np.uint64(32)
+    c2 = np.full_like(index, np.uint64(offset) & m32)
+    c3 = np.full_like(index, np.uint64(offset) >> np.uint64(32))
+    k0, k1 = np.uint64(seed) & m32, np.uint64(seed) >> np.uint64(32)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+        n1 = p1 & m32
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+        n3 = p0 & m32
+        c0, c1, c2, c3 = n0 & m32, n1, n2 & m32, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def check_gat_dropout(eng, dev, oracle):
+    """Attention dropout inside the fused op (gat_conv.py:104; GATConvFuse's dropout_rate): the mask is
+    rebuilt on the host from the RNG state the launch read, and forward + gradients are compared with the
+    in-tree math written in torch with that mask; plus keep-rate, fresh mask per call, eval mode = no-op."""
+    rng = np.random.default_rng(31)
+    old = eng.chunk
+    try:
+        for chunk, (N, E, H, C), pd in ((0, (40, 500, 4, 8), 0.4), (8, (30, 400, 8, 4), 0.25), (0, (25, 300, 3, 5), 0.6)):
+            eng.chunk = chunk
+            eng.graph_cache.clear(); eng.seg_cache.clear()
+            index = _rand_graph(rng, N, E)
+            index[1, : E // 4] = 2  # a hub row (chunked when chunk = 8)
+            it = to_t(index, dev)
+            el, er = (to_t(rng.standard_normal((N, H)).astype(np.float32), dev).requires_grad_(True) for _ in range(2))
+            x = to_t(rng.standard_normal((N, H, C)).astype(np.float32), dev).requires_grad_(True)
+            go = to_t(rng.standard_normal((N, H, C)).astype(np.float32), dev)
+            seed, offset = (int(v) for v in eng._rng_state(dev).cpu())
+            y = eng.gat_fused(it, el, er, x, 0.2, dropout_rate=pd)
+            assert int(eng._rng_state(dev)[1]) == offset + 1
+            y.backward(go)
+            # host mask per (sorted position, head) -> per original edge through the plan's permutation
+            gp = eng.graph_plan(it, N)
+            pos = np.arange(E, dtype=np.int64)
+            # word p & 3 of the draw for counter (p >> 2) * H + h  (gat.hip: drop_word)
+            words = philox4x32_10(((pos[:, None] >> 2) * H + np.arange(H)[None, :]).reshape(-1), offset, seed)
+            draw = words.reshape(E, H, 4)[pos, :, pos & 3]
+            keep_pos = draw >= np.uint32(int(pd * 4294967296.0))
+            perm = gp.fwd.perm.cpu().numpy().astype(np.int64) if gp.fwd.perm is not None else pos
+            keep = np.empty_like(keep_pos)
+            keep[perm] = keep_pos
+            mask = to_t(keep.astype(np.float32) / np.float32(1.0 - pd), dev)
+            # in-tree math in torch (gat_conv.py:103-112 + softmax.py:29-35) with that mask
+            el2, er2, x2 = (t.detach().clone().requires_grad_(True) for t in (el, er, x))
+            src, dst = it[0], it[1]
+            e = torch.nn.functional.leaky_relu(el2[src] + er2[dst], 0.2)
+            mx = torch.full((N, H), -3.4028234663852886e38, device=dev).scatter_reduce(
+                0, dst.view(-1, 1).expand(E, H), e, "amax", include_self=True)
+            ex = torch.exp(e - mx[dst])
+            den = torch.zeros(N, H, device=dev).index_add_(0, dst, ex)
+            alpha = ex / (den[dst] + 1e-16) * mask
+            ref = torch.zeros(N, H, C, device=dev).index_add_(0, dst, alpha.unsqueeze(-1) * x2[src])
+            ref.backward(go)
+            torch.testing.assert_close(y.detach(), ref.detach(), rtol=2e-5, atol=2e-6)
+            torch.testing.assert_close(x.grad, x2.grad, rtol=2e-4, atol=2e-5)
+            torch.testing.assert_close(el.grad, el2.grad, rtol=2e-4, atol=5e-5)
+            torch.testing.assert_close(er.grad, er2.grad, rtol=2e-4, atol=5e-5)
+            assert abs(float(keep_pos.mean()) - (1 - pd)) < 0.08
+            y2 = eng.gat_fused(it, el.detach(), er.detach(), x.detach(), 0.2, dropout_rate=pd)
+            assert not torch.equal(y2, y.detach()), "every call must draw a new mask"
+            y3 = eng.gat_fused(it, el.detach(), er.detach(), x.detach(), 0.2, dropout_rate=pd, training=False)
+            np.testing.assert_allclose(to_np(y3), oracle.gat_fwd(index, to_np(el.detach()), to_np(er.detach()),
+                                                                to_np(x.detach()), 0.2), rtol=2e-5, atol=2e-6)
+    finally:
+        eng.chunk = old
+        eng.graph_cache.clear(); eng.seg_cache.clear()
 
 
 def check_gat_random(eng, dev, oracle):

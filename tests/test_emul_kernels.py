@@ -63,6 +63,10 @@ def test_gat_fused_random(eng, oracle):
     pc.check_gat_random(eng, DEV, oracle)
 
 
+def test_gat_attention_dropout(eng, oracle):
+    pc.check_gat_dropout(eng, DEV, oracle)
+
+
 def test_edge_cases_and_errors(eng, oracle):
     pc.check_edge_cases(eng, DEV, oracle)
 

@@ -79,6 +79,10 @@ def test_gat_fused_random(eng, dev, oracle):
     pc.check_gat_random(eng, dev, oracle)
 
 
+def test_gat_attention_dropout(eng, dev, oracle):
+    pc.check_gat_dropout(eng, dev, oracle)
+
+
 def test_edge_cases_and_errors(eng, dev, oracle):
     pc.check_edge_cases(eng, dev, oracle)
 
