@@ -189,31 +189,36 @@ class _LinearSideWgrad(torch.autograd.Function):
     It is parked in ``sink`` and installed by ``DistGCN.join()`` after the streams are joined."""
 
     @staticmethod
-    def forward(ctx, x, w, side, sink):
+    def forward(ctx, x, w, side, sink, pad_out=0):
+        """`pad_out` extra all-zero output columns (class counts like 47 -> 48: 16-byte rows for the float4
+        aggregate, produced here for free instead of by a padded copy of the [N, 47] result)."""
         ctx.save_for_backward(x, w)
-        ctx.side, ctx.sink = side, sink
-        return x @ w.t()
+        ctx.side, ctx.sink, ctx.pad_out = side, sink, int(pad_out)
+        wt = w.t() if not pad_out else F.pad(w, (0, 0, 0, int(pad_out))).t()
+        return x @ wt
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        side = ctx.side
-        gx = g @ w if ctx.needs_input_grad[0] else None
+        side, n_out = ctx.side, w.shape[0]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = g @ (w if not ctx.pad_out else F.pad(w, (0, 0, 0, ctx.pad_out)))
         gw = None
         if ctx.needs_input_grad[1]:
             g = g.contiguous()
             if side is None or not g.is_cuda:
-                gw = wgrad(g, x)
+                gw = wgrad(g, x)[:n_out]
             else:
                 cur = torch.cuda.current_stream(g.device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    gws = wgrad(g, x)
+                    gws = wgrad(g, x)[:n_out]
                 g.record_stream(side)
                 x.record_stream(side)
                 gws.record_stream(cur)  # consumed on the main stream after join()
                 ctx.sink.append((w, gws))
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
 class DistGCN(torch.nn.Module):
@@ -250,16 +255,20 @@ class DistGCN(torch.nn.Module):
             self.side = torch.cuda.Stream(device=x.device)
         for i in range(n):
             hidden = i < n - 1
-            h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink)
+            n_out = self.lin[i].weight.shape[0]
+            pad = (-n_out) % 4 if n_out >= 8 else 0   # e.g. 47 classes -> 48 columns, dropped at the end
+            h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink, pad)
+            bias = self.bias[i] if not pad else F.pad(self.bias[i], (0, pad))
             p = self.dropout.p if hidden else 0.0
             if not pg.comm and h.shape[1] % 4 == 0:
                 # no halo to add afterwards: + bias, ReLU and dropout ride on the SpMM's only store
-                x = pg.eng.spmm_bias_act(pg.gp_loc, pg.w_loc, h, self.bias[i], relu=hidden, p_drop=p,
+                x = pg.eng.spmm_bias_act(pg.gp_loc, pg.w_loc, h, bias, relu=hidden, p_drop=p,
                                          training=self.training)
             else:
                 # + bias, ReLU and dropout of the hidden layers fused into one pass each way (epilogue.hip)
-                x = pg.eng.bias_act(pg.aggregate(h), self.bias[i], relu=hidden, p_drop=p,
-                                    training=self.training)
+                x = pg.eng.bias_act(pg.aggregate(h), bias, relu=hidden, p_drop=p, training=self.training)
+            if pad:
+                x = x[:, :n_out]
         return x
 
 

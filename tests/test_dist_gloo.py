@@ -126,6 +126,41 @@ def test_balanced_bounds_and_world1():
     torch.testing.assert_close(pg.aggregate(h), eng.c_spmm_sum(ei, w, h))
 
 
+def test_distgcn_matches_plain_composition_with_padded_classes():
+    """DistGCN (fused epilogue, class columns padded 10 -> 12 inside the last GEMM, side-stream weight
+    gradients off on CPU) == Linear -> spmm -> + bias -> ReLU written out in torch, forward and gradients."""
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    eng = _emul_engine()
+    from gammagl_amd.dist import DistGCN, PartitionedGraph
+
+    N, F, Hd, _, ei, x, y, train = _problem(3)
+    C = 10
+    w = torch.rand(ei.shape[1], generator=torch.Generator().manual_seed(1)) + 0.1
+    pg = PartitionedGraph(ei, w, N, 0, 1, eng=eng)
+    torch.manual_seed(0)
+    net = DistGCN(F, Hd, C, num_layers=3, drop_rate=0.0)
+    for b in net.bias:
+        torch.nn.init.normal_(b)
+    out = net(x, pg)
+    assert out.shape == (N, C)
+    go = torch.randn(N, C, generator=torch.Generator().manual_seed(2))
+    out.backward(go)
+    net.join()
+    got = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    gp = eng.graph_plan(ei, N)
+    h = x
+    for i in range(3):
+        h = eng.spmm(gp, w, h @ net.lin[i].weight.t()) + net.bias[i]
+        if i < 2:
+            h = torch.relu(h)
+    torch.testing.assert_close(out.detach(), h.detach(), rtol=1e-5, atol=1e-5)
+    h.backward(go)
+    for a, p in zip(got, net.parameters()):
+        torch.testing.assert_close(a, p.grad, rtol=1e-4, atol=1e-5)
+
+
 def _bench_worker(rank, world, port, tmp):
     import json
     import types
