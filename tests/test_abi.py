@@ -1,0 +1,75 @@
+"""The drop-in boundary without a GPU: libggl_mpops_hip.so loads, exports every function
+include/ggl_mpops.h declares, reports the header's ABI version, and the ctypes prototypes in
+gammagl_amd/_lib.py have the declared number of parameters (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+HEADER = os.path.join(REPO, "include", "ggl_mpops.h")
+LIB = os.path.join(REPO, "gammagl_amd", "lib", "libggl_mpops_hip.so")
+
+
+def declared_functions():
+    """name -> number of parameters, for every prototype in the header."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|size_t|int64_t|const\s+char\s*\*)\s*(ggl_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        protos[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos
+
+
+def header_abi_version():
+    return int(re.search(r"#define\s+GGL_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+
+
+def test_header_declares_the_path():
+    fns = declared_functions()
+    for must in ("ggl_plan_build", "ggl_segment_sum", "ggl_segment_mean", "ggl_segment_max", "ggl_spmm_sum",
+                 "ggl_spmm_mean", "ggl_spmm_max", "ggl_bspmm_sum", "ggl_gat_fused_fwd", "ggl_gat_fused_bwd_dst",
+                 "ggl_gat_fused_bwd_src", "ggl_spmm_sum_bias_act", "ggl_abi_version", "ggl_last_error"):
+        assert must in fns, must
+    assert len(fns) >= 40
+
+
+def test_hip_library_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "gammagl_amd", "csrc"), "-s"])
+    lib = ctypes.CDLL(LIB)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.ggl_abi_version.restype = ctypes.c_int
+    assert lib.ggl_abi_version() == header_abi_version()
+
+
+def test_ctypes_prototypes_match_the_header():
+    from gammagl_amd import _lib
+
+    fns = declared_functions()
+    assert _lib.ABI_VERSION == header_abi_version()
+    unbound = sorted(set(fns) - set(_lib.SIGNATURES))
+    undeclared = sorted(set(_lib.SIGNATURES) - set(fns))
+    assert not unbound and not undeclared, (unbound, undeclared)
+    wrong = {n: (len(_lib.SIGNATURES[n][1]), fns[n]) for n in fns if len(_lib.SIGNATURES[n][1]) != fns[n]}
+    assert not wrong, f"(ctypes, header) parameter counts differ: {wrong}"
+
+
+def test_host_emulation_build_has_the_same_surface():
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    lib = ctypes.CDLL(os.path.join(HERE, "emul", "libggl_emul.so"))
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    from gammagl_amd import _lib
+
+    with pytest.raises((ImportError, OSError)):
+        _lib.bind(str(tmp_path / "libggl_mpops_hip.so"))
