@@ -56,6 +56,8 @@ SIGNATURES = {
     "ggl_segment_mean_bwd": (c_int, [c_int, _V, _V, _V, c_int64, c_int64, _V, _V]),
     "ggl_segment_max_bwd": (c_int, [c_int, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
     "ggl_spmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V]),
+    "ggl_spmm_sum_ex": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, c_int64, c_int, _V]),
+    "ggl_segment_sum_ex": (c_int, [c_int, _V, c_int64, _P, c_int64, _V, c_int64, c_int, _V]),
     "ggl_spmm_sum_bias_act": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, c_int, c_float, _V, _V, _V]),
     "ggl_spmm_mean": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V]),
     "ggl_spmm_max": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V, _V]),

@@ -59,6 +59,10 @@ struct ReduceDims {
   int w_by_pos;
   // MODE_SPMM_EPI: same mask as ggl_bias_act_fwd draws for the same (rng state, N, K) — Philox word of
   // vector (row, k / epi_vec), component k % epi_vec
+  // row strides (elements) of x and out, and out += instead of out = : lets a caller aggregate a column
+  // block of a wider matrix in place and add a second edge set (halo sources) onto an existing result
+  int64_t x_ld, out_ld;
+  int accumulate;
   int epi_relu;
   int epi_vec;
   uint32_t epi_thresh;
@@ -191,7 +195,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
 #pragma unroll
     for (int u = 0; u < U; ++u) element(p + u, xrow[u], wv[u], who[u]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) VecIO<S, VEC>::load(q.x + xrow[u] * K + kk, raw[u]);
+    for (int u = 0; u < U; ++u) VecIO<S, VEC>::load(q.x + xrow[u] * d.x_ld + kk, raw[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) accumulate(raw[u], xrow[u], wv[u], who[u]);
   }
@@ -200,7 +204,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
     float wv;
     S raw[VEC];
     element(p, xrow, wv, who);
-    VecIO<S, VEC>::load(q.x + xrow * K + kk, raw);
+    VecIO<S, VEC>::load(q.x + xrow * d.x_ld + kk, raw);
     accumulate(raw, xrow, wv, who);
   }
 }
@@ -212,6 +216,18 @@ __device__ __forceinline__ void init_acc(typename TT<T>::A (&acc)[VEC], int64_t 
   for (int i = 0; i < VEC; ++i) {
     acc[i] = (OP == OP_MAX) ? TT<T>::lowest() : TT<T>::zero();
     arg[i] = arg_fill;
+  }
+}
+
+// accumulate mode: the row starts from what `out` already holds (sum only)
+template <typename T, int VEC, int OP>
+__device__ __forceinline__ void seed_acc(const ReduceDims &d, const typename TT<T>::S *__restrict__ out,
+                                         int64_t row, int64_t kk, typename TT<T>::A (&acc)[VEC]) {
+  if (OP == OP_SUM && d.accumulate) {
+    typename TT<T>::S o[VEC];
+    VecIO<typename TT<T>::S, VEC>::load(out + row * d.out_ld + kk, o);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = TT<T>::load(o[i]);
   }
 }
 
@@ -259,7 +275,7 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
   S o[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
-  VecIO<S, VEC>::store(out + row * K + kk, o);
+  VecIO<S, VEC>::store(out + row * d.out_ld + kk, o);
   if (OP == OP_MAX) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) argout[row * K + kk + i] = arg[i];
@@ -348,6 +364,7 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
     A acc[VEC];
     int64_t arg[VEC];
     init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
+    seed_acc<T, VEC, OP>(d, out, row, kk, acc);
     reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
     finish_row<T, VEC, OP, MODE>(q, d, out, argout, d.K, row, len, kk, acc, arg);
   }
@@ -376,6 +393,7 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
     A acc[1];
     int64_t arg[1];
     init_acc<T, 1, OP>(acc, arg, d.arg_fill);
+    seed_acc<T, 1, OP>(d, out, row, k, acc);
     for (int64_t c = c0; c < c1; ++c) {
       const A v = TT<T>::load(partial[c * d.K + k]);
       if (OP == OP_MAX) {
@@ -413,6 +431,8 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   int64_t n_long, n_chunks;
   void *partial;
   int64_t *partial_arg;
+  int64_t x_ld, out_ld;    // 0 = dense (K)
+  int accumulate;
   const float *epi_bias;   // MODE_SPMM_EPI
   const int64_t *epi_rng;
   int epi_relu;
@@ -477,6 +497,7 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   ReduceDims d{};
   d.N = a.N; d.K = a.K; d.E = a.E; d.arg_fill = a.arg_fill; d.chunk = a.chunk; d.H = a.H; d.C = a.C;
   d.n_long = a.n_long; d.n_chunks = a.n_chunks; d.w_by_pos = a.w_by_pos;
+  d.x_ld = a.x_ld > 0 ? a.x_ld : a.K; d.out_ld = a.out_ld > 0 ? a.out_ld : a.K; d.accumulate = a.accumulate;
   d.epi_relu = a.epi_relu; d.epi_thresh = a.epi_thresh; d.epi_scale = a.epi_scale;
   d.epi_vec = (a.K % 4 == 0) ? 4 : 1;
   const int64_t kv = ceil_div(a.K, VEC);
@@ -506,7 +527,7 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
   constexpr bool kStatic = (MODE == MODE_SEG || spmm_like(MODE));
   const bool vec4 = !options().force_generic && (a.K % 4 == 0) && aligned16(a.x) &&
                     aligned16(a.out) && (!a.partial || aligned16(a.partial)) &&
-                    (MODE != MODE_BSPMM || a.C % 4 == 0);
+                    (a.x_ld % 4 == 0) && (a.out_ld % 4 == 0) && (MODE != MODE_BSPMM || a.C % 4 == 0);
   if (vec4) return launch_typed<float, 4, OP, MODE, kStatic>(a, stream);
   return launch_typed<float, 1, OP, MODE, kStatic>(a, stream);
 }
@@ -514,7 +535,7 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
 // 16-byte vector path usable: K a multiple of the vector width and every base pointer 16-byte aligned
 static bool wide_ok(const ReduceArgs &a, int vec) {
   return !options().force_generic && a.K % vec == 0 && aligned16(a.x) && aligned16(a.out) &&
-         (!a.partial || aligned16(a.partial));
+         (!a.partial || aligned16(a.partial)) && a.x_ld % vec == 0 && a.out_ld % vec == 0;
 }
 
 template <int OP>
@@ -592,6 +613,22 @@ extern "C" int ggl_segment_sum(int dtype, const void *x, const ggl_segplan_t *pl
   return launch_seg<OP_SUM>(dtype, a, as_stream(stream));
 }
 
+// Strided / accumulating form: x rows x_ld elements apart, out rows out_ld apart (both >= K; 0 = K), and
+// with accumulate != 0 the sums are added to what out holds (the row's previous value comes first in the
+// summation order).  Used for column blocks of a wider matrix and for adding a second edge set in place.
+extern "C" int ggl_segment_sum_ex(int dtype, const void *x, int64_t x_ld, const ggl_segplan_t *plan,
+                                  int64_t K, void *out, int64_t out_ld, int accumulate, void *stream) {
+  ReduceArgs a{};
+  int rc = fill_plan(a, plan, dtype, K, false);
+  if (rc) return rc;
+  GGL_REQUIRE((x || plan->E * K == 0) && (out || plan->N * K == 0), GGL_EINVAL, "x/out is NULL");
+  GGL_REQUIRE((x_ld == 0 || x_ld >= K) && (out_ld == 0 || out_ld >= K), GGL_EINVAL, "row stride < K");
+  a.x = x;
+  a.out = out;
+  a.x_ld = x_ld; a.out_ld = out_ld; a.accumulate = accumulate ? 1 : 0;
+  return launch_seg<OP_SUM>(dtype, a, as_stream(stream));
+}
+
 extern "C" int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K,
                                 void *out, void *stream) {
   ReduceArgs a{};
@@ -645,6 +682,17 @@ extern "C" int ggl_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const
   ReduceArgs a{};
   int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
   if (rc) return rc;
+  return launch_f32<OP_SUM, MODE_SPMM>(a, as_stream(stream));
+}
+
+extern "C" int ggl_spmm_sum_ex(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                               const float *x, int64_t x_ld, int64_t K, float *out, int64_t out_ld,
+                               int accumulate, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
+  if (rc) return rc;
+  GGL_REQUIRE((x_ld == 0 || x_ld >= K) && (out_ld == 0 || out_ld >= K), GGL_EINVAL, "row stride < K");
+  a.x_ld = x_ld; a.out_ld = out_ld; a.accumulate = accumulate ? 1 : 0;
   return launch_f32<OP_SUM, MODE_SPMM>(a, as_stream(stream));
 }
 

@@ -143,12 +143,8 @@ class _HaloAggregate(torch.autograd.Function):
         out, _ = eng._spmm_fwd("sum", pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, pg.n_local)  # overlaps the exchange
         for (c0, c1, recv, work) in works:
             work.wait()
-            if pg.n_halo > 0:
-                o2, _ = eng._spmm_fwd("sum", pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, pg.n_local)
-                if c1 - c0 == out.shape[1]:
-                    out.add_(o2)
-                else:
-                    out[:, c0:c1].add_(o2)
+            if pg.n_halo > 0:  # halo-source edges added onto the column block in place (ggl_spmm_sum_ex)
+                eng.spmm_sum_into(pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, out[:, c0:c1], accumulate=True)
         ctx.pg = pg
         return out if out.shape[1] == ctx.k_orig else out[:, :ctx.k_orig].contiguous()
 
@@ -160,22 +156,16 @@ class _HaloAggregate(torch.autograd.Function):
         works = []
         if pg.comm:
             for (c0, c1) in _HaloAggregate._chunks(g.shape[1]):
-                gc = g if c1 - c0 == g.shape[1] else g[:, c0:c1].contiguous()
-                if pg.n_halo > 0:
-                    ghalo, _ = eng._spmm_fwd("sum", pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, gc, pg.n_halo)
-                else:
-                    ghalo = torch.empty((0, c1 - c0), dtype=g.dtype, device=g.device)
+                ghalo = torch.empty((pg.n_halo, c1 - c0), dtype=g.dtype, device=g.device)
+                if pg.n_halo > 0:  # reads the column block of g in place (row stride passed down)
+                    eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g[:, c0:c1], ghalo)
                 gsend, work = pg._a2a(pg.n_send, ghalo, pg.send_splits, pg.recv_splits)  # chunk c travels while c+1 computes
                 works.append((c0, c1, gsend, work))
         gh, _ = eng._spmm_fwd("sum", pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, pg.n_local)  # overlaps
         for (c0, c1, gsend, work) in works:
             work.wait()
-            if pg.n_send > 0:
-                back, _ = eng._segment_fwd("sum", gsend, pg.send_plan)  # deterministic scatter-add
-                if c1 - c0 == gh.shape[1]:
-                    gh.add_(back)
-                else:
-                    gh[:, c0:c1].add_(back)
+            if pg.n_send > 0:  # deterministic scatter-add of the returned rows, onto the column block in place
+                eng.segment_sum_into(gsend, pg.send_plan, gh[:, c0:c1], accumulate=True)
         return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None
 
 

@@ -369,6 +369,42 @@ class Engine:
                                              E, st))
         return out, arg
 
+    @staticmethod
+    def _row_stride(t, what):
+        if t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+            raise RuntimeError(f"{what} must be a 2-D f32 matrix with unit column stride (a column block is fine)")
+        return int(t.stride(0))
+
+    def spmm_sum_into(self, plan, col, w, x, out, accumulate=False):
+        """out (+)= A x for 2-D f32 x / out that may be column blocks of wider matrices (row strides are
+        passed down: no contiguous copy, no temporary, no separate add) — ggl_spmm_sum_ex."""
+        dev = x.device
+        K = int(x.shape[1])
+        if out.shape[1] != K or out.shape[0] != plan.N:
+            raise RuntimeError("out must be [plan rows, x columns]")
+        part = self._partial(plan, torch.float32, K, False, dev)
+        cs = plan.c_struct(part)
+        w_by_pos = 0
+        if w is not None and plan.perm is not None:
+            w, w_by_pos = self._sorted_weights(plan, w)
+        self._check(self.lib.ggl_spmm_sum_ex(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
+                                             self._row_stride(x, "x"), K, _ptr(out), self._row_stride(out, "out"),
+                                             int(bool(accumulate)), self._stream(dev)))
+        return out
+
+    def segment_sum_into(self, x, plan, out, accumulate=False):
+        """out (+)= segment_sum(x) over `plan`, same strided / in-place conventions — ggl_segment_sum_ex."""
+        dev = x.device
+        K = int(x.shape[1])
+        if int(x.shape[0]) != plan.E or out.shape[1] != K or out.shape[0] != plan.N:
+            raise IndexError("segment_sum_into: shapes do not match the plan")
+        part = self._partial(plan, torch.float32, K, False, dev)
+        cs = plan.c_struct(part)
+        self._check(self.lib.ggl_segment_sum_ex(self._code(x), _ptr(x), self._row_stride(x, "x"), ctypes.byref(cs), K,
+                                                _ptr(out), self._row_stride(out, "out"), int(bool(accumulate)),
+                                                self._stream(dev)))
+        return out
+
     def _spmm_fwd(self, op, plan, col, w, x, n_out, perm_override=None, aux=None):
         """op in sum/mean/max/mean_bwd/max_bwd.  x [N_in, *]; returns out [n_out, *] (+argsrc)."""
         dev = x.device

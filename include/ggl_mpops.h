@@ -180,6 +180,16 @@ int ggl_segment_max_bwd(int dtype, const void *gout, const int64_t *arg, int64_t
  * The backward of `sum` w.r.t. x is the same call on the transposed plan (rows = source nodes,
  * col = destination nodes), which is exactly spmm_sum_cpu_backward's gx[src] += w[e] * g[dst].
  * ---------------------------------------------------------------------------------------------- */
+/* Strided / accumulating forms of ggl_spmm_sum and ggl_segment_sum: x rows x_ld elements apart, out rows
+ * out_ld apart (0 = K; >= K otherwise), and with accumulate != 0 the row sums are ADDED to what out holds
+ * (the previous value first in the summation order).  They let the multi-GPU layer aggregate a column block
+ * of a wider matrix in place and add the halo-source edges onto the local-source result without a
+ * temporary and an extra pass. */
+int ggl_spmm_sum_ex(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                    const float *x, int64_t x_ld, int64_t K, float *out, int64_t out_ld, int accumulate,
+                    void *stream);
+int ggl_segment_sum_ex(int dtype, const void *x, int64_t x_ld, const ggl_segplan_t *plan, int64_t K,
+                       void *out, int64_t out_ld, int accumulate, void *stream);
 int ggl_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
                  const float *x, int64_t K, float *out, void *stream);
 int ggl_spmm_mean(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,

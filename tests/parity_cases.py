@@ -734,6 +734,49 @@ def check_spmm_bias_act(eng, dev):
         eng.graph_cache.clear(); eng.seg_cache.clear()
 
 
+def check_strided_accumulate(eng, dev, oracle):
+    """ggl_spmm_sum_ex / ggl_segment_sum_ex: column blocks of wider matrices read and written in place
+    (row strides), and out += (accumulate) — against the dense ops on contiguous copies."""
+    g = torch.Generator(device="cpu").manual_seed(17)
+    old = eng.chunk
+    try:
+        for chunk in (0, 8):
+            eng.chunk = chunk
+            eng.graph_cache.clear(); eng.seg_cache.clear()
+            N, M, E, KW = 37, 29, 500, 24
+            ei = torch.stack([torch.randint(0, M, (E,), generator=g), torch.randint(0, N, (E,), generator=g)])
+            ei[1, :150] = 5
+            ei = ei.to(dev)
+            w = torch.rand(E, generator=g).to(dev)
+            gp = eng.graph_plan(ei, N, M)
+            xw = torch.randn(M, KW, generator=g).to(dev)
+            for (c0, c1) in ((0, 8), (8, 24), (4, 16), (0, 24)):
+                xs = xw[:, c0:c1]
+                dense, _ = eng._spmm_fwd("sum", gp.fwd, gp.col, w, xs.contiguous(), N)
+                outw = torch.full((N, KW), 7.0, device=dev)
+                eng.spmm_sum_into(gp.fwd, gp.col, w, xs, outw[:, c0:c1])
+                assert torch.equal(outw[:, c0:c1], dense)
+                assert bool((outw[:, :c0] == 7).all()) and bool((outw[:, c1:] == 7).all())  # nothing else touched
+                base = torch.randn(N, KW, generator=g).to(dev)
+                acc = base.clone()
+                eng.spmm_sum_into(gp.fwd, gp.col, w, xs, acc[:, c0:c1], accumulate=True)
+                torch.testing.assert_close(acc[:, c0:c1], base[:, c0:c1] + dense, rtol=1e-5, atol=1e-5)
+                assert torch.equal(acc[:, :c0], base[:, :c0]) and torch.equal(acc[:, c1:], base[:, c1:])
+            # segment_sum over a strided message block, accumulated onto a column block
+            ids = ei[1].contiguous()
+            plan = eng.seg_plan(ids, N)
+            mw = torch.randn(E, KW, generator=g).to(dev)
+            base = torch.randn(N, KW, generator=g).to(dev)
+            acc = base.clone()
+            eng.segment_sum_into(mw[:, 4:12], plan, acc[:, 8:16], accumulate=True)
+            ref = oracle.segment_sum(to_np(mw[:, 4:12].contiguous()), to_np(ids), N)
+            np.testing.assert_allclose(to_np(acc[:, 8:16]), to_np(base[:, 8:16]) + ref, rtol=1e-5, atol=1e-5)
+            assert torch.equal(acc[:, :8], base[:, :8]) and torch.equal(acc[:, 16:], base[:, 16:])
+    finally:
+        eng.chunk = old
+        eng.graph_cache.clear(); eng.seg_cache.clear()
+
+
 def check_plan_cache(eng, dev):
     eng.seg_cache.clear()
     ids = torch.tensor([2, 0, 1, 0, 2, 2], device=dev)

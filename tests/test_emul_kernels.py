@@ -47,6 +47,10 @@ def test_gcn_and_gat_layer_golden(eng, golden):
     pc.check_layers_golden(eng, DEV, golden)
 
 
+def test_strided_and_accumulating_forms(eng, oracle):
+    pc.check_strided_accumulate(eng, DEV, oracle)
+
+
 def test_spmm_with_fused_epilogue(eng):
     pc.check_spmm_bias_act(eng, DEV)
 

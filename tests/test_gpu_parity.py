@@ -87,6 +87,10 @@ def test_edge_cases_and_errors(eng, dev, oracle):
     pc.check_edge_cases(eng, dev, oracle)
 
 
+def test_strided_and_accumulating_forms(eng, dev, oracle):
+    pc.check_strided_accumulate(eng, dev, oracle)
+
+
 def test_spmm_with_fused_epilogue(eng, dev):
     pc.check_spmm_bias_act(eng, dev)
 
