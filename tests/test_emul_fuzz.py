@@ -52,7 +52,10 @@ def make_ids(rng, N, E, kind):
 @settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
 @given(problems(), st.sampled_from(["float32", "float64", "int32", "float16", "bfloat16"]))
 def test_segment_ops_fuzz(oracle, prob, dt):
-    eng = engine()
+    run_segment_case(engine(), DEV, oracle, prob, dt)
+
+
+def run_segment_case(eng, DEV, oracle, prob, dt):
     N, E, K, chunk, kind, seed = prob
     rng = np.random.default_rng(seed)
     ids = make_ids(rng, N, E, kind)
@@ -84,7 +87,10 @@ def test_segment_ops_fuzz(oracle, prob, dt):
 @settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck))
 @given(problems())
 def test_gspmm_fuzz(oracle, prob):
-    eng = engine()
+    run_gspmm_case(engine(), DEV, oracle, prob)
+
+
+def run_gspmm_case(eng, DEV, oracle, prob):
     N, E, K, chunk, kind, seed = prob
     rng = np.random.default_rng(seed)
     index = np.stack([rng.integers(0, N, size=E), make_ids(rng, N, E, kind)]).astype(np.int64)
@@ -135,9 +141,12 @@ def gat_problems(draw):
 @settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck))
 @given(gat_problems())
 def test_gat_fused_fuzz(oracle, prob):
-    """One-walk online-softmax forward + edge-parallel / transposed-walk backward vs the oracle's three-pass
-    restatement of gat_conv.py:103-112: short rows, chunked hubs on either side, empty rows, big logits."""
-    eng = engine()
+    """One-walk online-softmax forward + two-walk backward vs the oracle's three-pass restatement of
+    gat_conv.py:103-112: short rows, chunked hubs on either side, empty rows, big logits."""
+    run_gat_case(engine(), DEV, oracle, prob)
+
+
+def run_gat_case(eng, DEV, oracle, prob):
     N, E, H, C, chunk, kind, scale, seed = prob
     rng = np.random.default_rng(seed)
     index = np.stack([make_ids(rng, N, E, "hub" if kind == "single" else "uniform"),
