@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gammagl_amd.layers import GCNModel, add_self_loops  # noqa: E402
+from gammagl_amd.synth import homophilous_graph  # noqa: E402
 
 
 def load(args, dev):
@@ -28,19 +29,8 @@ def load(args, dev):
         return (t("x", torch.float32), t("y", torch.int64), t("edge_index", torch.int64), t("train_idx", torch.int64),
                 t("val_idx", torch.int64), t("test_idx", torch.int64))
     n, f, c = 2708, 1433, 7   # Cora's node / feature / class counts
-    g = torch.Generator(device=dev).manual_seed(0)
-    y = torch.randint(0, c, (n,), generator=g, device=dev)
-    # homophilous graph: ~2 edges per node, 85 % of them inside the node's class (symmetrised below)
-    src = torch.arange(n, device=dev).repeat_interleave(2)
-    same = torch.rand(src.shape[0], generator=g, device=dev) < 0.85
-    order = torch.argsort(y * n + torch.arange(n, device=dev))           # nodes grouped by class
-    start = torch.searchsorted(y[order].contiguous(), torch.arange(c + 1, device=dev))
-    r = torch.rand(src.shape[0], generator=g, device=dev)
-    in_class = order[(start[y[src]] + (r * (start[y[src] + 1] - start[y[src]])).long()).clamp(max=n - 1)]
-    anywhere = torch.randint(0, n, (src.shape[0],), generator=g, device=dev)
-    dst = torch.where(same, in_class, anywhere)
-    ei = torch.cat([torch.stack([src, dst]), torch.stack([dst, src])], dim=1)
-    x = torch.randn(n, f, generator=g, device=dev) + 0.5 * F.one_hot(y, f).float()
+    x, y, ei = homophilous_graph(n, f, c, deg=2, seed=0, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1)
     perm = torch.randperm(n, generator=g, device=dev)
     return x, y, ei, perm[:140], perm[140:640], perm[640:1640]
 

@@ -251,6 +251,35 @@ class GCNModel(nn.Module):
         return self.conv[-1](x, edge_index, edge_weight, num_nodes)
 
 
+class GATModel(nn.Module):
+    """models/gat.py:4-73: dropout -> GATConv (-> ELU) per layer, attention dropout inside the conv, the
+    last layer averages its heads.  `fused=True` uses FusedGATConv (one kernel per direction)."""
+
+    def __init__(self, feature_dim, hidden_dim, num_class, heads, drop_rate, num_layers, fused=True):
+        super().__init__()
+        conv = FusedGATConv if fused else GATConv
+        if num_layers == 1:
+            hidden_dim = num_class
+        self.gat_list = nn.ModuleList()
+        for i in range(num_layers):
+            if i == 0:
+                self.gat_list.append(conv(feature_dim, hidden_dim, heads=heads, dropout_rate=drop_rate, concat=True))
+            elif i == num_layers - 1:
+                self.gat_list.append(conv(hidden_dim * heads, num_class, heads=heads, dropout_rate=drop_rate,
+                                          concat=False))
+            else:
+                self.gat_list.append(conv(hidden_dim * heads, hidden_dim, heads=heads, dropout_rate=drop_rate,
+                                          concat=True))
+        self.dropout = nn.Dropout(drop_rate)
+
+    def forward(self, x, edge_index, num_nodes):
+        for i, gat in enumerate(self.gat_list):
+            x = gat(self.dropout(x), edge_index, num_nodes)
+            if i < len(self.gat_list) - 1:
+                x = torch.nn.functional.elu(x)
+        return x
+
+
 class GraphSAGESampleModel(nn.Module):
     """models/graphsage.py:35-83 (GraphSAGE_Sample_Model): SAGEConv(mean) per sampled hop; the target
     nodes of a block are the first size[1] rows of its input ("target nodes are always placed first")."""
@@ -275,5 +304,5 @@ class GraphSAGESampleModel(nn.Module):
         return x
 
 
-__all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "GraphSAGESampleModel", "degree",
+__all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "GATModel", "GraphSAGESampleModel", "degree",
            "calc_gcn_norm", "segment_softmax", "add_self_loops"]

@@ -83,3 +83,23 @@ def rmat_graph(num_nodes, num_directed_edges, seed=0, device="cpu", relabel="ran
 def dataset_like(name, seed=0, device="cpu", **kw):
     n, e, f, c = DATASETS[name]
     return rmat_graph(n, e, seed=seed, device=device, **kw), n, f, c
+
+
+def homophilous_graph(n, f, c, deg=2, p_same=0.85, signal=0.5, seed=0, device="cpu"):
+    """Seeded node-classification toy with learnable structure (no dataset can be downloaded here): labels y,
+    features = noise + `signal` * one_hot(y), `deg` out-edges per node of which `p_same` stay inside the
+    node's class, symmetrised.  Returns x [n,f], y [n], edge_index [2, 2*deg*n] (no self-loops)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    y = torch.randint(0, c, (n,), generator=g, device=dev)
+    src = torch.arange(n, device=dev).repeat_interleave(deg)
+    same = torch.rand(src.shape[0], generator=g, device=dev) < p_same
+    order = torch.argsort(y * n + torch.arange(n, device=dev))           # nodes grouped by class
+    start = torch.searchsorted(y[order].contiguous(), torch.arange(c + 1, device=dev))
+    r = torch.rand(src.shape[0], generator=g, device=dev)
+    in_class = order[(start[y[src]] + (r * (start[y[src] + 1] - start[y[src]])).long()).clamp(max=n - 1)]
+    anywhere = torch.randint(0, n, (src.shape[0],), generator=g, device=dev)
+    dst = torch.where(same, in_class, anywhere)
+    ei = torch.cat([torch.stack([src, dst]), torch.stack([dst, src])], dim=1)
+    x = torch.randn(n, f, generator=g, device=dev) + signal * torch.nn.functional.one_hot(y, f).float()
+    return x, y, ei
