@@ -21,7 +21,7 @@ __global__ __launch_bounds__(kBlock) void row_gather_kernel(const typename TT<T>
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int L = 1 << logL;
-  const int64_t e = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * (kWave >> logL) + (lane >> logL);
+  const int64_t e = (block_id() * kWavesPerBlock + wave) * (kWave >> logL) + (lane >> logL);
   if (e >= E) return;
   const int li = lane & (L - 1);
   const int64_t s = ids[e];
@@ -45,8 +45,8 @@ template <typename S>
 __global__ __launch_bounds__(kBlock) void max_scatter_kernel(const S *gout, const int64_t *arg,
                                                              int64_t total, int64_t K, int64_t E,
                                                              S *gin) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < total; i += stride) {
     const int64_t a = arg[i];
     if (a >= 0 && a < E) gin[a * K + (i % K)] = gout[i];
   }
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(kBlock) void max_scatter_kernel(const S *gout, cons
 __global__ __launch_bounds__(kBlock) void bspmm_grad_w_kernel(const int64_t *index, const float *x,
                                                               const float *g, int64_t E, int64_t H,
                                                               int64_t C, float *gw) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E * H; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < E * H; i += stride) {
     const int64_t e = i / H, h = i - e * H;
     const float *xr = x + (index[e] * H + h) * C;
     const float *gr = g + (index[e + E] * H + h) * C;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_kernel(const int64_t *ind
 }
 
 __global__ __launch_bounds__(kBlock) void fill_i64_kernel(int64_t *p, int64_t n, int64_t v) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < n; i += stride) p[i] = v;
 }
 
 static inline int64_t grid_for(int64_t n) {
@@ -178,13 +178,15 @@ extern "C" int ggl_segment_max_bwd(int dtype, const void *gout, const int64_t *a
 //          and writes partial[(b*G + j), k].  stage 2: one thread per column adds the partials in
 //          order.  No atomics, no LDS: the result does not depend on scheduling.
 __global__ __launch_bounds__(kBlock) void colsum_stage1_kernel(const float *__restrict__ g, int64_t N,
-                                                               int64_t K, int64_t rows_per_block,
+                                                               int64_t K, int64_t nblocks,
+                                                               int64_t rows_per_block,
                                                                int kp, int groups,
                                                                float *__restrict__ partial) {
   const int j = threadIdx.x / kp;
   const int k0 = threadIdx.x - j * kp;
   if (j >= groups) return;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r0 = block_id() * rows_per_block;
+  if (block_id() >= nblocks) return;  // padding block of a folded grid
   const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
   for (int64_t k = k0; k < K; k += kp) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains, combined in a fixed order
@@ -196,14 +198,14 @@ __global__ __launch_bounds__(kBlock) void colsum_stage1_kernel(const float *__re
       a3 = __fadd_rn(a3, g[(r + 3 * (int64_t)groups) * K + k]);
     }
     for (; r < r1; r += groups) a0 = __fadd_rn(a0, g[r * K + k]);
-    partial[((int64_t)blockIdx.x * groups + j) * K + k] = __fadd_rn(__fadd_rn(a0, a1), __fadd_rn(a2, a3));
+    partial[(block_id() * groups + j) * K + k] = __fadd_rn(__fadd_rn(a0, a1), __fadd_rn(a2, a3));
   }
 }
 
 __global__ __launch_bounds__(kBlock) void colsum_stage2_kernel(const float *__restrict__ partial,
                                                                int64_t P, int64_t K,
                                                                float *__restrict__ out) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = thread_id();
   if (k >= K) return;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains, combined in a fixed order
   int64_t p = 0;
@@ -253,7 +255,7 @@ extern "C" int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, 
   colsum_geometry(N, K, &kp, &groups, &blocks, &rpb);
   hipStream_t s = as_stream(stream);
   float *partial = static_cast<float *>(workspace);
-  GGL_LAUNCH((colsum_stage1_kernel), blocks, kBlock, s, g, N, K, rpb, kp, groups, partial);
+  GGL_LAUNCH((colsum_stage1_kernel), blocks, kBlock, s, g, N, K, blocks, rpb, kp, groups, partial);
   GGL_LAUNCH_CHECK();
   const int64_t P = blocks * groups;
   if (P > kColsumSerial && P * 4 <= N) {  // still many partial rows: reduce them with the same two stages

@@ -45,14 +45,37 @@ void set_error(const char *fmt, ...);
   } while (0)
 #define GGL_LAUNCH_CHECK() GGL_HIP_CHECK(hipGetLastError())
 
-// kernel launch: KERN is a parenthesised kernel name, e.g. (k<float, 4>)
+// kernel launch: KERN is a parenthesised kernel name, e.g. (k<float, 4>).  A dispatch carries its grid as
+// 32-bit WORK-ITEM counts per dimension, so gridDim.x * blockDim.x must stay below 2^32: a 256-thread
+// block per 4 rows overflows that at 67 M rows (found on the papers100M-sized graph: the tail of the rows
+// was silently not launched).  Grids wider than max_grid_x blocks are therefore folded into (x, y) and
+// kernels that index by block use block_id(); every such kernel already returns for ids past its work.
+int64_t max_grid_x();
+static inline void fold_grid(int64_t grid, unsigned *gx, unsigned *gy) {
+  const int64_t mx = max_grid_x();
+  if (grid <= mx) { *gx = (unsigned)(grid > 0 ? grid : 1); *gy = 1; return; }
+  *gx = (unsigned)mx;
+  *gy = (unsigned)((grid + mx - 1) / mx);
+}
 #ifdef GGL_EMULATE
-#define GGL_LAUNCH(KERN, GRID, BLOCK, STREAM, ...) \
-  ::ggl_emul::launch((GRID), (BLOCK), [&]() { KERN(__VA_ARGS__); })
+#define GGL_LAUNCH(KERN, GRID, BLOCK, STREAM, ...)                                       \
+  do {                                                                                   \
+    unsigned ggl_gx_, ggl_gy_;                                                           \
+    ::ggl::fold_grid((GRID), &ggl_gx_, &ggl_gy_);                                        \
+    ::ggl_emul::launch2d(ggl_gx_, ggl_gy_, (BLOCK), [&]() { KERN(__VA_ARGS__); });       \
+  } while (0)
 #else
-#define GGL_LAUNCH(KERN, GRID, BLOCK, STREAM, ...) \
-  hipLaunchKernelGGL(KERN, dim3((unsigned)(GRID)), dim3((unsigned)(BLOCK)), 0, (STREAM), __VA_ARGS__)
+#define GGL_LAUNCH(KERN, GRID, BLOCK, STREAM, ...)                                       \
+  do {                                                                                   \
+    unsigned ggl_gx_, ggl_gy_;                                                           \
+    ::ggl::fold_grid((GRID), &ggl_gx_, &ggl_gy_);                                        \
+    hipLaunchKernelGGL(KERN, dim3(ggl_gx_, ggl_gy_), dim3((unsigned)(BLOCK)), 0, (STREAM), __VA_ARGS__); \
+  } while (0)
 #endif
+// linear block index of a (possibly folded) launch
+__device__ __forceinline__ int64_t block_id() { return (int64_t)blockIdx.y * (int64_t)gridDim.x + (int64_t)blockIdx.x; }
+__device__ __forceinline__ int64_t thread_id() { return block_id() * (int64_t)blockDim.x + (int64_t)threadIdx.x; }
+__device__ __forceinline__ int64_t grid_threads() { return (int64_t)gridDim.x * (int64_t)gridDim.y * (int64_t)blockDim.x; }
 
 struct Options {
   int64_t unroll = 4;        // neighbour loads in flight per lane in the f32 fast path (4 or 8)
@@ -65,6 +88,7 @@ struct Options {
   // 0 = natural row order; 1 = length-sorted rows where several rows share a wavefront (balances
   // the lanes of a wave); 2 = also for the wave-per-row kernels (heavy rows first)
   int64_t row_order = 1;
+  int64_t max_grid_x = 1 << 22;  // blocks per grid row before a launch is folded into 2-D (tests lower it)
 };
 Options &options();
 

@@ -40,13 +40,15 @@ __global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(const float *__res
                                                               const float *__restrict__ bias,
                                                               const int64_t *__restrict__ rng,
                                                               float *__restrict__ y, int64_t N, int64_t K,
-                                                              int64_t rows_per_block, int kp, int groups,
+                                                              int64_t nblocks, int64_t rows_per_block, int kp,
+                                                              int groups,
                                                               int relu, uint32_t drop_thresh, float scale) {
   const int j = threadIdx.x / kp;
   const int c0 = threadIdx.x - j * kp;
   if (j >= groups) return;
   const int64_t KV = (K + VEC - 1) / VEC;  // vectors per row (VEC = 4 only when K % 4 == 0)
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r0 = block_id() * rows_per_block;
+  if (block_id() >= nblocks) return;  // padding block of a folded grid
   const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
   const uint64_t seed = drop_thresh ? (uint64_t)rng[0] : 0, offset = drop_thresh ? (uint64_t)rng[1] : 0;
   for (int64_t c = c0; c < KV; c += kp) {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(const float *__res
 }
 
 __global__ void rng_advance_kernel(int64_t *rng, int64_t inc) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) rng[1] += inc;
+  if (block_id() == 0 && threadIdx.x == 0) rng[1] += inc;
 }
 
 // backward + first stage of the bias gradient.  Same thread geometry as the forward; every lane keeps a
@@ -95,14 +97,16 @@ template <int VEC>
 __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__restrict__ g,
                                                               const float *__restrict__ y,
                                                               float *__restrict__ ga, int64_t N,
-                                                              int64_t K, int64_t rows_per_block, int kp,
+                                                              int64_t K, int64_t nblocks,
+                                                              int64_t rows_per_block, int kp,
                                                               int groups, int masked, float scale,
                                                               float *__restrict__ partial) {
   const int j = threadIdx.x / kp;
   const int c0 = threadIdx.x - j * kp;
   if (j >= groups) return;
   const int64_t KV = (K + VEC - 1) / VEC;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r0 = block_id() * rows_per_block;
+  if (block_id() >= nblocks) return;  // padding block of a folded grid
   const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
   for (int64_t c = c0; c < KV; c += kp) {
     float acc[VEC];
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
     }
     if (partial) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) partial[((int64_t)blockIdx.x * groups + j) * K + c * VEC + i] = acc[i];
+      for (int i = 0; i < VEC; ++i) partial[(block_id() * groups + j) * K + c * VEC + i] = acc[i];
     }
   }
 }
@@ -182,10 +186,10 @@ extern "C" int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, in
   int64_t grid, rpb;
   geometry(N, K, vec4, &kp, &groups, &grid, &rpb);
   if (vec4)
-    GGL_LAUNCH((bias_act_fwd_kernel<4>), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, N, K, rpb,
+    GGL_LAUNCH((bias_act_fwd_kernel<4>), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, N, K, grid, rpb,
                kp, groups, relu, thresh, scale);
   else
-    GGL_LAUNCH((bias_act_fwd_kernel<1>), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, N, K, rpb,
+    GGL_LAUNCH((bias_act_fwd_kernel<1>), grid, kBlock, s, a, bias, (const int64_t *)rng_state, y, N, K, grid, rpb,
                kp, groups, relu, thresh, scale);
   GGL_LAUNCH_CHECK();
   if (thresh) return rng_advance(rng_state, stream);
@@ -227,10 +231,10 @@ extern "C" int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64
   hipStream_t s = as_stream(stream);
   float *partial = gbias ? static_cast<float *>(workspace) : nullptr;
   if (vec4)
-    GGL_LAUNCH((bias_act_bwd_kernel<4>), blocks, kBlock, s, g, y, ga, N, K, rpb, kp, groups, masked, scale,
+    GGL_LAUNCH((bias_act_bwd_kernel<4>), blocks, kBlock, s, g, y, ga, N, K, blocks, rpb, kp, groups, masked, scale,
                partial);
   else
-    GGL_LAUNCH((bias_act_bwd_kernel<1>), blocks, kBlock, s, g, y, ga, N, K, rpb, kp, groups, masked, scale,
+    GGL_LAUNCH((bias_act_bwd_kernel<1>), blocks, kBlock, s, g, y, ga, N, K, blocks, rpb, kp, groups, masked, scale,
                partial);
   GGL_LAUNCH_CHECK();
   if (gbias) {  // second stage: column sums of the [P, K] partial matrix

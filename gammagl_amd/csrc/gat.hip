@@ -157,8 +157,8 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int64_t H = d.H, K = d.K;
-  if ((int64_t)blockIdx.x < d.chunk_blocks) {  // one wavefront per chunk of a long row
-    const int64_t cid = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (block_id() < d.chunk_blocks) {  // one wavefront per chunk of a long row
+    const int64_t cid = block_id() * kWavesPerBlock + wave;
     if (cid >= d.n_chunks) return;
     int64_t lo = 0, hi = d.n_long - 1;
     while (lo < hi) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd_kernel(
     return;
   }
   const int L = 1 << d.logL;
-  const int64_t slot = (((int64_t)blockIdx.x - d.chunk_blocks) * kWavesPerBlock + wave) * (kWave >> d.logL) +
+  const int64_t slot = ((block_id() - d.chunk_blocks) * kWavesPerBlock + wave) * (kWave >> d.logL) +
                        (lane >> d.logL);
   if (slot >= d.N) return;
   const int64_t row = row_order ? (int64_t)row_order[slot] : slot;
@@ -210,7 +210,8 @@ __global__ __launch_bounds__(kBlock) void gat_long_final_kernel(
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr,
     const float *__restrict__ pacc, const float *__restrict__ pm, const float *__restrict__ pd,
     float *__restrict__ y, float *__restrict__ rowmax, float *__restrict__ rowden, const GatDims d) {
-  const int64_t j = blockIdx.x;
+  const int64_t j = block_id();
+  if (j >= d.n_long) return;
   const int64_t row = long_rows[j];
   const int64_t c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
   for (int64_t k = threadIdx.x; k < d.K; k += kBlock) {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(
   const int64_t C = CREG > 0 ? (int64_t)CREG : d.C;
   const uint64_t seed = d.drop_thresh ? (uint64_t)rng[0] : 0, offset = d.drop_thresh ? (uint64_t)rng[1] : 0;
   const int LG = 1 << d.logL;
-  const int64_t item = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> d.logL;
+  const int64_t item = (block_id() * kBlock + threadIdx.x) >> d.logL;
   const int li = threadIdx.x & (LG - 1);
   if (item >= d.n_chunks + d.N) return;
   const bool is_chunk = item < d.n_chunks;
@@ -358,8 +359,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_final_kernel(const int32_t
                                                                    const float *__restrict__ pger,
                                                                    float *__restrict__ ger, int64_t n_long,
                                                                    int64_t H) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_long * H; t += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t t = thread_id(); t < n_long * H; t += stride) {
     const int64_t j = t / H, h = t - j * H;
     float a = 0.0f;
     for (int64_t c = chunk_ptr[j]; c < chunk_ptr[j + 1]; ++c) a = __fadd_rn(a, pger[c * H + h]);
@@ -423,8 +424,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int64_t H = d.H, K = d.K;
-  if ((int64_t)blockIdx.x < d.chunk_blocks) {  // one wavefront per chunk of a long row
-    const int64_t cid = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (block_id() < d.chunk_blocks) {  // one wavefront per chunk of a long row
+    const int64_t cid = block_id() * kWavesPerBlock + wave;
     if (cid >= d.n_chunks) return;
     int64_t lo = 0, hi = d.n_long - 1;
     while (lo < hi) {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_kernel(
     return;
   }
   const int L = 1 << d.logL;
-  const int64_t slot = (((int64_t)blockIdx.x - d.chunk_blocks) * kWavesPerBlock + wave) * (kWave >> d.logL) +
+  const int64_t slot = ((block_id() - d.chunk_blocks) * kWavesPerBlock + wave) * (kWave >> d.logL) +
                        (lane >> d.logL);
   if (slot >= d.N) return;
   const int64_t row = row_order ? (int64_t)row_order[slot] : slot;
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_final_kernel(
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr,
     const float *__restrict__ pacc, const float *__restrict__ pgel, float *__restrict__ gx,
     float *__restrict__ gel, const GatDims d) {
-  const int64_t j = blockIdx.x;
+  const int64_t j = block_id();
+  if (j >= d.n_long) return;
   const int64_t row = long_rows[j];
   const int64_t c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
   for (int64_t k = threadIdx.x; k < d.K + d.H; k += kBlock) {

@@ -35,6 +35,8 @@ static int64_t env_i64(const char *name, int64_t dflt) {
   return (v && *v) ? atoll(v) : dflt;
 }
 
+int64_t max_grid_x() { return options().max_grid_x; }
+
 Options &options() {
   static Options o = [] {
     Options t;
@@ -43,6 +45,7 @@ Options &options() {
     t.xcd_swizzle = env_i64("GGL_XCD_SWIZZLE", t.xcd_swizzle);
     t.force_generic = env_i64("GGL_FORCE_GENERIC", t.force_generic);
     t.row_order = env_i64("GGL_ROW_ORDER", t.row_order);
+    t.max_grid_x = env_i64("GGL_MAX_GRID_X", t.max_grid_x);
     return t;
   }();
   return o;
@@ -51,8 +54,8 @@ Options &options() {
 // flags[0] = some id out of [0, N); flags[1] = ids not non-decreasing
 __global__ __launch_bounds__(kBlock) void check_ids_kernel(const int64_t *ids, int64_t E, int64_t N,
                                                            int32_t *flags) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < E; i += stride) {
     const int64_t v = ids[i];
     if (v < 0 || v >= N) flags[0] = 1;  // benign race: every writer stores the same value
     if (i > 0 && ids[i - 1] > v) flags[1] = 1;
@@ -61,8 +64,8 @@ __global__ __launch_bounds__(kBlock) void check_ids_kernel(const int64_t *ids, i
 
 __global__ __launch_bounds__(kBlock) void keys_iota_kernel(const int64_t *ids, int64_t E,
                                                            uint32_t *keys, int32_t *vals) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < E; i += stride) {
     if (keys) keys[i] = (uint32_t)ids[i];
     vals[i] = (int32_t)i;
   }
@@ -72,8 +75,8 @@ __global__ __launch_bounds__(kBlock) void keys_iota_kernel(const int64_t *ids, i
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void rowptr_kernel(const KeyT *keys, int64_t E, int64_t N,
                                                         int64_t *rowptr) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= N; s += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t s = thread_id(); s <= N; s += stride) {
     int64_t lo = 0, hi = E;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void span_count_kernel(const int64_t *rowpt
                                                             int64_t chunk, int64_t nspans,
                                                             int64_t *span_long, int64_t *span_chunks,
                                                             int64_t *span_maxlen) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = thread_id();
   if (t >= nspans) return;
   const int64_t r0 = t * kSpan, r1 = (r0 + kSpan < N) ? r0 + kSpan : N;
   int64_t nl = 0, nc = 0, mx = 0;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void span_count_kernel(const int64_t *rowpt
 // one thread: exclusive scan of the span counts in place; totals[0..2] = n_long, n_chunks, max_len
 __global__ void span_scan_kernel(int64_t nspans, int64_t *span_long, int64_t *span_chunks,
                                  const int64_t *span_maxlen, int64_t *totals) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (block_id() != 0 || threadIdx.x != 0) return;
   int64_t al = 0, ac = 0, mx = 0;
   for (int64_t t = 0; t < nspans; ++t) {
     const int64_t l = span_long[t], c = span_chunks[t];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void span_fill_kernel(const int64_t *rowptr
                                                            const int64_t *span_chunks,
                                                            int32_t *long_rows, int64_t *chunk_ptr,
                                                            int64_t n_long, int64_t n_chunks) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = thread_id();
   if (t == 0) chunk_ptr[n_long] = n_chunks;
   if (t >= nspans) return;
   const int64_t r0 = t * kSpan, r1 = (r0 + kSpan < N) ? r0 + kSpan : N;
@@ -151,16 +154,16 @@ __global__ __launch_bounds__(kBlock) void span_fill_kernel(const int64_t *rowptr
 __global__ __launch_bounds__(kBlock) void gather_i64_i32_kernel(const int64_t *src,
                                                                 const int32_t *perm, int64_t E,
                                                                 int32_t *out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride)
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < E; i += stride)
     out[i] = (int32_t)src[perm ? (int64_t)perm[i] : i];
 }
 
 __global__ __launch_bounds__(kBlock) void gather_rows_f32_kernel(const float *src,
                                                                  const int32_t *perm, int64_t total,
                                                                  int64_t H, float *out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < total; i += stride) {
     const int64_t p = i / H, h = i - p * H;
     out[i] = src[(perm ? (int64_t)perm[p] : p) * H + h];
   }
@@ -223,6 +226,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "xcd_swizzle")) o.xcd_swizzle = value;
   else if (!strcmp(name, "force_generic")) o.force_generic = value;
   else if (!strcmp(name, "row_order")) o.row_order = value;
+  else if (!strcmp(name, "max_grid_x")) o.max_grid_x = value > 0 ? value : 1;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
 }
@@ -234,6 +238,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "xcd_swizzle")) return o.xcd_swizzle;
   if (!strcmp(name, "force_generic")) return o.force_generic;
   if (!strcmp(name, "row_order")) return o.row_order;
+  if (!strcmp(name, "max_grid_x")) return o.max_grid_x;
   return -1;
 }
 
@@ -413,8 +418,8 @@ namespace ggl {
 // ind[p] = r  with ptr[r] <= p < ptr[r+1]
 __global__ __launch_bounds__(kBlock) void ptr2ind_kernel(const int64_t *__restrict__ ptr, int64_t M,
                                                          int64_t E, int64_t *__restrict__ ind) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t p = thread_id(); p < E; p += stride) {
     int64_t lo = 0, hi = M;  // first r with ptr[r+1] > p
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
@@ -429,8 +434,8 @@ __global__ __launch_bounds__(kBlock) void edge_keys_kernel(const int64_t *__rest
                                                            int64_t E, int64_t N,
                                                            uint64_t *__restrict__ keys,
                                                            int32_t *__restrict__ vals) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < E; i += stride) {
     keys[i] = (uint64_t)major[i] * (uint64_t)N + (uint64_t)minor[i];
     vals[i] = (int32_t)i;
   }

@@ -309,8 +309,8 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
   GGL_RPTR_PACK(S);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  if ((int64_t)blockIdx.x < d.chunk_blocks) {
-    const int c32 = __builtin_amdgcn_readfirstlane((int)((int64_t)blockIdx.x * kWavesPerBlock + wave));
+  if (block_id() < d.chunk_blocks) {
+    const int c32 = __builtin_amdgcn_readfirstlane((int)(block_id() * kWavesPerBlock + wave));
     const int64_t cid = (int64_t)(uint32_t)c32;
     if (cid >= d.n_chunks) return;
     // owning long row: last j with chunk_ptr[j] <= cid
@@ -340,7 +340,8 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
     }
     return;
   }
-  const int64_t blk = xcd_remap((int64_t)blockIdx.x - d.chunk_blocks, d.nblocks, d.swizzle);
+  if (block_id() - d.chunk_blocks >= d.nblocks) return;  // padding blocks of a folded (2-D) grid
+  const int64_t blk = xcd_remap(block_id() - d.chunk_blocks, d.nblocks, d.swizzle);
   const int L = 1 << d.logL;
   int64_t slot;
   int li;
@@ -385,7 +386,8 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
   RPtrs<typename TT<T>::S> q{};
   q.epi_bias = epi_bias;
   q.epi_rng = epi_rng;
-  const int64_t j = blockIdx.x;  // one block per long row
+  const int64_t j = block_id();  // one block per long row
+  if (j >= d.n_long) return;
   const int64_t row = long_rows[j];
   const int64_t c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
   const int64_t len = rowptr[row + 1] - rowptr[row];

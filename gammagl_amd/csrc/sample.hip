@@ -43,8 +43,8 @@ __global__ __launch_bounds__(kBlock) void sample_count_kernel(const int64_t *__r
                                                               const int64_t *__restrict__ seeds, int64_t B,
                                                               int64_t fanout, int replace,
                                                               int64_t *__restrict__ out_deg) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < B; i += stride) {
     const int64_t n = seeds[i];
     const int64_t deg = rowptr[n + 1] - rowptr[n];
     int64_t k;
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(kBlock) void sample_pick_kernel(const int64_t *__re
                                                              int64_t *__restrict__ e_pos,
                                                              int64_t *__restrict__ nbr) {
   const uint64_t seed = (uint64_t)rng[0], offset = (uint64_t)rng[1];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += stride) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < B; i += stride) {
     const int64_t n = seeds[i];
     const int64_t beg = rowptr[n], deg = rowptr[n + 1] - beg;
     const int64_t o = out_rowptr[i], k = out_rowptr[i + 1] - o;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void sample_pick_kernel(const int64_t *__re
 }
 
 __global__ void sample_rng_advance_kernel(int64_t *rng) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) rng[1] += 1;
+  if (block_id() == 0 && threadIdx.x == 0) rng[1] += 1;
 }
 
 static inline int64_t grid_for(int64_t n) {

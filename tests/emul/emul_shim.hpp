@@ -65,4 +65,21 @@ template <typename F> static inline void launch(int64_t grid, int64_t block, F &
     }
   }
 }
+template <typename F> static inline void launch2d(unsigned gx, unsigned gy, int64_t block, F &&body) {
+  gridDim.x = gx;
+  gridDim.y = gy;
+  blockDim.x = (unsigned)block;
+  for (unsigned by = 0; by < gy; ++by) {
+    blockIdx.y = by;
+    for (unsigned bx = 0; bx < gx; ++bx) {
+      blockIdx.x = bx;
+      for (int64_t t = 0; t < block; ++t) {
+        threadIdx.x = (unsigned)t;
+        body();
+      }
+    }
+  }
+  blockIdx.y = 0;
+  gridDim.y = 1;
+}
 }  // namespace ggl_emul

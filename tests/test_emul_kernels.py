@@ -47,6 +47,26 @@ def test_gcn_and_gat_layer_golden(eng, golden):
     pc.check_layers_golden(eng, DEV, golden)
 
 
+def test_folded_2d_grids(eng, oracle, golden):
+    """A dispatch holds at most 2^32 work-items per grid dimension (67 M rows at 4 rows per 256-thread
+    block): wider launches are folded into (x, y).  Force the fold on tiny problems (max_grid_x = 3) and
+    rerun the parity cases: every kernel must index through block_id() and ignore padding blocks."""
+    eng.set_option("max_grid_x", 3)
+    try:
+        pc.check_kat(eng, DEV, golden)
+        pc.check_random_vs_oracle(eng, DEV, oracle)
+        pc.check_long_rows(eng, DEV, oracle)
+        pc.check_gat_random(eng, DEV, oracle)
+        pc.check_gat_dropout(eng, DEV, oracle)
+        pc.check_spmm_bias_act(eng, DEV)
+        pc.check_strided_accumulate(eng, DEV, oracle)
+        pc.check_colsum(eng, DEV)
+        pc.check_bias_act(eng, DEV)
+        pc.check_convert(eng, DEV)
+    finally:
+        eng.set_option("max_grid_x", 1 << 22)
+
+
 def test_strided_and_accumulating_forms(eng, oracle):
     pc.check_strided_accumulate(eng, DEV, oracle)
 

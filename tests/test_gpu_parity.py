@@ -87,6 +87,25 @@ def test_edge_cases_and_errors(eng, dev, oracle):
     pc.check_edge_cases(eng, dev, oracle)
 
 
+def test_folded_2d_grids(eng, dev, oracle, golden):
+    """Launches wider than max_grid_x blocks are folded into 2-D grids (a dispatch holds < 2^32 work-items
+    per dimension); forced here with max_grid_x = 3 on small problems, all parity cases must still hold."""
+    eng.set_option("max_grid_x", 3)
+    try:
+        pc.check_kat(eng, dev, golden)
+        pc.check_random_vs_oracle(eng, dev, oracle, sizes=[(50, 400), (257, 3000)])
+        pc.check_long_rows(eng, dev, oracle)
+        pc.check_gat_random(eng, dev, oracle)
+        pc.check_gat_dropout(eng, dev, oracle)
+        pc.check_spmm_bias_act(eng, dev)
+        pc.check_strided_accumulate(eng, dev, oracle)
+        pc.check_colsum(eng, dev)
+        pc.check_bias_act(eng, dev)
+        pc.check_convert(eng, dev)
+    finally:
+        eng.set_option("max_grid_x", 1 << 22)
+
+
 def test_strided_and_accumulating_forms(eng, dev, oracle):
     pc.check_strided_accumulate(eng, dev, oracle)
 
