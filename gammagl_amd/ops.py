@@ -67,8 +67,7 @@ class SegPlan:
 class GraphPlan:
     """CSR (rows = destination) and, lazily, CSC (rows = source) plans of one edge_index."""
 
-    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT",
-                 "_row_of_pos")
+    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT")
 
     def __init__(self, engine, index, n_dst, n_src):
         self.engine = engine
@@ -80,7 +79,7 @@ class GraphPlan:
         self.fwd = engine.seg_plan(index[1], self.N_dst)
         engine._check_range(index[0], self.N_src)
         self.col = engine.gather_i32(index[0], self.fwd.perm)
-        self._bwd = self._colT = self._posT = self._row_of_pos = None
+        self._bwd = self._colT = self._posT = None
 
     @property
     def bwd(self):
@@ -93,13 +92,6 @@ class GraphPlan:
     def colT(self):
         self.bwd  # noqa: B018
         return self._colT
-
-    @property
-    def row_of_pos(self):
-        """destination row of every forward sorted position (int32 [E])."""
-        if self._row_of_pos is None:
-            self._row_of_pos = self.engine.gather_i32(self.index[1], self.fwd.perm)
-        return self._row_of_pos
 
     @property
     def posT(self):
