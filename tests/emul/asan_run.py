@@ -26,7 +26,7 @@ cases = [
     ("fwd_bwd", lambda: pc.check_segment_fwd_bwd(eng, dev, golden)), ("special", lambda: pc.check_special_values(eng, dev, golden)),
     ("spmm", lambda: pc.check_spmm_golden(eng, dev, golden)), ("layers", lambda: pc.check_layers_golden(eng, dev, golden)),
     ("random", lambda: pc.check_random_vs_oracle(eng, dev, o, sizes=[(50, 400)])), ("edge", lambda: pc.check_edge_cases(eng, dev, o)),
-    ("convert", lambda: pc.check_convert(eng, dev)), ("colsum", lambda: pc.check_colsum(eng, dev)), ("sampler", lambda: pc.check_sampler(eng, dev, o)), ("bias_act", lambda: pc.check_bias_act(eng, dev)), ("spmm_bias_act", lambda: pc.check_spmm_bias_act(eng, dev)), ("strided", lambda: pc.check_strided_accumulate(eng, dev, o)),
+    ("convert", lambda: pc.check_convert(eng, dev)), ("colsum", lambda: pc.check_colsum(eng, dev)), ("sampler", lambda: pc.check_sampler(eng, dev, o)), ("bias_act", lambda: pc.check_bias_act(eng, dev)), ("spmm_bias_act", lambda: pc.check_spmm_bias_act(eng, dev)), ("strided", lambda: pc.check_strided_accumulate(eng, dev, o)), ("gat_dropout", lambda: pc.check_gat_dropout(eng, dev, o)),
 ]
 for name, fn in cases:
     fn()
