@@ -74,7 +74,8 @@ def main():
         w = calc_gcn_norm(ei, n).contiguous()
         for K in (256, 64, 47, 16):
             x = torch.randn(n, K, generator=g, device=dev)
-            variants = [("u4 swz1", 4, 1), ("u8 swz1", 8, 1), ("u4 swz0", 4, 0)] if K == 256 else [("u4 swz1", 4, 1)]
+            # (u4 swz0) is the shipped default; the XCD remap (swz1) and deeper unroll are A/B variants
+            variants = [("u4 swz0", 4, 0), ("u8 swz0", 8, 0), ("u4 swz1", 4, 1)] if K == 256 else [("u4 swz0", 4, 0)]
             acc = {v[0]: [] for v in variants}
             accT = []
             for _ in range(args.rounds):
@@ -83,7 +84,7 @@ def main():
                     eng.set_option("xcd_swizzle", sw)
                     acc[name].append(eng.time_spmm_sum(gp, w, x, reps=args.reps))
                 eng.set_option("unroll", 4)
-                eng.set_option("xcd_swizzle", 1)
+                eng.set_option("xcd_swizzle", 0)
                 accT.append(ev_time(lambda: eng._spmm_fwd("sum", gp.bwd, gp.colT, w, x, n), args.reps))
             for name, _, _ in variants:
                 report(f"spmm_sum fwd [{order}/{relabel}] {name}", acc[name], E, n, K)
