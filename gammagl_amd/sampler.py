@@ -51,7 +51,7 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None):
     local = rank[inv[B:]]
     # every row's columns ascending by local id (sample.cpp:112-118)
     if E > 0:
-        row = torch.repeat_interleave(torch.arange(B, device=dev), deg)
+        row = torch.repeat_interleave(torch.arange(B, device=dev), deg, output_size=E)  # size known: no sync
         perm = torch.empty(E, dtype=torch.int32, device=dev)
         wsb = eng.lib.ggl_sort_edges_workspace_bytes(E, int(out_n_id.shape[0]))
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
@@ -94,7 +94,8 @@ class NeighborSampler:
         for size in self.sizes:
             n_dst = int(n_id.shape[0])
             rowptr, col, n_id, e_pos = sample_adj(self.rowptr, self.col, n_id, size, replace=False, eng=self.eng)
-            row = torch.repeat_interleave(torch.arange(n_dst, device=col.device), rowptr[1:] - rowptr[:-1])
+            row = torch.repeat_interleave(torch.arange(n_dst, device=col.device), rowptr[1:] - rowptr[:-1],
+                                          output_size=int(col.shape[0]))
             block = torch.stack([col, row])
             adjs.append(EdgeIndex(block, self.value[e_pos], (int(n_id.shape[0]), n_dst), rowptr, size))
             if size >= 0:  # rows hold <= fan-out entries: the aggregate's plan needs neither sort nor sync
