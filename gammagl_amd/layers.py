@@ -214,9 +214,14 @@ class GATConv(MessagePassing):
 
 
 class FusedGATConv(GATConv):
-    """Same parameters and math as GATConv; logits, softmax and aggregate run in one HIP kernel."""
+    """Same parameters and math as GATConv; logits, softmax, attention dropout and aggregate run in one HIP
+    kernel per direction.  The reference layer (fusedgat_conv.py:89-130) optionally takes a prebuilt
+    CSR/CSC (`row_ptr`, `col_ind`, `col_ptr`, `row_ind`, `permute`) to skip its numpy preprocessing; here
+    the destination-sorted plan is built on the device once per edge_index and cached, so those keywords are
+    accepted and not needed.  Aggregates into edge_index[1] like GATConv (the reference's fused layer builds
+    its CSR on edge_index[0], which only coincides on symmetric graphs — SURVEY.md §8a row G)."""
 
-    def forward(self, x, edge_index, num_nodes=None):
+    def forward(self, x, edge_index, num_nodes=None, **kwargs):
         x = (x @ self.w).reshape(-1, self.heads, self.out_channels)
         C = self.out_channels
         el = (x * self.att[:, :, :C]).sum(dim=-1)   # source term  a_src . x_j
