@@ -393,6 +393,10 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
                         f"weights precomputed (GCNConv norm='none' + calc_gcn_norm edge_weight)",
             "parallelism": f"node-partition x{world}, 1-hop halo all-to-all-v" if world > 1 else "1 GPU",
             "rank0_local_edges": pg.e_local, "rank0_halo_rows": pg.n_halo, "rank0_send_rows": pg.n_send,
+            # rows received + sent by rank 0 per step: each aggregate moves the halo rows in (forward) or their
+            # gradients out (backward) and the mirror image for the rows other ranks need, at the layer's width
+            "rank0_halo_GB_per_step": round(2 * (pg.n_halo + pg.n_send) * 4 *
+                                            sum([args.hidden] * (args.layers - 1) + [n_cls + (-n_cls) % 4]) / 1e9, 3),
             "setup_s": round(t_gen, 2), "loss": float(lsum)},
         "roofline": {"bound": "hbm", "kernel": f"row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, K={K}, rank 0 local rows"
                                f"{', halo-source edges' if use_halo else ''})",
