@@ -159,6 +159,9 @@ class SAGEConv(MessagePassing):
         num_nodes = int(dst_feat.shape[0])
         if self.aggr == 'mean':
             src_feat = self.fc_neigh(src_feat)
+            # message() + unsorted_segment_mean on purpose: a sampled block is a NEW edge list every batch, and
+            # the fused SpMM-mean would need its transposed plan (a sort + host syncs) for the backward —
+            # measured 4.5 vs 3.1 ms per batch (2048 seeds, [25,10]); the segment route needs none
             out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='mean')
         elif self.aggr == 'gcn':
             src_feat = self.fc_neigh(src_feat)
