@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import engine as _engine
-from .dense import Linear
+from .dense import Linear, _LinearFn
 from .mpops import (gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
                     unsorted_segment_sum, use_ext)
 
@@ -115,26 +115,56 @@ class GCNConv(MessagePassing):
         nn.init.xavier_uniform_(self.linear.weight)
         self.bias = nn.Parameter(torch.zeros(1, out_channels)) if add_bias else None
 
-    def forward(self, x, edge_index, edge_weight=None, num_nodes=None):
-        x = self.linear(x)
-        src, dst = edge_index[0], edge_index[1]
+    def _norm_weights(self, edge_index, edge_weight, num_nodes, device):
+        """gcn_conv.py:84-102: deg^-1/2 (or 1/deg) of the source and/or destination end of every edge, degrees
+        counted on the edge list as given.  The reference recomputes this in every layer of every step; with
+        edge_weight=None it depends on the graph alone, so it is computed once per edge_index and kept on the
+        cached GraphPlan (the same tensor every call also lets the SpMM stream its sorted copy)."""
+        gp = None
         if edge_weight is None:
-            edge_weight = torch.ones((edge_index.shape[1],), device=x.device)
-        edge_weight = edge_weight.reshape(-1)
-        weights = edge_weight
-        num_nodes = x.shape[0]
+            gp = _engine().graph_plan(edge_index, num_nodes)
+            hit = gp.aux.get(("gcn_norm", self._norm))
+            if hit is not None:
+                return hit
+        src, dst = edge_index[0], edge_index[1]
+        ew = torch.ones((edge_index.shape[1],), device=device) if edge_weight is None else edge_weight.reshape(-1)
+        weights = ew
         if self._norm in ['left', 'both']:
             deg = degree(src, num_nodes=num_nodes, dtype=torch.float32)
             norm = deg.pow(-0.5) if self._norm == 'both' else 1.0 / deg
-            weights = norm[src] * edge_weight
+            weights = norm[src] * ew
         if self._norm in ['right', 'both']:
             deg = degree(dst, num_nodes=num_nodes, dtype=torch.float32)
             norm = deg.pow(-0.5) if self._norm == 'both' else 1.0 / deg
             weights = weights * norm[dst]
-        out = self.propagate(x, edge_index, edge_weight=weights, num_nodes=num_nodes)
-        if self.bias is not None:
-            out = out + self.bias
-        return out
+        if gp is not None:
+            gp.aux[("gcn_norm", self._norm)] = weights
+        return weights
+
+    def forward(self, x, edge_index, edge_weight=None, num_nodes=None, _epilogue=None):
+        """`_epilogue=(relu, p_drop, training)` (used by GCNModel): the ReLU and dropout the model applies right
+        after this layer, fused with the bias into the aggregate's store (or one pass after it)."""
+        n_out = self.linear.weight.shape[0]
+        pad = (-n_out) % 4 if n_out >= 8 else 0
+        if pad and x.dim() == 2:  # class-count widths: 47 -> 48 columns inside the GEMM, dropped at the end
+            x = _LinearFn.apply(x.contiguous(), torch.nn.functional.pad(self.linear.weight, (0, 0, 0, pad)))
+        else:
+            x = self.linear(x)
+        num_nodes = x.shape[0]
+        weights = self._norm_weights(edge_index, edge_weight, num_nodes, x.device)
+        relu, p_drop, training = _epilogue if _epilogue is not None else (False, 0.0, False)
+        bias = self.bias
+        if pad and bias is not None:
+            bias = torch.nn.functional.pad(bias, (0, pad))
+        if x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0:
+            eng = _engine()
+            out = eng.spmm_bias_act(eng.graph_plan(edge_index, num_nodes), weights, x, bias, relu=relu,
+                                    p_drop=p_drop, training=training)
+        else:
+            out = self.propagate(x, edge_index, edge_weight=weights, num_nodes=num_nodes)
+            if bias is not None or relu or p_drop > 0:
+                out = _engine().bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
+        return out[:, :n_out] if pad else out
 
     def message_aggregate(self, x, edge_index, edge_weight=None, aggr="sum"):  # gcn_conv.py:110-115
         if edge_weight is None:
@@ -253,9 +283,10 @@ class GCNModel(nn.Module):
         if self.num_layers == 1:
             return self.conv[0](x, edge_index, edge_weight, num_nodes)
         for i in range(self.num_layers - 1):
-            x = self.conv[i](x, edge_index, edge_weight, num_nodes)
-            x = torch.relu(x)
-            x = self.dropout(x)
+            # relu(conv(x)) then dropout (models/gcn.py:55-59), handed to the layer so that bias, ReLU and
+            # dropout ride on the aggregate's store instead of three more passes over [N, hidden]
+            x = self.conv[i](x, edge_index, edge_weight, num_nodes,
+                             _epilogue=(True, self.dropout.p, self.training))
         return self.conv[-1](x, edge_index, edge_weight, num_nodes)
 
 

@@ -67,7 +67,7 @@ class SegPlan:
 class GraphPlan:
     """CSR (rows = destination) and, lazily, CSC (rows = source) plans of one edge_index."""
 
-    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT")
+    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT", "aux")
 
     def __init__(self, engine, index, n_dst, n_src):
         self.engine = engine
@@ -80,6 +80,7 @@ class GraphPlan:
         engine._check_range(index[0], self.N_src)
         self.col = engine.gather_i32(index[0], self.fwd.perm)
         self._bwd = self._colT = self._posT = None
+        self.aux = {}  # graph-constant tensors callers derive from this edge list (e.g. GCN edge norms)
 
     @property
     def bwd(self):

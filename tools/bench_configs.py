@@ -45,7 +45,7 @@ if "2" in which:
     x = torch.randn(n, f, generator=g, device=dev)
     y = torch.randint(0, c, (n,), generator=g, device=dev)
     idx = torch.randperm(n, generator=g, device=dev)[: n // 2]
-    tr = GCNTrainer(f, 256, c, num_layers=3, device=dev)  # faithful GCNConv: degrees recomputed per layer
+    tr = GCNTrainer(f, 256, c, num_layers=3, device=dev)  # GCNModel / GCNConv(norm='both') layer classes (norm weights cached per edge_index)
     ms = timeit(lambda: tr.step(x, ei, y, idx, n), reps=10, warm=3)
     print(f"[2] arxiv-sized 3-layer GCN h=256 train step (GCNConv norm='both', fused gspmm route): {ms:.2f} ms "
           f"-> {6 * E / ms / 1e6:.2f} Gedges/s", flush=True)
