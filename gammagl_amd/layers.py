@@ -172,6 +172,9 @@ class GCNConv(MessagePassing):
         return gspmm(edge_index, edge_weight, x, aggr)
 
 
+FUSED_MEAN_MIN_EDGES = 2_000_000  # SAGEConv(mean): fused rectangular SpMM-mean from this many edges up
+
+
 class SAGEConv(MessagePassing):
     def __init__(self, in_channels, out_channels, activation=None, aggr="mean", add_bias=True):
         super().__init__()
@@ -189,10 +192,16 @@ class SAGEConv(MessagePassing):
         num_nodes = int(dst_feat.shape[0])
         if self.aggr == 'mean':
             src_feat = self.fc_neigh(src_feat)
-            # message() + unsorted_segment_mean on purpose: a sampled block is a NEW edge list every batch, and
-            # the fused SpMM-mean would need its transposed plan (a sort + host syncs) for the backward —
-            # measured 4.5 vs 3.1 ms per batch (2048 seeds, [25,10]); the segment route needs none
-            out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='mean')
+            # Sampled blocks stay on message() + unsorted_segment_mean: a block is a NEW edge list every batch
+            # and the fused SpMM-mean would need its transposed plan (a sort + host syncs) for the backward —
+            # measured 4.5 vs 3.1 ms per batch (2048 seeds, [25,10]).  A big (full-graph) edge list is the
+            # other way round: the [E, K] message tensor costs far more than a plan that is built once.
+            if edge.shape[1] >= FUSED_MEAN_MIN_EDGES and src_feat.dim() == 2 and src_feat.dtype == torch.float32:
+                eng = _engine()
+                gp = eng.graph_plan(edge, num_nodes, int(src_feat.shape[0]))
+                out = eng.spmm(gp, None, src_feat, "mean")
+            else:
+                out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='mean')
         elif self.aggr == 'gcn':
             src_feat = self.fc_neigh(src_feat)
             n = int(1 + edge[0].max())

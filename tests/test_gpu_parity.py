@@ -212,6 +212,21 @@ def test_layers_fused_equals_unfused(eng, dev):
     cnt = torch.bincount(blk[1], minlength=nd).clamp(min=1).unsqueeze(1)
     agg = torch.zeros(nd, 16, device=dev).index_add_(0, blk[1], ref[blk[0]]) / cnt
     torch.testing.assert_close(ys, agg + sage.fc_self(x[:nd]) + sage.bias, rtol=1e-5, atol=1e-5)
+    # the fused rectangular SpMM-mean that big (full-graph) edge lists take == the segment route, values and grads
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    old = layers.FUSED_MEAN_MIN_EDGES
+    try:
+        layers.FUSED_MEAN_MIN_EDGES = 10**12
+        ya = sage((xa, xa[:nd]), blk)
+        layers.FUSED_MEAN_MIN_EDGES = 0
+        yb = sage((xb, xb[:nd]), blk)
+    finally:
+        layers.FUSED_MEAN_MIN_EDGES = old
+    assert torch.equal(ya, yb)  # same sums in the same order, same division
+    ya.square().sum().backward()
+    yb.square().sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-6)
 
 
 def _arxiv(dev, **kw):
