@@ -354,6 +354,149 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(
   }
 }
 
+// ---- wide heads (C > 16), GPU build only.  The lane-per-head walk above reads each lane's C-float strip
+// with C/4 strided 16-byte loads and collapsed on the Reddit GAT's last layer (8 heads x 41 classes: 222 ms at
+// C = 40, 870 ms at C = 41).  Here a GROUP of 2^LOGG lanes owns the row (or hub chunk) and the lanes split
+// the CHANNELS of every head: lane s holds g_i[h, 4s..4s+3] for all HH heads in registers, reads the same
+// slice of x_j per head (a head's strip is one coalesced read, the HH reads of an edge cover its whole
+// contiguous row), and the per-edge dots <g_i[h,:], x_j[h,:]> are reduced across the group with a butterfly
+// of wave shuffles — the one place this library reduces across lanes: GAT gradients are held to 1e-5
+// relative, not bit-exact, so the association may change.  After the butterflies every lane holds every
+// dot; lane h finishes head h (alpha, de, running ger sum in position order).  The host emulation build
+// cannot shuffle between its sequentially executed lanes and keeps using gat_bwd_dst_kernel for every C.
+#ifndef GGL_EMULATE
+template <int LOGG> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = (1 << LOGG) >> 1; o > 0; o >>= 1) v = __fadd_rn(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <int VEC, int LOGG, int HH>
+__global__ __launch_bounds__(kBlock) void gat_bwd_dst_wide_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ er,
+    const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ out,
+    const float *__restrict__ rowmax, const float *__restrict__ rowden, float *__restrict__ alpha,
+    float *__restrict__ de, float *__restrict__ ger, float *__restrict__ pger,
+    const int64_t *__restrict__ rng, const GatDims d) {
+  constexpr int G = 1 << LOGG;
+  static_assert(G >= HH, "lane h finishes head h");
+  const int64_t H = HH, C = d.C, K = d.K;
+  const int64_t item = thread_id() >> LOGG;
+  const int sub = (int)(threadIdx.x & (G - 1));
+  if (item >= d.n_chunks + d.N) return;  // whole groups leave together: the shuffles below stay in-group
+  const bool is_chunk = item < d.n_chunks;
+  int64_t row, beg, end;
+  if (is_chunk) {
+    int64_t lo = 0, hi = d.n_long - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (chunk_ptr[mid] <= item) lo = mid; else hi = mid - 1;
+    }
+    row = long_rows[lo];
+    beg = rowptr[row] + (item - chunk_ptr[lo]) * d.chunk;
+    const int64_t rend = rowptr[row + 1];
+    end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
+  } else {
+    const int64_t slot = item - d.n_chunks;
+    row = row_order ? (int64_t)row_order[slot] : slot;
+    beg = rowptr[row];
+    end = rowptr[row + 1];
+    if (end - beg > d.chunk) return;
+  }
+  const int64_t c0 = (int64_t)sub * VEC;
+  const bool act = c0 < C;  // C % VEC == 0 on this path
+  float gr[HH][VEC], dots[HH];
+#pragma unroll
+  for (int h = 0; h < HH; ++h) {
+    float ov[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { gr[h][q] = 0.0f; ov[q] = 0.0f; }
+    if (act) {
+      F32V<VEC>::load(g + row * K + h * C + c0, gr[h]);
+      F32V<VEC>::load(out + row * K + h * C + c0, ov);
+    }
+    float t = 0.0f;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) t = __fadd_rn(t, __fmul_rn(gr[h][q], ov[q]));
+    dots[h] = group_sum<LOGG>(t);
+  }
+  // lane h keeps the row constants of head h
+  float my_dot = 0.0f, my_er = 0.0f, my_m = 0.0f, my_inv = 1.0f;
+#pragma unroll
+  for (int h = 0; h < HH; ++h)
+    if (sub == h) my_dot = dots[h];
+  if (sub < HH) {
+    my_er = er[row * H + sub];
+    my_m = rowmax[row * H + sub];
+    my_inv = __fadd_rn(rowden[row * H + sub], 1e-16f);
+  }
+  const uint64_t seed = d.drop_thresh ? (uint64_t)rng[0] : 0, offset = d.drop_thresh ? (uint64_t)rng[1] : 0;
+  float gsum = 0.0f;
+  auto one_edge = [&](int64_t p, int64_t j, const float (&xv)[HH][VEC]) {
+    float part[HH];
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+      float t = 0.0f;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) t = __fadd_rn(t, __fmul_rn(gr[h][q], xv[h][q]));
+      part[h] = group_sum<LOGG>(t);
+    }
+    if (sub < HH) {
+      float da = 0.0f;
+#pragma unroll
+      for (int h = 0; h < HH; ++h)
+        if (sub == h) da = part[h];
+      const float raw = __fadd_rn(el[j * H + sub], my_er);
+      const float al = __fdiv_rn(GGL_EXPF(__fadd_rn(lrelu(raw, d.slope), -my_m)), my_inv);
+      float alk = al;
+      if (d.drop_thresh) {
+        const bool keep = drop_word(p, H, sub, offset, seed) >= d.drop_thresh;
+        alk = keep ? __fmul_rn(al, d.drop_scale) : 0.0f;
+        da = keep ? __fmul_rn(da, d.drop_scale) : 0.0f;
+      }
+      const float ds = __fmul_rn(al, __fadd_rn(da, -my_dot));
+      const float dv = raw > 0.0f ? ds : __fmul_rn(ds, d.slope);
+      alpha[(p * H + sub) * d.es] = alk;
+      de[(p * H + sub) * d.es] = dv;
+      gsum = __fadd_rn(gsum, dv);
+    }
+  };
+  int64_t p = beg;
+  for (; p + 2 <= end; p += 2) {  // two feature rows (2 x HH slices per lane) in flight
+    const int64_t j0 = col[p], j1 = col[p + 1];
+    float x0[HH][VEC], x1[HH][VEC];
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) { x0[h][q] = 0.0f; x1[h][q] = 0.0f; }
+      if (act) {
+        F32V<VEC>::load(x + j0 * K + h * C + c0, x0[h]);
+        F32V<VEC>::load(x + j1 * K + h * C + c0, x1[h]);
+      }
+    }
+    one_edge(p, j0, x0);
+    one_edge(p + 1, j1, x1);
+  }
+  for (; p < end; ++p) {
+    const int64_t j0 = col[p];
+    float x0[HH][VEC];
+#pragma unroll
+    for (int h = 0; h < HH; ++h) {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) x0[h][q] = 0.0f;
+      if (act) F32V<VEC>::load(x + j0 * K + h * C + c0, x0[h]);
+    }
+    one_edge(p, j0, x0);
+  }
+  if (sub < HH) {
+    if (is_chunk) pger[item * H + sub] = gsum;
+    else ger[row * H + sub] = gsum;
+  }
+}
+#endif  // !GGL_EMULATE
+
 __global__ __launch_bounds__(kBlock) void gat_bwd_dst_final_kernel(const int32_t *__restrict__ long_rows,
                                                                    const int64_t *__restrict__ chunk_ptr,
                                                                    const float *__restrict__ pger,
@@ -600,6 +743,48 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
   hipStream_t s = as_stream(stream);
   const bool vec4 = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
                     ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) && !options().force_generic;
+#ifndef GGL_EMULATE
+  // wide heads: lanes split the channels, shuffle-reduced dots (gat_bwd_dst_wide_kernel); needs a head count
+  // the kernel is instantiated for and a head that fits one group (C <= 64 * vec)
+  {
+    const int vec = vec4 ? 4 : 1;
+    const bool h_ok = (H == 1 || H == 2 || H == 4 || H == 8 || H == 16);
+    if (C > 16 && h_ok && C <= 64 * vec && !options().force_generic) {
+      int logg = pow2_log2(ceil_div(C, vec));
+      if (logg < 4) logg = 4;  // >= 16 lanes: covers H <= 16 finishing lanes
+      const int64_t wgrid = ceil_div(items << logg, (int64_t)kBlock);
+#define GGL_GAT_WIDE(V, LG, HH)                                                                          \
+  GGL_LAUNCH((gat_bwd_dst_wide_kernel<V, LG, HH>), wgrid, kBlock, s, plan->rowptr, col, order,            \
+             plan->long_rows, plan->chunk_ptr, el, er, x, g, out, rowmax, rowden, alpha, de, ger, pger,   \
+             rng_used, d)
+#define GGL_GAT_WIDE_H(V, LG)                                                                            \
+  do {                                                                                                   \
+    if (H == 1) GGL_GAT_WIDE(V, LG, 1);                                                                  \
+    else if (H == 2) GGL_GAT_WIDE(V, LG, 2);                                                             \
+    else if (H == 4) GGL_GAT_WIDE(V, LG, 4);                                                             \
+    else if (H == 8) GGL_GAT_WIDE(V, LG, 8);                                                             \
+    else GGL_GAT_WIDE(V, LG, 16);                                                                        \
+  } while (0)
+      if (vec4) {
+        if (logg == 4) GGL_GAT_WIDE_H(4, 4);
+        else if (logg == 5) GGL_GAT_WIDE_H(4, 5);
+        else GGL_GAT_WIDE_H(4, 6);
+      } else {
+        if (logg <= 5) { logg = 5; GGL_GAT_WIDE_H(1, 5); }
+        else GGL_GAT_WIDE_H(1, 6);
+      }
+#undef GGL_GAT_WIDE_H
+#undef GGL_GAT_WIDE
+      GGL_LAUNCH_CHECK();
+      if (plan->n_long > 0) {
+        GGL_LAUNCH((gat_bwd_dst_final_kernel), grid_for(plan->n_long * H), kBlock, s, plan->long_rows,
+                   plan->chunk_ptr, (const float *)pger, ger, plan->n_long, H);
+        GGL_LAUNCH_CHECK();
+      }
+      return GGL_OK;
+    }
+  }
+#endif
 #define GGL_GAT_DST(V, CR)                                                                              \
   GGL_LAUNCH((gat_bwd_dst_kernel<V, CR>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,    \
              plan->chunk_ptr, el, er, x, g, out, rowmax, rowden, alpha, de, ger, pger, rng_used, d)

@@ -264,13 +264,17 @@ class FusedGATConv(GATConv):
     its CSR on edge_index[0], which only coincides on symmetric graphs — SURVEY.md §8a row G)."""
 
     def forward(self, x, edge_index, num_nodes=None, **kwargs):
-        x = (x @ self.w).reshape(-1, self.heads, self.out_channels)
-        C = self.out_channels
-        el = (x * self.att[:, :, :C]).sum(dim=-1)   # source term  a_src . x_j
-        er = (x * self.att[:, :, C:]).sum(dim=-1)   # destination term a_dst . x_i
+        H, C = self.heads, self.out_channels
+        w = self.w
+        pad = (-C) % 4 if C >= 8 else 0
+        if pad:  # e.g. 41 classes per head: 44 channels inside the GEMM keep the kernels on 16-byte slices
+            w = torch.nn.functional.pad(w.reshape(-1, H, C), (0, pad)).reshape(-1, H * (C + pad))
+        x = (x @ w).reshape(-1, H, C + pad)
+        el = (x[:, :, :C] * self.att[:, :, :C]).sum(dim=-1)   # source term  a_src . x_j
+        er = (x[:, :, :C] * self.att[:, :, C:]).sum(dim=-1)   # destination term a_dst . x_i
         x = _engine().gat_fused(edge_index, el, er, x, self.negative_slope, num_nodes=num_nodes,
                                 dropout_rate=self.dropout_rate, training=self.training)
-        return self._finish(x)
+        return self._finish(x[:, :, :C] if pad else x)
 
 
 class GCNModel(nn.Module):

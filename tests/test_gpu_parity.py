@@ -204,6 +204,21 @@ def test_layers_fused_equals_unfused(eng, dev):
     yb.square().sum().backward()
     torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(gat.att.grad, fgat.att.grad, rtol=2e-4, atol=2e-5)
+    # wide, non-multiple-of-4 heads (the Reddit GAT's last layer: 41 classes per head, averaged): channels
+    # padded to 44 inside the layer's GEMM, wide-head backward kernel
+    gat2 = layers.GATConv(24, 41, heads=8, concat=False).to(dev)
+    fgat2 = layers.FusedGATConv(24, 41, heads=8, concat=False).to(dev)
+    fgat2.load_state_dict(gat2.state_dict())
+    xa2 = x.clone().requires_grad_(True)
+    xb2 = x.clone().requires_grad_(True)
+    ya2, yb2 = gat2(xa2, ei, N), fgat2(xb2, ei, N)
+    assert yb2.shape == (N, 41)
+    torch.testing.assert_close(ya2, yb2, rtol=1e-5, atol=1e-6)
+    ya2.square().sum().backward()
+    yb2.square().sum().backward()
+    torch.testing.assert_close(xa2.grad, xb2.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(gat2.att.grad, fgat2.att.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(gat2.w.grad, fgat2.w.grad, rtol=2e-4, atol=2e-5)
     sage = layers.SAGEConv(24, 16, aggr="mean").to(dev)
     nd = 200  # rectangular block: N_src = 500 -> N_dst = 200 (sage_conv.py:79-81)
     blk = ei[:, ei[1] < nd]
