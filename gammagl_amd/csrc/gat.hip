@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_wide_kernel(
     const int64_t *__restrict__ rng, const GatDims d) {
   constexpr int G = 1 << LOGG;
   static_assert(G >= HH, "lane h finishes head h");
-  const int64_t H = HH, C = d.C, K = d.K;
+  const int64_t H = d.H, C = d.C, K = d.K;  // H <= HH: HH is the compile-time bound of the head loops
   const int64_t item = thread_id() >> LOGG;
   const int sub = (int)(threadIdx.x & (G - 1));
   if (item >= d.n_chunks + d.N) return;  // whole groups leave together: the shuffles below stay in-group
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_wide_kernel(
     float ov[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { gr[h][q] = 0.0f; ov[q] = 0.0f; }
-    if (act) {
+    if (act && h < H) {
       F32V<VEC>::load(g + row * K + h * C + c0, gr[h]);
       F32V<VEC>::load(out + row * K + h * C + c0, ov);
     }
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_wide_kernel(
 #pragma unroll
   for (int h = 0; h < HH; ++h)
     if (sub == h) my_dot = dots[h];
-  if (sub < HH) {
+  if (sub < H) {
     my_er = er[row * H + sub];
     my_m = rowmax[row * H + sub];
     my_inv = __fadd_rn(rowden[row * H + sub], 1e-16f);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_wide_kernel(
       for (int q = 0; q < VEC; ++q) t = __fadd_rn(t, __fmul_rn(gr[h][q], xv[h][q]));
       part[h] = group_sum<LOGG>(t);
     }
-    if (sub < HH) {
+    if (sub < H) {
       float da = 0.0f;
 #pragma unroll
       for (int h = 0; h < HH; ++h)
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_wide_kernel(
     for (int h = 0; h < HH; ++h) {
 #pragma unroll
       for (int q = 0; q < VEC; ++q) { x0[h][q] = 0.0f; x1[h][q] = 0.0f; }
-      if (act) {
+      if (act && h < H) {
         F32V<VEC>::load(x + j0 * K + h * C + c0, x0[h]);
         F32V<VEC>::load(x + j1 * K + h * C + c0, x1[h]);
       }
@@ -486,11 +486,11 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_wide_kernel(
     for (int h = 0; h < HH; ++h) {
 #pragma unroll
       for (int q = 0; q < VEC; ++q) x0[h][q] = 0.0f;
-      if (act) F32V<VEC>::load(x + j0 * K + h * C + c0, x0[h]);
+      if (act && h < H) F32V<VEC>::load(x + j0 * K + h * C + c0, x0[h]);
     }
     one_edge(p, j0, x0);
   }
-  if (sub < HH) {
+  if (sub < H) {
     if (is_chunk) pger[item * H + sub] = gsum;
     else ger[row * H + sub] = gsum;
   }
@@ -748,7 +748,7 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
   // the kernel is instantiated for and a head that fits one group (C <= 64 * vec)
   {
     const int vec = vec4 ? 4 : 1;
-    const bool h_ok = (H == 1 || H == 2 || H == 4 || H == 8 || H == 16);
+    const bool h_ok = H <= 16;  // instantiated head-loop bounds: 1, 2, 4, 8, 16 (the next one >= H is used)
     if (C > 16 && h_ok && C <= 64 * vec && !options().force_generic) {
       int logg = pow2_log2(ceil_div(C, vec));
       if (logg < 4) logg = 4;  // >= 16 lanes: covers H <= 16 finishing lanes
@@ -761,8 +761,8 @@ extern "C" int ggl_gat_fused_bwd_dst(const ggl_segplan_t *plan, const int32_t *c
   do {                                                                                                   \
     if (H == 1) GGL_GAT_WIDE(V, LG, 1);                                                                  \
     else if (H == 2) GGL_GAT_WIDE(V, LG, 2);                                                             \
-    else if (H == 4) GGL_GAT_WIDE(V, LG, 4);                                                             \
-    else if (H == 8) GGL_GAT_WIDE(V, LG, 8);                                                             \
+    else if (H <= 4) GGL_GAT_WIDE(V, LG, 4);                                                             \
+    else if (H <= 8) GGL_GAT_WIDE(V, LG, 8);                                                             \
     else GGL_GAT_WIDE(V, LG, 16);                                                                        \
   } while (0)
       if (vec4) {

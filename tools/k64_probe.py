@@ -18,7 +18,7 @@ ei = rmat_graph(n, e, seed=0, device=dev)
 E = ei.shape[1]
 w = calc_gcn_norm(ei, n).contiguous()
 gp = eng.graph_plan(ei, n)
-for K in (32, 64, 128):
+for K in [int(k) for k in os.environ.get("KS", "32,64,128").split(",")]:
     x = torch.randn(n, K, device=dev)
     line = f"K={K:4d}:"
     for fg in (0, 1):
