@@ -810,6 +810,12 @@ class Engine:
         gp, weight, x = self._spmm_args(index, weight, x)
         if weight is None or weight.dim() != 2 or weight.shape[1] != x.shape[1]:
             raise RuntimeError("bspmm expects weight of shape [num_edges, heads]")
+        C = int(x.shape[2])
+        if C % 4 != 0 and C >= 8 and gp.E >= 8 * x.shape[0]:
+            # odd channel counts (41 classes per head ...): one zero-padded copy of x keeps the row walks and the
+            # per-edge weight-gradient dots on 16-byte slices; the pad channels sum to zero and are dropped
+            xp = torch.nn.functional.pad(x, (0, (-C) % 4))
+            return self.BSpMMSum.apply(gp, weight, xp.contiguous())[:, :, :C]
         return self.BSpMMSum.apply(gp, weight, x)
 
     def gat_fused(self, index, el, er, x, negative_slope=0.2, num_nodes=None, dropout_rate=0.0, training=True):
