@@ -55,7 +55,9 @@ __global__ __launch_bounds__(kBlock) void sample_count_kernel(const int64_t *__r
   }
 }
 
-// one thread per seed row; writes positions (e_pos = index into col) and the neighbour ids
+// one thread per seed row that needs a random draw; writes its positions (e_pos = index into col).  Rows
+// that keep their whole neighbourhood are left to sample_emit_kernel, which is parallel over OUTPUT positions
+// (a thread copying a 100 000-neighbour hub serially made a full-neighbourhood hop 8.7 ms).
 __global__ __launch_bounds__(kBlock) void sample_pick_kernel(const int64_t *__restrict__ rowptr,
                                                              const int64_t *__restrict__ col,
                                                              const int64_t *__restrict__ seeds, int64_t B,
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void sample_pick_kernel(const int64_t *__re
     const int64_t beg = rowptr[n], deg = rowptr[n + 1] - beg;
     const int64_t o = out_rowptr[i], k = out_rowptr[i + 1] - o;
     if (fanout < 0 || (!replace && deg <= fanout)) {
-      for (int64_t j = 0; j < k; ++j) e_pos[o + j] = beg + j;  // the whole neighbourhood, in CSR order
+      continue;  // the whole neighbourhood, in CSR order: sample_emit_kernel
     } else if (replace) {
       for (int64_t j = 0; j < k; ++j) e_pos[o + j] = beg + bounded(philox_u32((uint64_t)i, (uint64_t)j, seed, offset), deg);
     } else {  // Floyd: k = fanout distinct positions out of deg
@@ -82,7 +84,36 @@ __global__ __launch_bounds__(kBlock) void sample_pick_kernel(const int64_t *__re
         e_pos[o + s] = beg + (taken ? j : t);
       }
     }
-    for (int64_t j = 0; j < k; ++j) nbr[o + j] = col[e_pos[o + j]];
+  }
+}
+
+// one thread per output position q: the seed row that owns q (binary search in out_rowptr), the CSR position
+// for rows kept whole, and the neighbour id for every row
+__global__ __launch_bounds__(kBlock) void sample_emit_kernel(const int64_t *__restrict__ rowptr,
+                                                             const int64_t *__restrict__ col,
+                                                             const int64_t *__restrict__ seeds, int64_t B,
+                                                             int64_t fanout, int replace,
+                                                             const int64_t *__restrict__ out_rowptr,
+                                                             int64_t *__restrict__ e_pos,
+                                                             int64_t *__restrict__ nbr) {
+  const int64_t total = out_rowptr[B];
+  const int64_t stride = grid_threads();
+  for (int64_t q = thread_id(); q < total; q += stride) {
+    int64_t lo = 0, hi = B - 1;  // last i with out_rowptr[i] <= q
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (out_rowptr[mid] <= q) lo = mid; else hi = mid - 1;
+    }
+    const int64_t n = seeds[lo];
+    const int64_t beg = rowptr[n], deg = rowptr[n + 1] - beg;
+    int64_t pos;
+    if (fanout < 0 || (!replace && deg <= fanout)) {
+      pos = beg + (q - out_rowptr[lo]);
+      e_pos[q] = pos;
+    } else {
+      pos = e_pos[q];
+    }
+    nbr[q] = col[pos];
   }
 }
 
@@ -120,6 +151,9 @@ extern "C" int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const 
   hipStream_t s = as_stream(stream);
   GGL_LAUNCH((sample_pick_kernel), grid_for(B), kBlock, s, rowptr, col, seeds, B, fanout, replace,
              out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((sample_emit_kernel), 4096, kBlock, s, rowptr, col, seeds, B, fanout, replace, out_rowptr, e_pos,
+             nbr);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((sample_rng_advance_kernel), 1, 64, s, rng_state);
   GGL_LAUNCH_CHECK();
