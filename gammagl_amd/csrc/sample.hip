@@ -152,8 +152,13 @@ extern "C" int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const 
   GGL_LAUNCH((sample_pick_kernel), grid_for(B), kBlock, s, rowptr, col, seeds, B, fanout, replace,
              out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
   GGL_LAUNCH_CHECK();
-  GGL_LAUNCH((sample_emit_kernel), 4096, kBlock, s, rowptr, col, seeds, B, fanout, replace, out_rowptr, e_pos,
-             nbr);
+#ifdef GGL_EMULATE
+  const int64_t emit_grid = 4;     // grid-stride loop: any grid is correct; the host emulation walks it serially
+#else
+  const int64_t emit_grid = 4096;  // the output size lives on the device (out_rowptr[B]): fixed grid, strided
+#endif
+  GGL_LAUNCH((sample_emit_kernel), emit_grid, kBlock, s, rowptr, col, seeds, B, fanout, replace, out_rowptr,
+             e_pos, nbr);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((sample_rng_advance_kernel), 1, 64, s, rng_state);
   GGL_LAUNCH_CHECK();
