@@ -230,14 +230,14 @@ def test_layers_fused_equals_unfused(eng, dev):
     # the fused rectangular SpMM-mean that big (full-graph) edge lists take == the segment route, values and grads
     xa = x.clone().requires_grad_(True)
     xb = x.clone().requires_grad_(True)
-    old = layers.FUSED_MEAN_MIN_EDGES
+    old = layers.FUSED_MIN_EDGES
     try:
-        layers.FUSED_MEAN_MIN_EDGES = 10**12
+        layers.FUSED_MIN_EDGES = 10**12
         ya = sage((xa, xa[:nd]), blk)
-        layers.FUSED_MEAN_MIN_EDGES = 0
+        layers.FUSED_MIN_EDGES = 0
         yb = sage((xb, xb[:nd]), blk)
     finally:
-        layers.FUSED_MEAN_MIN_EDGES = old
+        layers.FUSED_MIN_EDGES = old
     assert torch.equal(ya, yb)  # same sums in the same order, same division
     ya.square().sum().backward()
     yb.square().sum().backward()

@@ -30,7 +30,7 @@ def ev(fn, reps=3):
 
 
 for thr, label in ((10**12, "message() + unsorted_segment_mean"), (0, "fused SpMM-mean")):
-    layers.FUSED_MEAN_MIN_EDGES = thr
+    layers.FUSED_MIN_EDGES = thr
     f = ev(lambda: conv(x.detach(), ei))
     fb = ev(lambda: conv(x, ei).sum().backward())
     print(f"SAGEConv(128->128, mean) on E={ei.shape[1]}: {label}: fwd {f:.1f} ms, fwd+bwd {fb:.1f} ms  "
