@@ -21,7 +21,7 @@ from torch import nn
 
 from . import engine as _engine
 from .dense import Linear, _LinearFn
-from .mpops import (gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
+from .mpops import (bspmm, gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
                     unsorted_segment_sum, use_ext)
 
 
@@ -113,6 +113,13 @@ class MessagePassing(nn.Module):
             gp = eng.graph_plan(edge_index, int(kwargs['num_nodes']), int(x.shape[0]))
             ew = kwargs.get('edge_weight')
             x = eng.spmm(gp, None if ew is None else ew.reshape(-1).contiguous(), x, aggr)
+        elif (aggr == 'sum' and edge_index.shape[1] >= FUSED_MIN_EDGES and x.dim() == 3 and x.dtype == torch.float32
+              and kwargs.get('edge_weight') is not None and kwargs['edge_weight'].dim() == 2
+              and int(kwargs['num_nodes']) == x.shape[0] and type(self).message is MessagePassing.message
+              and type(self).aggregate is MessagePassing.aggregate):
+            # multi-head messages x[src,h,:] * w[e,h] summed per destination == bspmm (what GATConv's own
+            # commented-out message_aggregate would call, gat_conv.py:124-129): no [E, H, C] message tensor
+            x = bspmm(edge_index, kwargs['edge_weight'], x, 'sum')
         else:
             msg = self.message(x, edge_index, edge_weight=kwargs.get('edge_weight'))
             x = self.aggregate(msg, edge_index, num_nodes=kwargs['num_nodes'], aggr=aggr)
