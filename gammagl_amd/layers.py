@@ -103,7 +103,10 @@ class MessagePassing(nn.Module):
             x = self.message_aggregate(x, edge_index, edge_weight=kwargs.get('edge_weight'), aggr=aggr)
         elif (aggr in ('sum', 'mean') and edge_index.shape[1] >= FUSED_MIN_EDGES and x.dim() == 2
               and x.dtype == torch.float32 and type(self).message is MessagePassing.message
-              and type(self).aggregate is MessagePassing.aggregate):
+              and type(self).aggregate is MessagePassing.aggregate
+              # gspmm treats the edge weight as a constant (gspmm.cpp:30); a weight that needs a gradient
+              # must stay on the message() route, which differentiates through the multiply
+              and not (kwargs.get('edge_weight') is not None and kwargs['edge_weight'].requires_grad)):
             # The default message() (gather * weight) + aggregate() pair IS an SpMM.  A big (full-graph) edge
             # list takes the fused rectangular kernel: no [E, K] message tensor (Reddit-sized SAGEConv layer:
             # 155 -> 14.7 ms forward+backward, 59 GB less HBM), same sums in the same order.  Sampled blocks stay
