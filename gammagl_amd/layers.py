@@ -181,7 +181,13 @@ class GCNConv(MessagePassing):
         bias = self.bias
         if pad and bias is not None:
             bias = torch.nn.functional.pad(bias, (0, pad))
-        if x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0:
+        if weights.requires_grad:
+            # a learnable edge weight: gspmm treats weights as constants (gspmm.cpp:30), so stay on the
+            # message() * weight -> unsorted_segment_sum route, which differentiates through the multiply
+            out = self.aggregate(self.message(x, edge_index, weights), edge_index, num_nodes, 'sum')
+            if bias is not None or relu or p_drop > 0:
+                out = _engine().bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
+        elif x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0:
             eng = _engine()
             out = eng.spmm_bias_act(eng.graph_plan(edge_index, num_nodes), weights, x, bias, relu=relu,
                                     p_drop=p_drop, training=training)

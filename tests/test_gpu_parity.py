@@ -204,6 +204,15 @@ def test_layers_fused_equals_unfused(eng, dev):
     yb.square().sum().backward()
     torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(gat.att.grad, fgat.att.grad, rtol=2e-4, atol=2e-5)
+    # a learnable edge weight keeps its gradient (message route instead of the constant-weight gspmm)
+    ew = torch.rand(ei.shape[1], device=dev, requires_grad=True)
+    conv_n = layers.GCNConv(24, 16, norm='none').to(dev)
+    conv_n(x, ei, ew).sum().backward()
+    ref_gw = torch.zeros_like(ew)
+    with torch.no_grad():
+        h = conv_n.linear(x)
+        ref_gw = h[ei[0]].sum(1)  # d/dw_e sum_i out[i,:] = sum_k h[src_e, k]
+    torch.testing.assert_close(ew.grad, ref_gw, rtol=1e-5, atol=1e-5)
     # wide, non-multiple-of-4 heads (the Reddit GAT's last layer: 41 classes per head, averaged): channels
     # padded to 44 inside the layer's GEMM, wide-head backward kernel
     gat2 = layers.GATConv(24, 41, heads=8, concat=False).to(dev)
