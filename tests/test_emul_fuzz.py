@@ -5,7 +5,6 @@ import os
 import subprocess
 
 import numpy as np
-import pytest
 import torch
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
