@@ -9,7 +9,11 @@ from hypothesis import strategies as st
 import test_emul_fuzz as F
 
 pytestmark = pytest.mark.gpu
-_cfg = dict(max_examples=100, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+import os  # noqa: E402
+
+# defaults: 100 derandomised examples per property; GGL_FUZZ_EXAMPLES / GGL_FUZZ_RANDOM=1 widen a manual hunt
+_cfg = dict(max_examples=int(os.environ.get("GGL_FUZZ_EXAMPLES", "100")), deadline=None,
+            derandomize=os.environ.get("GGL_FUZZ_RANDOM", "0") != "1", suppress_health_check=list(HealthCheck))
 
 
 @pytest.fixture(scope="module")
