@@ -147,7 +147,8 @@ extern "C" int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const 
                                int64_t *e_pos, int64_t *nbr, void *stream) {
   GGL_REQUIRE(B >= 0, GGL_EINVAL, "negative batch");
   if (B == 0) return GGL_OK;
-  GGL_REQUIRE(rowptr && col && seeds && out_rowptr && rng_state && e_pos && nbr, GGL_EINVAL, "NULL pointer");
+  // col may be NULL for a graph without edges: it is only read at positions the rows own
+  GGL_REQUIRE(rowptr && seeds && out_rowptr && rng_state && e_pos && nbr, GGL_EINVAL, "NULL pointer");
   hipStream_t s = as_stream(stream);
   GGL_LAUNCH((sample_pick_kernel), grid_for(B), kBlock, s, rowptr, col, seeds, B, fanout, replace,
              out_rowptr, (const int64_t *)rng_state, e_pos, nbr);

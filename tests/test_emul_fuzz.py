@@ -170,3 +170,116 @@ def run_gat_case(eng, DEV, oracle, prob):
     finally:
         eng.chunk = old
         eng.seg_cache.clear(); eng.graph_cache.clear()
+
+
+@st.composite
+def sampler_problems(draw):
+    N = draw(st.integers(2, 40))
+    E = draw(st.integers(0, 300))
+    B = draw(st.integers(1, min(N, 12)))
+    fanout = draw(st.sampled_from([-1, 1, 2, 5, 25]))
+    replace = draw(st.booleans())
+    seed = draw(st.integers(0, 2**31 - 1))
+    return N, E, B, fanout, replace, seed
+
+
+@settings(max_examples=80, deadline=None, suppress_health_check=list(HealthCheck))
+@given(sampler_problems())
+def test_sample_adj_fuzz(prob):
+    """Structure of a sampled block (sample.cpp:10-135): row sizes, membership in the true neighbourhood,
+    distinctness without replacement, seeds-first relabelling, columns ascending within a row, edge ids."""
+    run_sampler_case(engine(), DEV, prob)
+
+
+def run_sampler_case(eng, DEV, prob):
+    from gammagl_amd.sampler import sample_adj
+
+    N, E, B, fanout, replace, seed = prob
+    rng = np.random.default_rng(seed)
+    dst = np.sort(rng.integers(0, N, size=E)).astype(np.int64)     # CSR rows = destination
+    col = rng.integers(0, N, size=E).astype(np.int64)
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(np.bincount(dst, minlength=N), out=rowptr[1:])
+    seeds = rng.permutation(N)[:B].astype(np.int64)
+    out_rowptr, local, n_id, e_pos = sample_adj(pc.to_t(rowptr, DEV), pc.to_t(col, DEV), pc.to_t(seeds, DEV), fanout,
+                                                replace=replace, eng=eng)
+    out_rowptr, local, n_id, e_pos = (pc.to_np(t) for t in (out_rowptr, local, n_id, e_pos))
+    assert list(n_id[:B]) == list(seeds) and len(set(n_id.tolist())) == len(n_id)
+    assert out_rowptr[0] == 0 and out_rowptr[-1] == len(local) == len(e_pos)
+    for i, s in enumerate(seeds):
+        deg = rowptr[s + 1] - rowptr[s]
+        want = deg if fanout < 0 else ((fanout if deg > 0 else 0) if replace else min(deg, fanout))
+        lo, hi = out_rowptr[i], out_rowptr[i + 1]
+        assert hi - lo == want, (i, deg, want)
+        ep = e_pos[lo:hi]
+        assert ((ep >= rowptr[s]) & (ep < rowptr[s + 1])).all()            # edges of this seed's CSR row
+        assert (n_id[local[lo:hi]] == col[ep]).all()                       # local id <-> global neighbour
+        if not replace:
+            assert len(set(ep.tolist())) == len(ep)                        # distinct positions
+        assert (np.diff(local[lo:hi]) >= 0).all()                          # columns ascending (sample.cpp:112-118)
+    # every non-seed node of n_id is somebody's sampled neighbour
+    assert set(n_id[B:].tolist()) <= set(col[e_pos].tolist())
+
+
+@st.composite
+def fused_problems(draw):
+    N = draw(st.integers(1, 40))
+    M = draw(st.integers(1, 40))
+    E = draw(st.integers(0, 300))
+    K = draw(st.sampled_from([4, 8, 12, 16, 64, 256, 260]))
+    chunk = draw(st.sampled_from([1, 3, 64, 4096]))
+    kind = draw(st.sampled_from(["uniform", "sorted", "hub", "single"]))
+    relu = draw(st.booleans())
+    p = draw(st.sampled_from([0.0, 0.0, 0.3, 0.7]))
+    seed = draw(st.integers(0, 2**31 - 1))
+    return N, M, E, K, chunk, kind, relu, p, seed
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@given(fused_problems())
+def test_fused_epilogue_and_strided_fuzz(prob):
+    run_fused_case(engine(), DEV, prob)
+
+
+def run_fused_case(eng, DEV, prob):
+    """(1) SpMM with the epilogue in its store == SpMM then the epilogue kernel on the same RNG state, bit for
+    bit, values and gradients; (2) the strided / accumulating SpMM == the dense op on copies."""
+    N, M, E, K, chunk, kind, relu, p, seed = prob
+    rng = np.random.default_rng(seed)
+    index = np.stack([rng.integers(0, M, size=E), make_ids(rng, N, E, kind)]).astype(np.int64)
+    it = pc.to_t(index, DEV)
+    g = torch.Generator().manual_seed(seed % 1000)
+    w = torch.rand(E, generator=g).to(DEV)
+    old = eng.chunk
+    eng.chunk = chunk
+    eng.seg_cache.clear(); eng.graph_cache.clear(); eng.w_cache.clear()
+    try:
+        gp = eng.graph_plan(it, N, M)
+        xa = torch.randn(M, K, generator=g).to(DEV).requires_grad_(True)
+        ba = torch.randn(1, K, generator=g).to(DEV).requires_grad_(True)
+        xb, bb = xa.detach().clone().requires_grad_(True), ba.detach().clone().requires_grad_(True)
+        go = torch.randn(N, K, generator=g).to(DEV)
+        st_ = eng._rng_state(DEV).clone()
+        ya = eng.spmm_bias_act(gp, w, xa, ba, relu=relu, p_drop=p, training=True)
+        eng._rng_state(DEV).copy_(st_)
+        yb = eng.bias_act(eng.spmm(gp, w, xb), bb, relu=relu, p_drop=p, training=True)
+        assert torch.equal(ya, yb), prob
+        ya.backward(go)
+        yb.backward(go)
+        assert torch.equal(xa.grad, xb.grad) and torch.equal(ba.grad, bb.grad), prob
+        # strided / accumulating form on a column block of wider matrices
+        KW = K + 8
+        c0 = int(rng.integers(0, 3)) * 4
+        xw = torch.randn(M, KW, generator=g).to(DEV)
+        base = torch.randn(N, KW, generator=g).to(DEV)
+        dense, _ = eng._spmm_fwd("sum", gp.fwd, gp.col, w, xw[:, c0:c0 + K].contiguous(), N)
+        acc = base.clone()
+        eng.spmm_sum_into(gp.fwd, gp.col, w, xw[:, c0:c0 + K], acc[:, c0:c0 + K], accumulate=True)
+        np.testing.assert_allclose(pc.to_np(acc[:, c0:c0 + K]), pc.to_np(base[:, c0:c0 + K] + dense), rtol=1e-5, atol=1e-5)
+        assert torch.equal(acc[:, :c0], base[:, :c0]) and torch.equal(acc[:, c0 + K:], base[:, c0 + K:])
+        out = torch.full((N, KW), 3.0).to(DEV)
+        eng.spmm_sum_into(gp.fwd, gp.col, w, xw[:, c0:c0 + K], out[:, c0:c0 + K])
+        assert torch.equal(out[:, c0:c0 + K], dense)
+    finally:
+        eng.chunk = old
+        eng.seg_cache.clear(); eng.graph_cache.clear(); eng.w_cache.clear()

@@ -41,3 +41,15 @@ def test_gspmm_fuzz_gpu(target, oracle, prob):
 @given(F.gat_problems())
 def test_gat_fused_fuzz_gpu(target, oracle, prob):
     F.run_gat_case(target[0], target[1], oracle, prob)
+
+
+@settings(**_cfg)
+@given(F.sampler_problems())
+def test_sample_adj_fuzz_gpu(target, prob):
+    F.run_sampler_case(target[0], target[1], prob)
+
+
+@settings(**_cfg)
+@given(F.fused_problems())
+def test_fused_epilogue_and_strided_fuzz_gpu(target, prob):
+    F.run_fused_case(target[0], target[1], prob)
