@@ -535,6 +535,23 @@ def test_training_step_captures_into_a_hipgraph(eng, dev):
         graphed()
     lg = float(graphed())
     assert abs(le - lg) <= 1e-4 * abs(le) + 1e-6, (le, lg)
+    # dropout inside a captured step (fused epilogue + fused GAT attention dropout): the RNG state lives on the
+    # device and is advanced by the graph itself, so every replay draws a fresh mask
+    from gammagl_amd.layers import FusedGATConv
+
+    gat = FusedGATConv(f, 8, heads=8, dropout_rate=0.6).to(dev)
+    bias = torch.zeros(1, 64, device=dev)
+    out_buf = torch.zeros((), device=dev)
+
+    def fwd_only():
+        h = eng.bias_act(gat(x, ei, n), bias, relu=True, p_drop=0.5, training=True)
+        out_buf.copy_(h.sum().detach())
+        return out_buf
+
+    gat.train()
+    g2 = GraphedStep(fwd_only, warmup=2)
+    vals = [float(g2()) for _ in range(4)]
+    assert len(set(vals)) == 4, vals
 
 
 def test_degree_from_plan_equals_segment_sum_of_ones(eng, dev):
