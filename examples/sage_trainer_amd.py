@@ -59,6 +59,11 @@ def main():
             acc = float((tr.net(x[n_id], adjs).argmax(1) == y[dst]).float().mean())
         if rank == 0:
             print("Epoch [{:0>3d}] sampled test acc: {:.4f}".format(epoch + 1, acc))
+    # layer-wise full-neighbourhood inference over all nodes (GraphSAGE_Sample_Model.inference)
+    full = NeighborSampler(edge_index, [-1], num_nodes=n)
+    logits = tr.net.inference(x, full)
+    if rank == 0:
+        print("Full-neighbourhood test acc: {:.4f}".format(float((logits[test_idx].argmax(1) == y[test_idx]).float().mean())))
     if world > 1:
         import torch.distributed as dist
 

@@ -352,6 +352,28 @@ class GATModel(nn.Module):
         return x
 
 
+class GraphSAGEFullModel(nn.Module):
+    """models/graphsage.py:7-32 (GraphSAGE_Full_Model): full-graph GraphSAGE — dropout on the input, n_layers
+    hidden SAGEConv layers with `activation`, an output SAGEConv without, dropout between layers.  On a big edge
+    list every mean / gcn aggregate takes the fused SpMM route (MessagePassing.propagate)."""
+
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, activation, dropout, aggregator_type):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        convs = [SAGEConv(in_feats, n_hidden, activation, aggregator_type)]
+        convs += [SAGEConv(n_hidden, n_hidden, activation, aggregator_type) for _ in range(n_layers - 1)]
+        convs += [SAGEConv(n_hidden, n_classes, None, aggregator_type)]
+        self.convs = nn.ModuleList(convs)
+
+    def forward(self, feat, edge):
+        h = self.dropout(feat)
+        for i, layer in enumerate(self.convs):
+            h = layer(h, edge)
+            if i != len(self.convs) - 1:
+                h = self.dropout(h)
+        return h
+
+
 class GraphSAGESampleModel(nn.Module):
     """models/graphsage.py:35-83 (GraphSAGE_Sample_Model): SAGEConv(mean) per sampled hop; the target
     nodes of a block are the first size[1] rows of its input ("target nodes are always placed first")."""
@@ -375,6 +397,25 @@ class GraphSAGESampleModel(nn.Module):
                 x = self.dropout(x)
         return x
 
+    @torch.no_grad()
+    def inference(self, feat, sampler, batch_size=4096):
+        """models/graphsage.py:85-103: layer by layer over ALL nodes with one full-neighbourhood hop per batch
+        (a NeighborSampler built with sample_lists=[-1]); returns the logits of every node."""
+        n = feat.shape[0]
+        for i, layer in enumerate(self.convs):
+            out = None
+            for b in range(0, n, batch_size):
+                dst = torch.arange(b, min(n, b + batch_size), device=feat.device)
+                _, n_id, adj = sampler.sample(dst)
+                adj = adj[0] if isinstance(adj, (list, tuple)) else adj
+                h = feat[n_id]
+                h = layer((h, h[: adj.size[1]]), adj.edge_index)
+                if out is None:
+                    out = torch.empty((n, h.shape[1]), dtype=h.dtype, device=h.device)
+                out[dst] = h
+            feat = out
+        return feat
 
-__all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "GATModel", "GraphSAGESampleModel", "degree",
+
+__all__ = ["MessagePassing", "GCNConv", "SAGEConv", "GATConv", "FusedGATConv", "GCNModel", "GATModel", "GraphSAGEFullModel", "GraphSAGESampleModel", "degree",
            "calc_gcn_norm", "segment_softmax", "add_self_loops"]
