@@ -489,6 +489,32 @@ def test_training_is_bitwise_reproducible(eng, dev):
         assert torch.equal(a, b)
 
 
+def test_ops_follow_the_current_stream(eng, dev, oracle):
+    """Every launch goes to torch's CURRENT stream (include/ggl_mpops.h: stream-ordered, no host sync): work
+    queued on a side stream behind a producer on that same stream sees the producer's data."""
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, 2000, (2, 60000), generator=g)
+    w = torch.rand(60000, generator=g)
+    xs = torch.randn(2000, 64, generator=g)
+    eid, wd = ei.to(dev), w.to(dev)
+    eng.c_spmm_sum(eid, wd, xs.to(dev))  # plan + sorted weights built on the default stream
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    xd = torch.empty(2000, 64, device=dev)
+    big = torch.randn(4096, 4096, device=dev)
+    with torch.cuda.stream(side):
+        for _ in range(10):
+            big = big @ big * 1e-4            # keeps the side stream busy so ordering matters
+        xd.copy_(xs.to(dev, non_blocking=True))  # producer on the side stream
+        y = eng.c_spmm_sum(eid, wd, xd)          # consumer on the same stream
+        mx, arg = eng.segment_max_with_arg(xd[eid[0]], eid[1].contiguous(), 2000)
+    side.synchronize()
+    np.testing.assert_allclose(y.cpu().numpy(), oracle.spmm_sum_fwd(ei.numpy(), w.numpy(), xs.numpy()), rtol=1e-5, atol=1e-5)
+    omx, oarg = oracle.segment_max(xs.numpy()[ei[0].numpy()], ei[1].numpy(), 2000)
+    np.testing.assert_array_equal(mx.cpu().numpy(), omx)
+    np.testing.assert_array_equal(arg.cpu().numpy(), oarg)
+
+
 def test_neighbor_sampler(eng, dev, oracle):
     pc.check_sampler(eng, dev, oracle)
 
