@@ -18,8 +18,15 @@ from . import engine as _engine
 from .ops import _ptr
 
 
-def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None):
-    """Sample ``num_neighbors`` in-neighbours of every row in ``idx`` (all of them if negative)."""
+_BIG = 1 << 62
+
+
+def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_pos=None):
+    """Sample ``num_neighbors`` in-neighbours of every row in ``idx`` (all of them if negative).
+
+    ``first_pos``: optional int64 scratch of one entry per graph node, filled with ``_BIG`` (NeighborSampler
+    keeps one): the relabelling then runs on it without sorting (first occurrence of every node by a
+    scatter-min, ids by a prefix sum over the first occurrences) and hands it back reset."""
     eng = eng or _engine()
     dev = eng._dev(rowptr, col, idx)
     rowptr = rowptr.contiguous().to(torch.int64)
@@ -41,14 +48,24 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None):
     e_pos, nbr = e_pos[:E], nbr[:E]
     # relabel: seeds keep 0..B-1 (sample.cpp:24-29), new nodes follow in first-seen order (:48-51)
     cat = torch.cat([idx, nbr])
-    uniq, inv = torch.unique(cat, return_inverse=True)
-    first = torch.full((uniq.shape[0],), cat.shape[0], dtype=torch.int64, device=dev)
-    first.scatter_reduce_(0, inv, torch.arange(cat.shape[0], device=dev), "amin", include_self=True)
-    order = torch.argsort(first)                      # unique ids by first appearance
-    rank = torch.empty_like(order)
-    rank[order] = torch.arange(order.shape[0], device=dev)
-    out_n_id = uniq[order]
-    local = rank[inv[B:]]
+    if first_pos is not None:
+        ar = torch.arange(cat.shape[0], device=dev)
+        first_pos.scatter_reduce_(0, cat, ar, "amin", include_self=True)   # first position of every node met
+        fp = first_pos[cat]
+        is_first = fp == ar
+        new_id = torch.cumsum(is_first, 0) - 1                              # ids in first-seen order
+        out_n_id = cat[is_first]
+        local = new_id[fp[B:]]
+        first_pos[cat] = _BIG                                               # hand the scratch back clean
+    else:
+        uniq, inv = torch.unique(cat, return_inverse=True)
+        first = torch.full((uniq.shape[0],), cat.shape[0], dtype=torch.int64, device=dev)
+        first.scatter_reduce_(0, inv, torch.arange(cat.shape[0], device=dev), "amin", include_self=True)
+        order = torch.argsort(first)                      # unique ids by first appearance
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.shape[0], device=dev)
+        out_n_id = uniq[order]
+        local = rank[inv[B:]]
     # every row's columns ascending by local id (sample.cpp:112-118)
     if E > 0:
         row = torch.repeat_interleave(torch.arange(B, device=dev), deg, output_size=E)  # size known: no sync
@@ -87,13 +104,15 @@ class NeighborSampler:
         self.rowptr = plan.rowptr
         self.col = ei[0] if plan.perm is None else ei[0][plan.perm.long()]
         self.value = (torch.arange(ei.shape[1], device=ei.device) if plan.perm is None else plan.perm.long())
+        self._first_pos = torch.full((self.num_nodes,), _BIG, dtype=torch.int64, device=ei.device)  # relabel scratch
 
     def sample(self, batch):
         batch = torch.as_tensor(batch, device=self.rowptr.device, dtype=torch.int64).reshape(-1)
         n_id, adjs = batch, []
         for size in self.sizes:
             n_dst = int(n_id.shape[0])
-            rowptr, col, n_id, e_pos = sample_adj(self.rowptr, self.col, n_id, size, replace=False, eng=self.eng)
+            rowptr, col, n_id, e_pos = sample_adj(self.rowptr, self.col, n_id, size, replace=False, eng=self.eng,
+                                                  first_pos=self._first_pos)
             row = torch.repeat_interleave(torch.arange(n_dst, device=col.device), rowptr[1:] - rowptr[:-1],
                                           output_size=int(col.shape[0]))
             block = torch.stack([col, row])

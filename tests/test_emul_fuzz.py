@@ -203,7 +203,18 @@ def run_sampler_case(eng, DEV, prob):
     seeds = rng.permutation(N)[:B].astype(np.int64)
     out_rowptr, local, n_id, e_pos = sample_adj(pc.to_t(rowptr, DEV), pc.to_t(col, DEV), pc.to_t(seeds, DEV), fanout,
                                                 replace=replace, eng=eng)
+    # the sort-free relabelling NeighborSampler uses (dense first-position scratch) gives the same block
+    from gammagl_amd import sampler as _s
+    scratch = torch.full((N,), _s._BIG, dtype=torch.int64, device=DEV)
+    st0 = eng._rng_state(DEV).clone()
     out_rowptr, local, n_id, e_pos = (pc.to_np(t) for t in (out_rowptr, local, n_id, e_pos))
+    eng._rng_state(DEV)[1] -= 1        # same draw again
+    r2 = sample_adj(pc.to_t(rowptr, DEV), pc.to_t(col, DEV), pc.to_t(seeds, DEV), fanout, replace=replace, eng=eng,
+                    first_pos=scratch)
+    assert torch.equal(eng._rng_state(DEV), st0)
+    for a_, b_ in zip((out_rowptr, local, n_id, e_pos), r2):
+        np.testing.assert_array_equal(a_, pc.to_np(b_))
+    assert bool((scratch == _s._BIG).all())
     assert list(n_id[:B]) == list(seeds) and len(set(n_id.tolist())) == len(n_id)
     assert out_rowptr[0] == 0 and out_rowptr[-1] == len(local) == len(e_pos)
     for i, s in enumerate(seeds):
