@@ -89,7 +89,28 @@ if "3" in which:
               f"forward+backward {t_ub:.2f} ms  -> fused speed-up {t_u / t_f:.1f}x / {t_ub / t_fb:.1f}x")
     except torch.cuda.OutOfMemoryError as ex:
         print("    unfused GATConv: OOM", str(ex)[:80])
-    del ei, gp, x
+    del gp
+    # the whole model of config 3: 2-layer, 8-head GAT (602 -> 8 x 8 -> 41 classes, last layer averages its heads),
+    # feature and attention dropout 0.6 (examples/gat/gat_trainer.py defaults), one full-graph training step
+    from gammagl_amd.layers import GATModel
+    import torch.nn.functional as F
+
+    torch.manual_seed(0)
+    net = GATModel(602, 8, 41, 8, 0.6, 2, fused=True).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=0.005, weight_decay=5e-4)
+    yl = torch.randint(0, 41, (n,), generator=g, device=dev)
+    tidx = torch.arange(0, n, 3, device=dev)
+
+    def gat_step():
+        net.train()
+        opt.zero_grad(set_to_none=True)
+        F.cross_entropy(net(x, ei, n)[tidx], yl[tidx]).backward()
+        opt.step()
+
+    ms = timeit(gat_step, reps=5, warm=2)
+    print(f"    2-layer 8-head GATModel(602 -> 8x8 -> 41) training step, dropout 0.6: {ms:.1f} ms "
+          f"({2 * 2 * E / ms / 1e6:.2f} Gedges/s over 2 layers x fwd+bwd)", flush=True)
+    del net, opt, ei, x
     eng.seg_cache.clear(); eng.graph_cache.clear(); torch.cuda.empty_cache()
 
 if "4" in which:
