@@ -78,6 +78,73 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_kernel(const int64_t *ind
   }
 }
 
+#ifndef GGL_EMULATE
+// Wide heads (C > 16), GPU build only: a group of 2^LOGG lanes per (edge, head) splits the channels — each
+// strip x[src,h,:] / g[dst,h,:] is one coalesced read instead of a thread's C/4 strided ones.  The dot is then
+// summed ACROSS the lanes in channel order: the running sum ripples from lane to lane through wave shuffles, each
+// lane adding its four products in order, so the result is the reference's serial sum over c bit for bit
+// (bspmm_sum_cpu.cpp:95-107; pinned by the golden weight gradients).  kPerGroup consecutive items per group keep
+// their loads in flight together; the last lane of the ripple holds the dot and writes it.
+constexpr int kGradWPerGroup = 4;
+
+template <int LOGG>
+__global__ __launch_bounds__(kBlock) void bspmm_grad_w_wide_kernel(const int64_t *__restrict__ index,
+                                                                   const float *__restrict__ x,
+                                                                   const float *__restrict__ g, int64_t E,
+                                                                   int64_t H, int64_t C,
+                                                                   float *__restrict__ gw) {
+  constexpr int G = 1 << LOGG, U = kGradWPerGroup;
+  const int64_t total = E * H;
+  const int64_t base = (thread_id() >> LOGG) * U;
+  const int sub = (int)(threadIdx.x & (G - 1));
+  if (base >= total) return;  // whole groups leave together
+  const float *xr[U], *gr[U];
+  float part[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t it = base + u < total ? base + u : base;
+    const int64_t e = it / H, h = it - e * H;
+    xr[u] = x + (index[e] * H + h) * C;
+    gr[u] = g + (index[e + E] * H + h) * C;
+    part[u] = 0.0f;
+  }
+  for (int64_t c0 = 0; c0 < C; c0 += (int64_t)G * 4) {  // C % 4 == 0 on this path
+    const int64_t c = c0 + (int64_t)sub * 4;
+    const bool act = c < C;
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = act ? *reinterpret_cast<const float4 *>(xr[u] + c) : float4{0.f, 0.f, 0.f, 0.f};
+      b[u] = act ? *reinterpret_cast<const float4 *>(gr[u] + c) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ripple: lane k takes the running sums from lane k-1 and adds its own four products, in channel order
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float prev = __shfl(part[u], k == 0 ? G - 1 : k - 1, G);  // (k == 0: the sum carried over from c0 - G*4)
+        if (sub == k && act) {
+          float r = prev;
+          r = __fadd_rn(r, __fmul_rn(a[u].x, b[u].x));
+          r = __fadd_rn(r, __fmul_rn(a[u].y, b[u].y));
+          r = __fadd_rn(r, __fmul_rn(a[u].z, b[u].z));
+          r = __fadd_rn(r, __fmul_rn(a[u].w, b[u].w));
+          part[u] = r;
+        } else if (sub == k) {
+          part[u] = prev;  // past the end of the strip: just carry the sum along
+        }
+      }
+    }
+  }
+  // the last lane of the ripple holds the complete dot
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float dot = __shfl(part[u], G - 1, G);
+    if (sub == u && base + u < total) gw[base + u] = dot;
+  }
+}
+#endif
+
 __global__ __launch_bounds__(kBlock) void fill_i64_kernel(int64_t *p, int64_t n, int64_t v) {
   const int64_t stride = grid_threads();
   for (int64_t i = thread_id(); i < n; i += stride) p[i] = v;
@@ -273,6 +340,24 @@ extern "C" int ggl_bspmm_grad_w(const int64_t *index, const float *x, const floa
   GGL_REQUIRE(E >= 0 && H > 0 && C > 0, GGL_EINVAL, "bad sizes");
   if (E == 0) return GGL_OK;
   GGL_REQUIRE(index && x && g && gw, GGL_EINVAL, "NULL pointer");
+#ifndef GGL_EMULATE
+  // (measured at products size: 8 x 44 channels 165 -> 127 ms forward+backward with the ripple; beyond 16 lanes the
+  // lane-to-lane ripple costs more than the strided loads it saves — 1 x 256: 103 -> 171 ms — so wider heads
+  // stay on the thread-per-item kernel; a butterfly would be faster still, 57 ms, but not bit-exact)
+  if (C > 16 && C <= 64 && C % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0 && !options().force_generic) {
+    int logg = 2;
+    while (logg < 4 && ((int64_t)4 << logg) < C) ++logg;  // lanes per item: next power of two >= C / 4, 4..16
+    const int64_t groups = ceil_div(E * H, (int64_t)kGradWPerGroup);
+    const int64_t wgrid = ceil_div(groups << logg, (int64_t)kBlock);
+    hipStream_t s = as_stream(stream);
+    if (logg <= 2) GGL_LAUNCH((bspmm_grad_w_wide_kernel<2>), wgrid, kBlock, s, index, x, g, E, H, C, gw);
+    else if (logg == 3) GGL_LAUNCH((bspmm_grad_w_wide_kernel<3>), wgrid, kBlock, s, index, x, g, E, H, C, gw);
+    else GGL_LAUNCH((bspmm_grad_w_wide_kernel<4>), wgrid, kBlock, s, index, x, g, E, H, C, gw);
+    GGL_LAUNCH_CHECK();
+    return GGL_OK;
+  }
+#endif
   GGL_LAUNCH((bspmm_grad_w_kernel), grid_for(E * H), kBlock, as_stream(stream), index, x, g, E, H, C,
              gw);
   GGL_LAUNCH_CHECK();

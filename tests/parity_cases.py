@@ -780,6 +780,26 @@ def check_strided_accumulate(eng, dev, oracle):
         eng.graph_cache.clear(); eng.seg_cache.clear()
 
 
+def check_bspmm_wide(eng, dev):
+    """bspmm forward, input gradient and WEIGHT gradient for wide / odd channel counts (the weight gradient has a
+    lanes-split-channels kernel for C > 16 on the GPU) against the formula written out in torch."""
+    g = torch.Generator(device="cpu").manual_seed(13)
+    for (N, E, H, C) in ((30, 400, 2, 24), (25, 300, 1, 100), (40, 500, 8, 44), (20, 260, 3, 20), (18, 200, 8, 41),
+                         (16, 150, 1, 300), (22, 240, 4, 8)):
+        ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+        x = torch.randn(N, H, C, generator=g).to(dev).requires_grad_(True)
+        w = torch.rand(E, H, generator=g).to(dev).requires_grad_(True)
+        go = torch.randn(N, H, C, generator=g).to(dev)
+        y = eng.c_bspmm_sum(ei, w, x)
+        y.backward(go)
+        xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        ref = torch.zeros(N, H, C, device=dev).index_add_(0, ei[1], xr[ei[0]] * wr.unsqueeze(-1))
+        ref.backward(go)
+        torch.testing.assert_close(y.detach(), ref.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(x.grad, xr.grad, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(w.grad, wr.grad, rtol=1e-5, atol=1e-5)
+
+
 def check_plan_cache(eng, dev):
     eng.seg_cache.clear()
     ids = torch.tensor([2, 0, 1, 0, 2, 2], device=dev)

@@ -67,6 +67,10 @@ def test_folded_2d_grids(eng, oracle, golden):
         eng.set_option("max_grid_x", 1 << 22)
 
 
+def test_bspmm_wide_heads(eng):
+    pc.check_bspmm_wide(eng, DEV)
+
+
 def test_strided_and_accumulating_forms(eng, oracle):
     pc.check_strided_accumulate(eng, DEV, oracle)
 

@@ -106,6 +106,10 @@ def test_folded_2d_grids(eng, dev, oracle, golden):
         eng.set_option("max_grid_x", 1 << 22)
 
 
+def test_bspmm_wide_heads(eng, dev):
+    pc.check_bspmm_wide(eng, dev)
+
+
 def test_strided_and_accumulating_forms(eng, dev, oracle):
     pc.check_strided_accumulate(eng, dev, oracle)
 
