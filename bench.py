@@ -3,6 +3,10 @@
 ogbn-products-sized synthetic graph, MI355X, through the gammagl_amd HIP kernels.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE JSON line on rank 0.
+With N > 1 and no launcher environment (WORLD_SIZE unset) bench.py launches the N ranks ITSELF
+(torch.distributed.run, 127.0.0.1, one rank per GPU) and relays rank 0's line; under a launcher it checks
+that WORLD_SIZE == --gpus and refuses to print a line for a different world size.  Every rank builds only
+its own share of the graph (gammagl_amd.synth.rmat_partitioned): no rank holds the edge list.
 
 * a "step" = one full training step of GCNModel(100 -> 256 -> 256 -> 47, norm='none') on
   precomputed symmetric-normalised edge weights (edge_weight = calc_gcn_norm(edge_index), the
@@ -16,8 +20,11 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
   with hipEvents on its launch stream: algorithmic bytes E*(4*256+8) + N*(4*256+8) per launch
   (SURVEY.md §8d) / time, against the 8 TB/s HBM3E peak;
 * cpu_baseline (N = 1 only) = the reference's own CPU extension (oracle/_ref, compiled from the
-  reference sources; our C restatement if it is absent) running the same 6 aggregations on a bounded
-  R-MAT sample, 1 core (the shipped extension is serial: setup.py:50 never defines its OpenMP macro).
+  reference sources; our C restatement if it is absent), 1 core (the shipped extension is serial:
+  setup.py:50 never defines its OpenMP macro): ONE full-size K=256 aggregate of the benchmark graph itself
+  (~20 s), plus the 6 aggregations of a step on a bounded R-MAT sample as a secondary figure.
+* GGL_BENCH_EMUL=1 (tests only): gloo + the host-emulated kernels on CPU, to exercise the launcher and the
+  N-rank code path where there is no GPU; the line then says "engine": "host-emulation" and is no measurement.
 """
 import argparse
 import json
@@ -48,43 +55,69 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(hidden, classes, seed):
-    """Reference CPU extension (or the oracle port) on a bounded sample: ~10-20 s of one core."""
-    from gammagl_amd.synth import rmat_graph
+def _ref_or_port():
     from oracle import oracle as orc
 
-    n_s, e_s = 400000, 16_000_000
+    try:
+        return orc.load_ref_ext(), "reference", orc
+    except Exception:  # noqa: BLE001
+        orc.build()
+        return None, "port", orc
+
+
+def cpu_baseline(hidden, classes, seed, full_graph=None):
+    """Reference CPU extension (or the oracle port), 1 core.  `full_graph` = (edge_index [2,E] int64 on the
+    host, weights [E], N): one K=hidden forward aggregate of the benchmark graph itself; then the 6 aggregations
+    of a step on a bounded sample (~8 s)."""
+    from gammagl_amd.synth import rmat_graph
+
+    ref, kind, orc = _ref_or_port()
+    impl = "reference c_spmm_sum (oracle/_ref)" if kind == "reference" else "oracle C port"
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(1)
+    gen = torch.Generator().manual_seed(seed)
+    out = {}
+    if full_graph is not None:
+        ei, w, n = full_graph
+        E = int(ei.shape[1])
+        x = torch.randn(n, hidden, generator=gen)
+        t0 = time.perf_counter()
+        if ref is not None:
+            ref.c_spmm_sum(ei, w, x)
+        else:
+            orc.spmm_sum_fwd(ei.numpy(), w.numpy(), x.numpy())
+        dt = time.perf_counter() - t0
+        out = {"value": E / dt, "unit": "edges/s", "cores": 1, "kind": kind,
+               "sample": f"ONE forward aggregate (K={hidden}) of the full benchmark graph: N={n}, E={E}, {impl}, "
+                         f"{dt:.1f} s on 1 core of {cores}"}
+        del x
+    n_s, e_s = 400000, (8_000_000 if full_graph is not None else 16_000_000)
     ei = rmat_graph(n_s, e_s, seed=seed + 17, device="cpu")
     E = ei.shape[1]
-    gen = torch.Generator().manual_seed(seed)
     w = torch.rand(E, generator=gen)
     widths = [hidden, hidden, classes]
     feats = [torch.randn(n_s, k, generator=gen) for k in widths]
-    ref = None
-    try:
-        ref = orc.load_ref_ext()
-    except Exception:  # noqa: BLE001
-        ref = None
-    torch.set_num_threads(1)
     t0 = time.perf_counter()
     if ref is not None:
-        kind = "reference"
         eiT = ei.flip(0).contiguous()
         for x in feats:
             ref.c_spmm_sum(ei, w, x)        # forward aggregate (spmm_sum_cpu_forward)
             ref.c_spmm_sum(eiT, w, x)       # backward = the same loop on the transposed edge list
     else:
-        kind = "port"
-        orc.build()
         ein, wn = ei.numpy(), w.numpy()
         for x in feats:
             orc.spmm_sum_fwd(ein, wn, x.numpy())
             orc.spmm_sum_bwd(ein, wn, x.numpy())
     dt = time.perf_counter() - t0
-    impl = "reference c_spmm_sum (oracle/_ref)" if kind == "reference" else "oracle C port"
+    step = {"value": 6 * E / dt, "unit": "edges/s", "cores": 1, "kind": kind,
+            "sample": f"R-MAT N={n_s} E={E} (loops incl.), the 6 aggregations of one 3-layer GCN step "
+                      f"(K={widths} fwd + transposed bwd), {impl}, {dt:.1f} s on 1 core of {cores}"}
+    if out:
+        out["step_sample"] = step
+    else:
+        out = step
     # second baseline (BASELINE.md §3): the reference's pure-torch formulation of the same aggregate
     # (mpops/torch.py:16-18,335-342: x[src] * w -> zeros().scatter_add_), all host threads, smaller sample
-    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     e_t = min(E, 3_000_000)
     src, dst, wt = ei[0, :e_t], ei[1, :e_t], w[:e_t]
@@ -94,29 +127,70 @@ def cpu_baseline(hidden, classes, seed):
             msg = x[s_] * wt.view(-1, 1)
             torch.zeros_like(x).scatter_add_(0, d_.view(-1, 1).expand_as(msg), msg)
     dt_t = time.perf_counter() - t1
-    return {
-        "value": 6 * E / dt, "unit": "edges/s", "cores": 1, "kind": kind,
-        "sample": f"R-MAT N={n_s} E={E} (loops incl.), the 6 aggregations of one 3-layer GCN step "
-                  f"(K={widths} fwd + transposed bwd), {impl}, {dt:.1f} s on 1 core of {cores}",
-        "torch_fallback": {"value": 6 * e_t / dt_t, "unit": "edges/s", "cores": cores,
-                           "sample": f"pure-torch mpops formulation (gather * w -> scatter_add_), first {e_t} edges of "
-                                     f"the same sample, {dt_t:.1f} s on {cores} threads"},
-    }
+    out["torch_fallback"] = {"value": 6 * e_t / dt_t, "unit": "edges/s", "cores": cores,
+                             "sample": f"pure-torch mpops formulation (gather * w -> scatter_add_), first {e_t} edges "
+                                       f"of the sample, {dt_t:.1f} s on {cores} threads"}
+    return out
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn(args):
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run on this node
+    (one per GPU, rendezvous on 127.0.0.1) and relay their output.  Refuses when the node has fewer GPUs."""
+    import subprocess
+
+    emul = os.environ.get("GGL_BENCH_EMUL") == "1"
+    if not emul:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); not reporting a "
+                             f"{args.gpus}-GPU line from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    emul = os.environ.get("GGL_BENCH_EMUL") == "1"
+    eng = None
+    if emul:  # tests only: the launcher + N-rank path on a GPU-less box (gloo, host-emulated kernels)
+        import subprocess
+
+        from gammagl_amd import _lib
+        from gammagl_amd.ops import Engine
+
+        subprocess.check_call([os.path.join(REPO, "tests", "emul", "build.sh")])
+        eng = Engine(_lib.bind(os.path.join(REPO, "tests", "emul", "libggl_emul.so")), require_cuda=False)
+        dev, backend = torch.device("cpu"), "gloo"
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+        torch.cuda.set_device(local_rank)
+        dev, backend = torch.device("cuda", local_rank), "nccl"
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if emul:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group(backend, device_id=dev)
 
     from gammagl_amd.dist import run_distributed_bench
     from gammagl_amd.synth import DATASETS
@@ -125,11 +199,21 @@ def main():
         n_nodes, n_edges, f_in, n_cls = 20000, 400000, 100, 47
     else:
         n_nodes, n_edges, f_in, n_cls = DATASETS[args.workload]
-    out = run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls)
+    out, pg = run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls, eng=eng)
+    out["engine"] = "host-emulation (launcher test, not a measurement)" if emul else "hip"
+    if emul:
+        out["roofline"] = None
+    if world > 1:
+        import torch.distributed as dist
+
+        assert dist.get_world_size() == args.gpus
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.hidden, n_cls, args.seed)
-        print(json.dumps(out))
+        if world == 1 and not args.no_cpu_baseline and not emul:
+            # the benchmark graph itself on the host (rank 0 holds all of it at N = 1)
+            ei = torch.cat([torch.stack([pg.ei_loc[0] + pg.lo, pg.ei_loc[1] + pg.lo]).cpu()], dim=1)
+            full = (ei.contiguous(), pg.w_loc.cpu(), n_nodes) if args.workload != "tiny" else None
+            out["cpu_baseline"] = cpu_baseline(args.hidden, n_cls, args.seed, full)
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
 

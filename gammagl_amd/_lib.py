@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SegPlanC(ctypes.Structure):
@@ -44,6 +44,7 @@ SIGNATURES = {
     "ggl_fill_i64": (c_int, [_V, c_int64, c_int64, _V]),
     "ggl_gather_i64_to_i32": (c_int, [_V, _V, c_int64, _V, _V]),
     "ggl_gather_rows_f32": (c_int, [_V, _V, c_int64, c_int64, _V, _V]),
+    "ggl_gather_rows_f32_ex": (c_int, [_V, c_int64, _V, c_int64, c_int64, _V, c_int64, _V]),
     "ggl_ind2ptr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_ind2ptr": (c_int, [_V, c_int64, c_int64, _V, _V, c_size_t, _V]),
     "ggl_ptr2ind": (c_int, [_V, c_int64, c_int64, _V, _V]),
@@ -69,7 +70,10 @@ SIGNATURES = {
     "ggl_colsum_f32": (c_int, [_V, c_int64, c_int64, _V, _V, c_size_t, _V]),
     "ggl_bias_act_fwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V]),
     "ggl_bias_act_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "ggl_bias_act_bwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V, c_size_t, _V]),
+    "ggl_bias_act_bwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V, _V, c_size_t, _V]),
+    "ggl_spmm_epi_ex": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, c_int64, c_int, c_int, _V, c_int64,
+                                _V, c_int, c_float, _V, c_int64, c_int64, c_int, _V]),
+    "ggl_segment_epi": (c_int, [_V, _P, c_int64, c_int, _V, c_int64, _V, c_int, c_float, _V, _V, _V]),
     "ggl_gat_fused_fwd": (c_int, [_P, _V, _V, _V, _V, c_float, c_int64, c_int64, c_float, _V, _V, _V, _V, _V]),
     "ggl_gat_partial_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,

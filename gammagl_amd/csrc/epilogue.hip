@@ -5,9 +5,10 @@
 // backward: six passes over [N,K] per hidden layer (measured 4.0 ms of a 110 ms products-sized step,
 // profiles/r1_bench_products_summary.txt).  Here it is one pass each way:
 //   forward : y = keep(i) * relu(a + bias) / (1 - p)        keep(i) from Philox4x32-10(seed, offset; i)
-//   backward: ga = (y > 0) ? g / (1 - p) : 0  (y == 0 exactly where ReLU or dropout killed the value,
-//             so no mask tensor is stored), and the bias gradient = column sums of ga accumulated in
-//             the same pass (two deterministic stages, as in ggl_colsum_f32).
+//   backward: ga = keep(i) * [relu ? y > 0 : 1] * g / (1 - p): the dropout mask is REDRAWN from the
+//             {seed, offset} the forward read (no mask tensor is stored; y only tells where the ReLU
+//             clipped), and the bias gradient = column sums of ga accumulated in the same pass (two
+//             deterministic stages, as in ggl_colsum_f32).
 // The RNG state (seed, offset) lives in device memory and is advanced by a one-thread kernel after every
 // forward, so a captured hipGraph draws a fresh mask on each replay.  No LDS, no atomics.
 #include "common.hpp"
@@ -47,6 +48,8 @@ __global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(const float *__res
   const int c0 = threadIdx.x - j * kp;
   if (j >= groups) return;
   const int64_t KV = (K + VEC - 1) / VEC;  // vectors per row (VEC = 4 only when K % 4 == 0)
+  const int ev = (K % 4 == 0) ? 4 : 1;     // elements per dropout word vector
+  const int64_t KVm = K / ev;
   const int64_t r0 = block_id() * rows_per_block;
   if (block_id() >= nblocks) return;  // padding block of a folded grid
   const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
@@ -58,8 +61,11 @@ __global__ __launch_bounds__(kBlock) void bias_act_fwd_kernel(const float *__res
     auto finish = [&](int64_t r, float (&t)[VEC]) {
       uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
       if (drop_thresh) {
-        const U4 u = philox4x32_10((uint64_t)(r * KV + c), offset, seed);
+        // the word of element (r, k) depends on K alone (vectors of 4 when K % 4 == 0), not on which kernel
+        // variant the pointer alignment selected: the fused SpMM epilogue and the backward draw the same mask
+        const U4 u = philox4x32_10((uint64_t)(r * KVm + (c * VEC) / ev), offset, seed);
         rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
+        if (VEC == 1) rw[0] = rw[(c * VEC) % ev];
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -100,11 +106,15 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
                                                               int64_t K, int64_t nblocks,
                                                               int64_t rows_per_block, int kp,
                                                               int groups, int masked, float scale,
+                                                              const int64_t *__restrict__ rng,
+                                                              uint32_t drop_thresh,
                                                               float *__restrict__ partial) {
   const int j = threadIdx.x / kp;
   const int c0 = threadIdx.x - j * kp;
   if (j >= groups) return;
   const int64_t KV = (K + VEC - 1) / VEC;
+  const int ev = (K % 4 == 0) ? 4 : 1;
+  const int64_t KVm = K / ev;
   const int64_t r0 = block_id() * rows_per_block;
   if (block_id() >= nblocks) return;  // padding block of a folded grid
   const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
@@ -113,9 +123,20 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
     auto finish = [&](int64_t r, float (&gv)[VEC], const float (&yv)[VEC]) {
+      uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      if (rng) {  // the mask the forward drew: same word for vector (r, c)
+        const U4 u = philox4x32_10((uint64_t)(r * KVm + (c * VEC) / ev), (uint64_t)rng[1], (uint64_t)rng[0]);
+        rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
+        if (VEC == 1) rw[0] = rw[(c * VEC) % ev];
+      }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        if (masked) gv[i] = (yv[i] > 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
+        // masked: 1 = y > 0 (ReLU, and dropout when no rng state is given), 2 = y != 0 (dropout without ReLU
+        // and without an rng state), 3 = redrawn dropout mask only, 4 = redrawn mask and y > 0
+        if (masked == 1) gv[i] = (yv[i] > 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
+        else if (masked == 2) gv[i] = (yv[i] != 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
+        else if (masked == 3) gv[i] = (rw[i] >= drop_thresh) ? __fmul_rn(gv[i], scale) : 0.0f;
+        else if (masked == 4) gv[i] = (rw[i] >= drop_thresh && yv[i] > 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
         acc[i] = __fadd_rn(acc[i], gv[i]);  // rows in ascending order, unrolled or not
       }
       stv<VEC>(ga + r * K + c * VEC, gv);
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
 #pragma unroll
       for (int u = 0; u < kRowUnroll; ++u) {
         ldv<VEC>(g + (r + (int64_t)u * groups) * K + c * VEC, gv[u]);
-        if (masked) ldv<VEC>(y + (r + (int64_t)u * groups) * K + c * VEC, yv[u]);
+        if (masked && masked != 3) ldv<VEC>(y + (r + (int64_t)u * groups) * K + c * VEC, yv[u]);
         else yv[u][0] = 0.0f;
       }
 #pragma unroll
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
     for (; r < r1; r += groups) {
       float gv[VEC], yv[VEC];
       ldv<VEC>(g + r * K + c * VEC, gv);
-      if (masked) ldv<VEC>(y + r * K + c * VEC, yv);
+      if (masked && masked != 3) ldv<VEC>(y + r * K + c * VEC, yv);
       else yv[0] = 0.0f;
       finish(r, gv, yv);
     }
@@ -212,18 +233,23 @@ extern "C" size_t ggl_bias_act_bwd_workspace_bytes(int64_t N, int64_t K) {
 }
 
 extern "C" int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int relu,
-                                float p_drop, float *ga, float *gbias, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+                                float p_drop, const int64_t *rng_used, float *ga, float *gbias,
+                                void *workspace, size_t workspace_bytes, void *stream) {
   GGL_REQUIRE(N >= 0 && K >= 0 && p_drop >= 0.0f && p_drop < 1.0f, GGL_EINVAL, "bad arguments");
   if (K == 0) return GGL_OK;
   GGL_REQUIRE((g && ga) || N == 0, GGL_EINVAL, "NULL pointer");
-  const int masked = (relu || p_drop > 0.0f) ? 1 : 0;
-  GGL_REQUIRE(!masked || y || N == 0, GGL_EINVAL, "y is needed to rebuild the ReLU/dropout mask");
+  // rng_used = the {seed, offset} the forward read (a copy taken before it advanced): the dropout mask is
+  // redrawn exactly.  Without it the mask is rebuilt from y (y > 0 with ReLU; y != 0 without — exact except
+  // for kept activations that are exactly 0).
+  const bool redraw = p_drop > 0.0f && rng_used != nullptr;
+  const int masked = redraw ? (relu ? 4 : 3) : (relu ? 1 : (p_drop > 0.0f ? 2 : 0));
+  const uint32_t thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  GGL_REQUIRE(!masked || masked == 3 || y || N == 0, GGL_EINVAL, "y is needed to rebuild the ReLU/dropout mask");
   GGL_REQUIRE(!gbias || (workspace && workspace_bytes >= ggl_bias_act_bwd_workspace_bytes(N, K)),
               GGL_EWORKSPACE, "bias_act_bwd workspace too small");
   const bool vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) &&
                     ((reinterpret_cast<uintptr_t>(ga) & 15u) == 0) &&
-                    (!masked || (reinterpret_cast<uintptr_t>(y) & 15u) == 0);
+                    (!masked || masked == 3 || (reinterpret_cast<uintptr_t>(y) & 15u) == 0);
   int kp, groups;
   int64_t blocks, rpb;
   geometry(N, K, vec4, &kp, &groups, &blocks, &rpb);
@@ -232,10 +258,10 @@ extern "C" int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64
   float *partial = gbias ? static_cast<float *>(workspace) : nullptr;
   if (vec4)
     GGL_LAUNCH((bias_act_bwd_kernel<4>), blocks, kBlock, s, g, y, ga, N, K, blocks, rpb, kp, groups, masked, scale,
-               partial);
+               redraw ? rng_used : nullptr, thresh, partial);
   else
     GGL_LAUNCH((bias_act_bwd_kernel<1>), blocks, kBlock, s, g, y, ga, N, K, blocks, rpb, kp, groups, masked, scale,
-               partial);
+               redraw ? rng_used : nullptr, thresh, partial);
   GGL_LAUNCH_CHECK();
   if (gbias) {  // second stage: column sums of the [P, K] partial matrix
     const size_t part = bwd_partial_bytes(N, K);

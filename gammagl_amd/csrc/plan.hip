@@ -169,6 +169,30 @@ __global__ __launch_bounds__(kBlock) void gather_rows_f32_kernel(const float *sr
   }
 }
 
+// out[i, 0:K] = src[idx[i], 0:K] for row-major matrices with row strides (elements) src_ld / out_ld: the send
+// buffer of one feature-column block of the halo exchange, gathered straight out of the activation matrix
+// (no strided view + index_select + contiguous copy).  VEC = 4: one 16-byte access per lane, K / 4 lanes per
+// row, rows coalesced.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gather_rows_ex_kernel(const float *__restrict__ src, int64_t src_ld,
+                                                                const int64_t *__restrict__ idx, int64_t n,
+                                                                int64_t K, float *__restrict__ out,
+                                                                int64_t out_ld) {
+  const int64_t kv = K / VEC;
+  const int64_t total = n * kv;
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < total; i += stride) {
+    const int64_t r = i / kv, c = (i - r * kv) * VEC;
+    const float *s = src + idx[r] * src_ld + c;
+    float *o = out + r * out_ld + c;
+    if (VEC == 4) {
+      *reinterpret_cast<float4 *>(o) = *reinterpret_cast<const float4 *>(s);
+    } else {
+      o[0] = s[0];
+    }
+  }
+}
+
 static inline int64_t grid_for(int64_t n) {
   int64_t g = ceil_div(n, kBlock);
   const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks: grid-stride the rest (guide G11)
@@ -403,6 +427,24 @@ extern "C" int ggl_gather_rows_f32(const float *src, const int32_t *perm, int64_
   if (E == 0) return GGL_OK;
   GGL_LAUNCH((gather_rows_f32_kernel), grid_for(E * H), kBlock, as_stream(stream), src, perm, E * H,
              H, out);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+extern "C" int ggl_gather_rows_f32_ex(const float *src, int64_t src_ld, const int64_t *idx, int64_t n, int64_t K,
+                                      float *out, int64_t out_ld, void *stream) {
+  GGL_REQUIRE(n >= 0 && K >= 0 && src_ld >= K && out_ld >= K, GGL_EINVAL, "bad arguments");
+  if (n == 0 || K == 0) return GGL_OK;
+  GGL_REQUIRE(src && idx && out, GGL_EINVAL, "NULL pointer");
+  const bool vec4 = K % 4 == 0 && src_ld % 4 == 0 && out_ld % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  // enough blocks in flight to cover the random-row latency (a pure gather: 32 blocks per CU)
+  int64_t g = ceil_div(n * (vec4 ? K / 4 : K), kBlock);
+  if (g > 256 * 32) g = 256 * 32;
+  if (vec4)
+    GGL_LAUNCH((gather_rows_ex_kernel<4>), g, kBlock, as_stream(stream), src, src_ld, idx, n, K, out, out_ld);
+  else
+    GGL_LAUNCH((gather_rows_ex_kernel<1>), g, kBlock, as_stream(stream), src, src_ld, idx, n, K, out, out_ld);
   GGL_LAUNCH_CHECK();
   return GGL_OK;
 }

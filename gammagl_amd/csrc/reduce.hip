@@ -31,10 +31,14 @@ enum Mode {
   MODE_BSPMM = 2,      // value = w[.,h] * x[col[p],h,:],    h = k / C
   MODE_MEANBWD = 3,    // value = g[col[p],:] / count[col[p]] * w       (spmm_mean_cpu.cpp:95-101)
   MODE_MAXBWD = 4,     // value = w * g[col[p],k] if argsrc[col[p],k] == row (spmm_max_cpu.cpp:88-93)
-  MODE_SPMM_EPI = 5    // MODE_SPMM + the layer epilogue applied to the finished row before its only store:
-                       // y = dropout(relu(sum + bias))  (gcn_conv.py:105-106, models/gcn.py:55-59)
+  MODE_SPMM_EPI = 5,   // MODE_SPMM + the layer epilogue applied to the finished row before its only store:
+                       // y = dropout(relu(reduced + add[row] + bias))  (gcn_conv.py:105-106, models/gcn.py:55-59;
+                       // add = SAGEConv's fc_self(x_dst) term, sage_conv.py:100-108)
+  MODE_SEG_EPI = 6     // MODE_SEG + the same epilogue (the message() + aggregate() route of a sampled block)
 };
 constexpr bool spmm_like(int mode) { return mode == MODE_SPMM || mode == MODE_SPMM_EPI; }
+constexpr bool seg_like(int mode) { return mode == MODE_SEG || mode == MODE_SEG_EPI; }
+constexpr bool epi_mode(int mode) { return mode == MODE_SPMM_EPI || mode == MODE_SEG_EPI; }
 
 // How positions map to element / weight indices, fixed at compile time for the hot f32 kernels so
 // the inner loop carries no pointer tests:
@@ -67,6 +71,10 @@ struct ReduceDims {
   int epi_vec;
   uint32_t epi_thresh;
   float epi_scale;
+  // a column block [epi_col0, epi_col0 + K) of a row of epi_K columns: the dropout word of element (row, k)
+  // is the one the full-width launch draws, so a result assembled block by block carries the same mask
+  int64_t epi_K, epi_col0;
+  int64_t add_ld;          // row stride of epi_add
 };
 
 template <typename S> struct RPtrs {
@@ -79,6 +87,7 @@ template <typename S> struct RPtrs {
   const int64_t *__restrict__ aux_arg;
   const float *__restrict__ epi_bias;
   const int64_t *__restrict__ epi_rng;
+  const float *__restrict__ epi_add;
 };
 
 // ---- VEC-wide loads / stores of storage elements ------------------------------------------------
@@ -140,12 +149,12 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
   const int64_t K = d.K;
   const int64_t head = (MODE == MODE_BSPMM) ? kk / d.C : 0;
   // resolve the index mode (compile time unless IDX_RUNTIME)
-  const bool seg_perm = (MODE == MODE_SEG) && (IDX == IDX_RUNTIME ? q.perm != nullptr : IDX == IDX_PERM);
-  const bool has_w = (MODE != MODE_SEG) && (IDX == IDX_RUNTIME ? q.w != nullptr : IDX != IDX_NONE);
+  const bool seg_perm = seg_like(MODE) && (IDX == IDX_RUNTIME ? q.perm != nullptr : IDX == IDX_PERM);
+  const bool has_w = !seg_like(MODE) && (IDX == IDX_RUNTIME ? q.w != nullptr : IDX != IDX_NONE);
   const bool w_perm = has_w && (IDX == IDX_RUNTIME ? (!d.w_by_pos && q.perm != nullptr) : IDX == IDX_PERM);
 
   auto element = [&](int64_t p, int64_t &xrow, float &wv, int64_t &who) {
-    if (MODE == MODE_SEG) {
+    if (seg_like(MODE)) {
       const int64_t e = seg_perm ? (int64_t)q.perm[p] : p;
       xrow = e;
       who = e;
@@ -239,25 +248,8 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
                                            int64_t len, int64_t kk, typename TT<T>::A (&acc)[VEC],
                                            const int64_t (&arg)[VEC]) {
   using S = typename TT<T>::S;
-  if (MODE == MODE_SPMM_EPI) {
-    uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    const int64_t ev = d.epi_vec;
-    if (d.epi_thresh) {
-      const int64_t KV = (K + ev - 1) / ev;
-      const U4 u = philox4x32_10((uint64_t)(row * KV + kk / ev), (uint64_t)q.epi_rng[1], (uint64_t)q.epi_rng[0]);
-      rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
-    }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float v = (float)acc[i];
-      if (q.epi_bias) v = __fadd_rn(v, q.epi_bias[kk + i]);
-      if (d.epi_relu) v = (v < 0.0f) ? 0.0f : v;
-      if (d.epi_thresh) v = (rw[(kk + i) % ev] >= d.epi_thresh) ? __fmul_rn(v, d.epi_scale) : 0.0f;
-      acc[i] = (typename TT<T>::A)v;
-    }
-  }
   if (OP == OP_MEAN) {
-    if (MODE == MODE_SEG) {
+    if (seg_like(MODE)) {
       // segment_mean_cpu.cpp:67-76: count lives in x's dtype; divide only where count > 1
       const typename TT<T>::A c = TT<T>::count(len);
       if (TT<T>::gt1(c)) {
@@ -270,6 +262,27 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = (typename TT<T>::A)__fdiv_rn((float)acc[i], (float)len);
       }
+    }
+  }
+  if (epi_mode(MODE)) {
+    uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    const int64_t ev = d.epi_vec;
+    const int64_t kg = d.epi_col0 + kk;  // column of acc[0] in the full epi_K-wide row
+    if (d.epi_thresh) {
+      const int64_t KV = (d.epi_K + ev - 1) / ev;
+      const U4 u = philox4x32_10((uint64_t)(row * KV + kg / ev), (uint64_t)q.epi_rng[1], (uint64_t)q.epi_rng[0]);
+      rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
+    }
+    float addv[VEC];
+    if (q.epi_add) VecIO<float, VEC>::load(q.epi_add + row * d.add_ld + kk, addv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float v = (float)acc[i];
+      if (q.epi_add) v = __fadd_rn(v, addv[i]);
+      if (q.epi_bias) v = __fadd_rn(v, q.epi_bias[kk + i]);
+      if (d.epi_relu) v = (v < 0.0f) ? 0.0f : v;
+      if (d.epi_thresh) v = (rw[(kg + i) % ev] >= d.epi_thresh) ? __fmul_rn(v, d.epi_scale) : 0.0f;
+      acc[i] = (typename TT<T>::A)v;
     }
   }
   S o[VEC];
@@ -286,8 +299,9 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
   const S *__restrict__ x, const int32_t *__restrict__ perm, const int32_t *__restrict__ col,      \
       const float *__restrict__ w, const int64_t *__restrict__ rowptr,                             \
       const int64_t *__restrict__ aux_rowptr, const int64_t *__restrict__ aux_arg,                 \
-      const float *__restrict__ epi_bias, const int64_t *__restrict__ epi_rng
-#define GGL_RPTR_PACK(S) RPtrs<S> q{x, perm, col, w, rowptr, aux_rowptr, aux_arg, epi_bias, epi_rng}
+      const float *__restrict__ epi_bias, const int64_t *__restrict__ epi_rng,                      \
+      const float *__restrict__ epi_add
+#define GGL_RPTR_PACK(S) RPtrs<S> q{x, perm, col, w, rowptr, aux_rowptr, aux_arg, epi_bias, epi_rng, epi_add}
 
 // ---- the one launch: chunks of long rows first, then every row with len <= chunk -----------------
 // Blocks [0, chunk_blocks) each reduce 4 chunks of long rows (one wavefront per chunk) into the
@@ -381,11 +395,13 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
                                                             int64_t *__restrict__ argout,
                                                             const float *__restrict__ epi_bias,
                                                             const int64_t *__restrict__ epi_rng,
+                                                            const float *__restrict__ epi_add,
                                                             const ReduceDims d) {
   using A = typename TT<T>::A;
   RPtrs<typename TT<T>::S> q{};
   q.epi_bias = epi_bias;
   q.epi_rng = epi_rng;
+  q.epi_add = epi_add;
   const int64_t j = block_id();  // one block per long row
   if (j >= d.n_long) return;
   const int64_t row = long_rows[j];
@@ -435,11 +451,14 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   int64_t *partial_arg;
   int64_t x_ld, out_ld;    // 0 = dense (K)
   int accumulate;
-  const float *epi_bias;   // MODE_SPMM_EPI
+  const float *epi_bias;   // epilogue modes
   const int64_t *epi_rng;
   int epi_relu;
   uint32_t epi_thresh;
   float epi_scale;
+  const float *epi_add;
+  int64_t add_ld;
+  int64_t epi_K, epi_col0; // 0 / 0 = the launch covers whole rows
 };
 
 static inline int pow2_ceil_log2(int64_t v) {
@@ -449,7 +468,7 @@ static inline int pow2_ceil_log2(int64_t v) {
 }
 
 #define GGL_RPTR_ARGS(S)                                                                           \
-  static_cast<const S *>(a.x), a.perm, a.col, a.w, a.rowptr, a.aux_rowptr, a.aux_arg, a.epi_bias, a.epi_rng
+  static_cast<const S *>(a.x), a.perm, a.col, a.w, a.rowptr, a.aux_rowptr, a.aux_arg, a.epi_bias, a.epi_rng, a.epi_add
 
 template <typename T, int VEC, int OP, int MODE, int IDX>
 static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
@@ -487,7 +506,7 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
   if (a.n_long > 0) {
     GGL_LAUNCH((long_final_kernel<T, OP, MODE>), a.n_long, kBlock, stream, a.rowptr, a.long_rows,
                a.chunk_ptr, static_cast<const S *>(a.partial), (const int64_t *)a.partial_arg, out,
-               a.arg, a.epi_bias, a.epi_rng, d);
+               a.arg, a.epi_bias, a.epi_rng, a.epi_add, d);
     GGL_LAUNCH_CHECK();
   }
   return GGL_OK;
@@ -501,7 +520,9 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   d.n_long = a.n_long; d.n_chunks = a.n_chunks; d.w_by_pos = a.w_by_pos;
   d.x_ld = a.x_ld > 0 ? a.x_ld : a.K; d.out_ld = a.out_ld > 0 ? a.out_ld : a.K; d.accumulate = a.accumulate;
   d.epi_relu = a.epi_relu; d.epi_thresh = a.epi_thresh; d.epi_scale = a.epi_scale;
-  d.epi_vec = (a.K % 4 == 0) ? 4 : 1;
+  d.epi_K = a.epi_K > 0 ? a.epi_K : a.K; d.epi_col0 = a.epi_col0;
+  d.epi_vec = (d.epi_K % 4 == 0) ? 4 : 1;
+  d.add_ld = a.add_ld > 0 ? a.add_ld : a.K;
   const int64_t kv = ceil_div(a.K, VEC);
   d.logL = pow2_ceil_log2(kv < kWave ? kv : kWave);
   if (d.logL > 6) d.logL = 6;
@@ -512,7 +533,7 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   if (a.N <= 0 || a.K <= 0) return GGL_OK;
   if constexpr (!STATIC_IDX) {
     return launch_idx<T, VEC, OP, MODE, IDX_RUNTIME>(a, d, stream);
-  } else if constexpr (MODE == MODE_SEG) {
+  } else if constexpr (seg_like(MODE)) {
     if (a.perm) return launch_idx<T, VEC, OP, MODE, IDX_PERM>(a, d, stream);
     return launch_idx<T, VEC, OP, MODE, IDX_DIRECT>(a, d, stream);
   } else {
@@ -526,10 +547,11 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <int OP, int MODE>
 static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
-  constexpr bool kStatic = (MODE == MODE_SEG || spmm_like(MODE));
+  constexpr bool kStatic = (seg_like(MODE) || spmm_like(MODE));
   const bool vec4 = !options().force_generic && (a.K % 4 == 0) && aligned16(a.x) &&
                     aligned16(a.out) && (!a.partial || aligned16(a.partial)) &&
-                    (a.x_ld % 4 == 0) && (a.out_ld % 4 == 0) && (MODE != MODE_BSPMM || a.C % 4 == 0);
+                    (a.x_ld % 4 == 0) && (a.out_ld % 4 == 0) && (MODE != MODE_BSPMM || a.C % 4 == 0) &&
+                    (!a.epi_add || (aligned16(a.epi_add) && a.add_ld % 4 == 0));
   if (vec4) return launch_typed<float, 4, OP, MODE, kStatic>(a, stream);
   return launch_typed<float, 1, OP, MODE, kStatic>(a, stream);
 }
@@ -715,6 +737,70 @@ extern "C" int ggl_spmm_sum_bias_act(const ggl_segplan_t *plan, const int32_t *c
   a.epi_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
   a.epi_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
   rc = launch_f32<OP_SUM, MODE_SPMM_EPI>(a, as_stream(stream));
+  if (rc) return rc;
+  if (a.epi_thresh && plan->N > 0 && K > 0) return rng_advance(rng_state, stream);
+  return GGL_OK;
+}
+
+// The general epilogue form behind ggl_spmm_sum_bias_act: sum or mean, strided x / out (a column block of a
+// wider matrix), accumulate (a second edge set added onto an existing partial result: the halo-source edges of
+// the multi-GPU path, whose epilogue therefore rides on the LAST block added), an extra per-row term
+// `add` (SAGEConv: mean + fc_self(x_dst) + bias -> act, sage_conv.py:100-108) and the dropout word of element
+// (row, epi_col0 + k) of an epi_K-wide row, so that column blocks assemble the mask of the full-width launch.
+// `bias` and `add` point at the block's first column.  advance_rng != 0 steps the rng state afterwards
+// (once per logical layer: set it on the last column block only).
+extern "C" int ggl_spmm_epi_ex(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                               const float *x, int64_t x_ld, int64_t K, float *out, int64_t out_ld,
+                               int accumulate, int mean, const float *add, int64_t add_ld, const float *bias,
+                               int relu, float p_drop, int64_t *rng_state, int64_t epi_K, int64_t epi_col0,
+                               int advance_rng, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
+  if (rc) return rc;
+  GGL_REQUIRE((x_ld == 0 || x_ld >= K) && (out_ld == 0 || out_ld >= K) && (add_ld == 0 || add_ld >= K),
+              GGL_EINVAL, "row stride < K");
+  GGL_REQUIRE(!(mean && accumulate), GGL_EINVAL, "mean cannot accumulate onto a partial result");
+  GGL_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, GGL_EINVAL, "p_drop must be in [0, 1)");
+  GGL_REQUIRE(p_drop == 0.0f || rng_state, GGL_EINVAL, "dropout needs an rng_state");
+  GGL_REQUIRE(epi_col0 >= 0 && (epi_K == 0 || epi_col0 + K <= epi_K), GGL_EINVAL, "column block outside the row");
+  a.x_ld = x_ld; a.out_ld = out_ld; a.accumulate = accumulate ? 1 : 0;
+  a.epi_bias = bias;
+  a.epi_add = add; a.add_ld = add_ld;
+  a.epi_rng = rng_state;
+  a.epi_relu = relu ? 1 : 0;
+  a.epi_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  a.epi_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  a.epi_K = epi_K; a.epi_col0 = epi_col0;
+  rc = mean ? launch_f32<OP_MEAN, MODE_SPMM_EPI>(a, as_stream(stream))
+            : launch_f32<OP_SUM, MODE_SPMM_EPI>(a, as_stream(stream));
+  if (rc) return rc;
+  if (a.epi_thresh && advance_rng && plan->N > 0 && K > 0) return rng_advance(rng_state, stream);
+  return GGL_OK;
+}
+
+// segment_sum / segment_mean of f32 messages x[E, K] with the same epilogue on the finished row: the
+// message() + aggregate() route of a sampled SAGEConv block with "+ fc_self(x_dst) + bias -> act" fused into
+// the store.  Bit-identical to ggl_segment_{sum,mean} followed by the adds in torch.
+extern "C" int ggl_segment_epi(const float *x, const ggl_segplan_t *plan, int64_t K, int mean, const float *add,
+                               int64_t add_ld, const float *bias, int relu, float p_drop, int64_t *rng_state,
+                               float *out, void *stream) {
+  ReduceArgs a{};
+  int rc = fill_plan(a, plan, GGL_F32, K, false);
+  if (rc) return rc;
+  GGL_REQUIRE((x || plan->E * K == 0) && (out || plan->N * K == 0), GGL_EINVAL, "x/out is NULL");
+  GGL_REQUIRE(add_ld == 0 || add_ld >= K, GGL_EINVAL, "row stride < K");
+  GGL_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, GGL_EINVAL, "p_drop must be in [0, 1)");
+  GGL_REQUIRE(p_drop == 0.0f || rng_state, GGL_EINVAL, "dropout needs an rng_state");
+  a.x = x;
+  a.out = out;
+  a.epi_bias = bias;
+  a.epi_add = add; a.add_ld = add_ld;
+  a.epi_rng = rng_state;
+  a.epi_relu = relu ? 1 : 0;
+  a.epi_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  a.epi_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  rc = mean ? launch_f32<OP_MEAN, MODE_SEG_EPI>(a, as_stream(stream))
+            : launch_f32<OP_SUM, MODE_SEG_EPI>(a, as_stream(stream));
   if (rc) return rc;
   if (a.epi_thresh && plan->N > 0 && K > 0) return rng_advance(rng_state, stream);
   return GGL_OK;

@@ -15,10 +15,13 @@
 
 namespace ggl {
 
+// Counter = (row a, draw b, call offset): every word of the counter block is its own coordinate, so draws of
+// different calls never share a counter (an offset XORed into the draw index made call n, draw j collide with
+// call n ^ j, draw 0); the key carries a stream tag, so the sampler's words are also disjoint from the dropout
+// masks drawn from the same {seed, offset} state.  a, b < 2^32 (checked at launch).
 __device__ __forceinline__ uint32_t philox_u32(uint64_t a, uint64_t b, uint64_t seed, uint64_t offset) {
-  uint32_t c0 = (uint32_t)a, c1 = (uint32_t)(a >> 32), c2 = (uint32_t)b ^ (uint32_t)offset,
-           c3 = (uint32_t)(b >> 32) ^ (uint32_t)(offset >> 32);
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t c0 = (uint32_t)a, c1 = (uint32_t)b, c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+  uint32_t k0 = (uint32_t)seed ^ 0x53414D50u /* 'SAMP' */, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -149,6 +152,7 @@ extern "C" int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const 
   if (B == 0) return GGL_OK;
   // col may be NULL for a graph without edges: it is only read at positions the rows own
   GGL_REQUIRE(rowptr && seeds && out_rowptr && rng_state && e_pos && nbr, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE(B < ((int64_t)1 << 32) && fanout < ((int64_t)1 << 32), GGL_EINVAL, "batch / fan-out >= 2^32");
   hipStream_t s = as_stream(stream);
   GGL_LAUNCH((sample_pick_kernel), grid_for(B), kBlock, s, rowptr, col, seeds, B, fanout, replace,
              out_rowptr, (const int64_t *)rng_state, e_pos, nbr);

@@ -28,6 +28,7 @@ import torch.nn.functional as F
 
 from . import engine as _default_engine
 from .dense import wgrad
+from .ops import _ptr
 
 HALO_CHUNKS = int(os.environ.get("GGL_HALO_CHUNKS", "0"))  # 0 = automatic (4 at K >= 256, 2 at K >= 128)
 
@@ -42,8 +43,19 @@ def balanced_bounds(dst, num_nodes, world):
     return [0] + [int(c) for c in cuts.tolist()] + [int(num_nodes)]
 
 
+class _Done:
+    """Stand-in for a collective's work handle where nothing travels (dry runs)."""
+
+    def wait(self):
+        return True
+
+
 class PartitionedGraph:
-    """This rank's share of a weighted graph, plus everything the halo exchange needs."""
+    """This rank's share of a weighted graph, plus everything the halo exchange needs.
+
+    Two ways in: from the global edge list (every rank filters it: small graphs and tests), or —
+    `from_local` — from the edges this rank already owns (`synth.rmat_partitioned`: no rank ever sees the
+    whole list; the only route to a papers100M-sized graph)."""
 
     def __init__(self, edge_index, edge_weight, num_nodes, rank=0, world=1, group=None, eng=None,
                  bounds=None, self_halo_from=None):
@@ -51,17 +63,36 @@ class PartitionedGraph:
         local rows >= that global id as if they lived on a remote rank, so the complete exchange path
         (send lists, all-to-all-v with itself, halo SpMM, reverse exchange) runs through RCCL on a
         single GPU."""
+        src, dst = edge_index[0], edge_index[1]
+        bounds = bounds or balanced_bounds(dst, num_nodes, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        mine = (dst >= lo) & (dst < hi)
+        self._setup(src[mine], dst[mine] - lo, edge_weight[mine], bounds, num_nodes, int(edge_index.shape[1]),
+                    rank, world, group, eng, self_halo_from=self_halo_from)
+
+    @classmethod
+    def from_local(cls, src, dst_local, w, bounds, num_nodes, e_global, rank=0, world=1, group=None, eng=None,
+                   send_rows=None):
+        """`src` global source ids / `dst_local` local destination ids / `w` weights of the edges whose
+        destination this rank owns.  `send_rows` (a list with one tensor of local row ids per peer) makes it a
+        DRY partition: the process plays rank `rank` of a len(send_rows)-way partition on its own — send lists
+        as given, buffers and kernels exactly as in a real run, nothing on the wire (one GPU measuring one
+        rank's share of a graph that needs eight)."""
+        pg = cls.__new__(cls)
+        pg._setup(src, dst_local, w, bounds, num_nodes, e_global, rank, world, group, eng, send_rows=send_rows)
+        return pg
+
+    def _setup(self, s, d, w, bounds, num_nodes, e_global, rank, world, group, eng, self_halo_from=None,
+               send_rows=None):
         self.eng = eng if eng is not None else _default_engine()
         self.rank, self.world, self.group = rank, world, group
-        self.comm = world > 1 or self_halo_from is not None
-        dev = edge_index.device
-        src, dst = edge_index[0], edge_index[1]
-        self.bounds = bounds or balanced_bounds(dst, num_nodes, world)
+        self.dry = send_rows is not None
+        self.comm = world > 1 or self_halo_from is not None or self.dry
+        dev = s.device
+        self.bounds = list(bounds)
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
         self.lo, self.hi, self.n_local, self.n_global = lo, hi, hi - lo, int(num_nodes)
-        self.e_global = int(edge_index.shape[1])
-        mine = (dst >= lo) & (dst < hi)
-        s, d, w = src[mine], dst[mine] - lo, edge_weight[mine]
+        self.e_global = int(e_global)
         self.e_local = int(s.shape[0])
         is_loc = (s >= lo) & (s < (hi if self_halo_from is None else int(self_halo_from)))
         # edges whose source row is local
@@ -69,7 +100,8 @@ class PartitionedGraph:
         self.w_loc = w[is_loc].contiguous()
         self.gp_loc = self.eng.graph_plan(self.ei_loc, self.n_local, self.n_local)
         # edges whose source row lives elsewhere: halo buffer ordered by global id (= by owner)
-        rs, rd = s[~is_loc], d[~is_loc]
+        rem = ~is_loc
+        rs, rd = s[rem], d[rem]
         self.halo_ids = torch.unique(rs)  # sorted
         self.n_halo = int(self.halo_ids.shape[0])
         bt = torch.tensor(self.bounds, device=dev, dtype=torch.int64)
@@ -77,12 +109,16 @@ class PartitionedGraph:
         self.recv_splits = (owner_start[1:] - owner_start[:-1]).tolist()
         if self.n_halo > 0:
             self.ei_halo = torch.stack([torch.searchsorted(self.halo_ids, rs), rd]).contiguous()
-            self.w_halo = w[~is_loc].contiguous()
+            self.w_halo = w[rem].contiguous()
             self.gp_halo = self.eng.graph_plan(self.ei_halo, self.n_local, self.n_halo)
         else:
             self.ei_halo = self.w_halo = self.gp_halo = None
-        # tell every owner which of its rows we need
-        if self.comm:
+        del rs, rd, rem, is_loc
+        # tell every owner which of its rows we need (only halo ids travel, never an edge list)
+        if self.dry:
+            self.send_splits = [int(t.numel()) for t in send_rows]
+            self.send_idx = torch.cat([t.to(torch.int64) for t in send_rows]).contiguous()
+        elif self.comm:
             rc = torch.tensor(self.recv_splits, device=dev, dtype=torch.int64)
             sc = torch.empty_like(rc)
             dist.all_to_all_single(sc, rc, group=group)
@@ -91,22 +127,28 @@ class PartitionedGraph:
             dist.all_to_all_single(req, self.halo_ids.contiguous(), self.send_splits, self.recv_splits,
                                    group=group)
             self.send_idx = (req - lo).contiguous()
-            assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
         else:
             self.send_splits = [0]
             self.send_idx = torch.empty(0, device=dev, dtype=torch.int64)
+        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
         self.n_send = int(self.send_idx.shape[0])
         self.send_plan = self.eng.seg_plan(self.send_idx, self.n_local) if self.n_send > 0 else None
 
     # ---- raw building blocks -------------------------------------------------------------------
     def _a2a(self, out_rows, inp, out_splits, in_splits):
         out = torch.empty((out_rows,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+        if self.dry:  # nothing travels: the receive buffer keeps whatever it holds (finite values for timing)
+            out.zero_()
+            return out, _Done()
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
         return out, work
 
-    def aggregate(self, h):
-        """out[i] = sum_{j->i} w_ij h[j] for the local rows i (autograd-aware)."""
-        return _HaloAggregate.apply(h, self)
+    def aggregate(self, h, bias=None, relu=False, p_drop=0.0, training=True):
+        """out[i] = dropout(relu(sum_{j->i} w_ij h[j] + bias)) for the local rows i (autograd-aware).  The
+        epilogue (gcn_conv.py:105-106, models/gcn.py:55-59) rides on the store of the LAST edge block added:
+        the local SpMM when this rank has no halo, the halo-source SpMM otherwise."""
+        p = float(p_drop) if training else 0.0
+        return _HaloAggregate.apply(h, self, bias, bool(relu), p)
 
 
 class _HaloAggregate(torch.autograd.Function):
@@ -129,30 +171,79 @@ class _HaloAggregate(torch.autograd.Function):
         return [(i * w, (i + 1) * w) for i in range(n)]
 
     @staticmethod
-    def forward(ctx, h, pg):
+    def forward(ctx, h, pg, bias, relu, p_drop):
         eng = pg.eng
         ctx.k_orig = h.shape[1]
+        epi = bias is not None or relu or p_drop > 0
+        fused = epi and h.shape[1] % 4 == 0   # (odd widths: aggregate on padded rows, epilogue as its own pass)
         h = _HaloAggregate._pad4(h.contiguous())
+        K = h.shape[1]
+        rng = eng._rng_state(h.device) if (fused and p_drop > 0) else None
+        ctx.rng_used = rng.clone() if rng is not None else None
+        b = bias.contiguous().reshape(-1) if (fused and bias is not None) else None
         works = []
         if pg.comm:
-            for (c0, c1) in _HaloAggregate._chunks(h.shape[1]):
-                send = h.index_select(0, pg.send_idx) if c1 - c0 == h.shape[1] else \
-                    h[:, c0:c1].index_select(0, pg.send_idx).contiguous()
+            for (c0, c1) in _HaloAggregate._chunks(K):
+                send = torch.empty((pg.n_send, c1 - c0), dtype=h.dtype, device=h.device)
+                if pg.n_send > 0:  # one kernel: rows of the column block straight into the send buffer
+                    eng.gather_rows_into(h[:, c0:c1], pg.send_idx, send)
                 recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits)
                 works.append((c0, c1, recv, work))
-        out, _ = eng._spmm_fwd("sum", pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, pg.n_local)  # overlaps the exchange
-        for (c0, c1, recv, work) in works:
+        out = torch.empty((pg.n_local, K), dtype=torch.float32, device=h.device)
+        last_is_local = fused and (not pg.comm or pg.n_halo == 0)
+        # local-source edges: overlaps the exchange
+        if last_is_local:
+            eng.spmm_epi_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out, bias=b, relu=relu, p_drop=p_drop,
+                              rng=rng, epi_K=K)
+        else:
+            eng.spmm_sum_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out)
+        for i, (c0, c1, recv, work) in enumerate(works):
             work.wait()
-            if pg.n_halo > 0:  # halo-source edges added onto the column block in place (ggl_spmm_sum_ex)
-                eng.spmm_sum_into(pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, out[:, c0:c1], accumulate=True)
-        ctx.pg = pg
-        return out if out.shape[1] == ctx.k_orig else out[:, :ctx.k_orig].contiguous()
+            if pg.n_halo > 0:  # halo-source edges added onto the column block in place
+                if fused:
+                    eng.spmm_epi_into(pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, out[:, c0:c1], accumulate=True,
+                                      bias=b, relu=relu, p_drop=p_drop, rng=rng, epi_K=K, col0=c0,
+                                      advance_rng=(i == len(works) - 1))
+                else:
+                    eng.spmm_sum_into(pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, out[:, c0:c1], accumulate=True)
+        if out.shape[1] != ctx.k_orig:
+            out = out[:, :ctx.k_orig].contiguous()
+        if epi and not fused:
+            rng = eng._rng_state(h.device) if p_drop > 0 else None
+            ctx.rng_used = rng.clone() if rng is not None else None
+            y = torch.empty_like(out)
+            bb = bias.contiguous().reshape(-1) if bias is not None else None
+            eng._check(eng.lib.ggl_bias_act_fwd(_ptr(out), _ptr(bb), out.shape[0], out.shape[1], int(relu),
+                                                float(p_drop), _ptr(rng), _ptr(y), eng._stream(out.device)))
+            out = y
+        ctx.pg, ctx.epi = pg, (epi, relu, p_drop, None if bias is None else bias.shape)
+        if epi:
+            ctx.save_for_backward(out)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         pg = ctx.pg
         eng = pg.eng
-        g = _HaloAggregate._pad4(g.contiguous())
+        g = g.contiguous()
+        epi, relu, p_drop, bshape = ctx.epi
+        gb = None
+        if epi:  # through dropout / ReLU / + bias in one pass (mask redrawn from the saved rng state)
+            (y,) = ctx.saved_tensors
+            N, K0 = int(g.shape[0]), int(g.shape[1])
+            ga = torch.empty_like(g)
+            gb = torch.empty(K0, dtype=torch.float32, device=g.device) if bshape is not None else None
+            wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K0)
+            ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=g.device)
+            eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K0, int(relu), float(p_drop),
+                                                _ptr(ctx.rng_used), _ptr(ga), _ptr(gb), _ptr(ws), wsb,
+                                                eng._stream(g.device)))
+            g = ga
+            if gb is not None:
+                gb = gb.reshape(bshape)
+        if not ctx.needs_input_grad[0]:
+            return None, None, gb, None, None
+        g = _HaloAggregate._pad4(g)
         works = []
         if pg.comm:
             for (c0, c1) in _HaloAggregate._chunks(g.shape[1]):
@@ -166,7 +257,7 @@ class _HaloAggregate(torch.autograd.Function):
             work.wait()
             if pg.n_send > 0:  # deterministic scatter-add of the returned rows, onto the column block in place
                 eng.segment_sum_into(gsend, pg.send_plan, gh[:, c0:c1], accumulate=True)
-        return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None
+        return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None, gb, None, None
 
 
 class _LinearSideWgrad(torch.autograd.Function):
@@ -250,13 +341,9 @@ class DistGCN(torch.nn.Module):
             h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink, pad)
             bias = self.bias[i] if not pad else F.pad(self.bias[i], (0, pad))
             p = self.dropout.p if hidden else 0.0
-            if not pg.comm and h.shape[1] % 4 == 0:
-                # no halo to add afterwards: + bias, ReLU and dropout ride on the SpMM's only store
-                x = pg.eng.spmm_bias_act(pg.gp_loc, pg.w_loc, h, bias, relu=hidden, p_drop=p,
-                                         training=self.training)
-            else:
-                # + bias, ReLU and dropout of the hidden layers fused into one pass each way (epilogue.hip)
-                x = pg.eng.bias_act(pg.aggregate(h), bias, relu=hidden, p_drop=p, training=self.training)
+            # + bias, ReLU and dropout ride on the store of the last edge block added to a row: the local SpMM
+            # on one GPU, the halo-source SpMM behind the exchange otherwise (reduce.hip MODE_SPMM_EPI)
+            x = pg.aggregate(h, bias, relu=hidden, p_drop=p, training=self.training)
             if pad:
                 x = x[:, :n_out]
         return x
@@ -292,42 +379,40 @@ class DistGCNTrainer:
         return loss.detach()
 
 
+def build_partition(n_nodes, n_edges, seed, rank, world, group, dev, eng, relabel="random", order="src",
+                    parts=None, stats=None):
+    """This rank's PartitionedGraph of the synthetic benchmark graph, built WITHOUT a global edge list:
+    `synth.rmat_partitioned` hands every rank only the edges whose destination it owns (same graph for
+    every world size), the halo bookkeeping exchanges node ids only.  `parts` > world == 1: a dry
+    partition — this process plays rank `rank` of `parts` (one GPU measuring one rank's share)."""
+    from .synth import rmat_partitioned
+
+    g = rmat_partitioned(n_nodes, n_edges, seed=seed, rank=rank, world=world, group=group, device=dev,
+                         relabel=relabel, order=order, parts=parts, stats=stats)
+    dry = world == 1 and (parts or 1) > 1
+    pg = PartitionedGraph.from_local(g["src"], g["dst"], g["w"], g["bounds"], n_nodes, g["e_global"],
+                                     rank=g["rank"], world=world, group=group, eng=eng,
+                                     send_rows=g.get("send_rows") if dry else None)
+    return pg
+
+
 def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls, eng=None):
     """bench.py body for any world size (world == 1 degenerates to no exchange)."""
-    from .synth import rmat_graph
-
     eng = eng if eng is not None else _default_engine()
     t_gen = time.perf_counter()
-    if rank == 0 or world == 1:
-        ei = rmat_graph(n_nodes, n_edges, seed=args.seed, device=dev, relabel=args.relabel, order=args.order)
-    if world > 1:
-        # one generator, one graph: rank 0 builds the edge list and broadcasts it (2 GB over xGMI) so the
-        # partition bookkeeping can never disagree between ranks
-        shape = torch.tensor(list(ei.shape) if rank == 0 else [0, 0], device=dev, dtype=torch.int64)
-        dist.broadcast(shape, src=0)
-        if rank != 0:
-            ei = torch.empty(tuple(shape.tolist()), device=dev, dtype=torch.int64)
-        dist.broadcast(ei, src=0)
-    E = int(ei.shape[1])
-    # calc_gcn_norm (utils/norm.py:24-30) through `eng`: graph-constant, computed once and handed to the
-    # model as edge_weight with norm='none'
-    deg = eng.c_segment_sum(torch.ones((E, 1), device=dev), ei[0].contiguous(), n_nodes).reshape(-1)
-    dis = deg.pow(-0.5)
-    w = (dis[ei[0]] * dis[ei[1]]).contiguous()
-    del deg, dis
-    eng.seg_cache.clear()
-    eng.graph_cache.clear()
-    pg = PartitionedGraph(ei, w, n_nodes, rank, world, eng=eng)
-    del ei, w
+    stats = {}
+    pg = build_partition(n_nodes, n_edges, args.seed, rank, world, None, dev, eng, relabel=args.relabel,
+                         order=args.order, stats=stats)
+    E = pg.e_global
     if dev.type == "cuda":
         torch.cuda.empty_cache()
         torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
-    gen = torch.Generator(device=dev).manual_seed(args.seed)
-    x = torch.randn(n_nodes, f_in, generator=gen, device=dev)[pg.lo:pg.hi].contiguous()
-    y = torch.randint(0, n_cls, (n_nodes,), generator=gen, device=dev)[pg.lo:pg.hi].contiguous()
-    train_mask = torch.rand(n_nodes, generator=gen, device=dev) < 0.08
-    train_local = torch.nonzero(train_mask[pg.lo:pg.hi]).reshape(-1)
+    # features / labels / train mask of the local rows only (no [N, F] tensor on any rank)
+    gen = torch.Generator(device=dev).manual_seed(args.seed + 7919 * (rank + 1))
+    x = torch.randn(pg.n_local, f_in, generator=gen, device=dev)
+    y = torch.randint(0, n_cls, (pg.n_local,), generator=gen, device=dev)
+    train_local = torch.nonzero(torch.rand(pg.n_local, generator=gen, device=dev) < 0.08).reshape(-1)
     nt = torch.tensor([train_local.numel()], device=dev, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(nt)  # the global train-set size every rank normalises its loss by
@@ -367,41 +452,46 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
     alg = e_loc * (4 * K + 8) + pg.n_local * (4 * K + 8)
     ms = max(ms, 1e-9)  # (the host-emulated test build reports 0)
     achieved = alg / (ms * 1e-3) / 1e9
-    # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
-    # WRITE_SIZE runs of tools/pmc_probe.py on the same graph; gfx950 read-side x2 correction applied by
-    # tools/pmc_summary.py) — only meaningful for the exact workload it was collected on
-    traffic = None
-    if world == 1 and args.workload == "products" and K == 256 and args.order == "src" and args.relabel == "random":
+    # HBM bytes per launch of this kernel: from the committed rocprofv3 --pmc passes of THIS workload
+    # (separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_probe.py on the same graph; gfx950 read-side x2
+    # correction applied by tools/pmc_summary.py) — reported with its source, never for another workload
+    traffic, traffic_source = None, None
+    if world == 1 and args.workload == "products" and K == 256 and args.order == "src" and args.relabel == "random" \
+            and args.seed == 0:
         try:
             import json
-            import os
 
-            prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                                "r1_pmc_products_k256.json")
-            traffic = json.load(open(prof))["ggl::row_reduce_kernel<float, 4, 0, 1, 1, true, 4>"]["hbm_bytes_per_launch"]
+            name = "r2_pmc_products_k256.json"
+            prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
+            rec = json.load(open(prof))
+            if int(rec.get("graph_edges", -1)) == E:
+                traffic = rec["spmm_sum_k256"]["hbm_bytes_per_launch"]
+                traffic_source = "profiles/" + name + " (rocprofv3 --pmc passes of tools/pmc_probe.py on this graph, not collected in this run)"
         except Exception:  # noqa: BLE001
             traffic = None
+    widths = [args.hidden] * (args.layers - 1) + [n_cls + (-n_cls) % 4]
     out = {
         "metric": "edges aggregated/sec, 3-layer GCN hidden=256 training step, ogbn-products-sized graph",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
         "config": {
             "workload": f"{args.workload}-sized R-MAT: N={n_nodes}, E={E} directed incl. self-loops, features "
                         f"{f_in}->{args.hidden}x{args.layers - 1}->{n_cls}, edge order={args.order}, relabel={args.relabel}, "
                         f"full-graph GCN train step (fwd+bwd+Adam), {n_agg} aggregations/step, symmetric-norm edge "
                         f"weights precomputed (GCNConv norm='none' + calc_gcn_norm edge_weight)",
-            "parallelism": f"node-partition x{world}, 1-hop halo all-to-all-v" if world > 1 else "1 GPU",
+            "parallelism": f"node-partition x{world}, 1-hop halo all-to-all-v, per-rank graph construction" if world > 1 else "1 GPU",
             "rank0_local_edges": pg.e_local, "rank0_halo_rows": pg.n_halo, "rank0_send_rows": pg.n_send,
+            "rank0_peak_edges_during_build": stats.get("peak_edges"),
             # rows received + sent by rank 0 per step: each aggregate moves the halo rows in (forward) or their
             # gradients out (backward) and the mirror image for the rows other ranks need, at the layer's width
-            "rank0_halo_GB_per_step": round(2 * (pg.n_halo + pg.n_send) * 4 *
-                                            sum([args.hidden] * (args.layers - 1) + [n_cls + (-n_cls) % 4]) / 1e9, 3),
+            "rank0_halo_GB_per_step": round(2 * (pg.n_halo + pg.n_send) * 4 * sum(widths) / 1e9, 3),
             "setup_s": round(t_gen, 2), "loss": float(lsum)},
         "roofline": {"bound": "hbm", "kernel": f"row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, K={K}, rank 0 local rows"
                                f"{', halo-source edges' if use_halo else ''})",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": traffic, "ms_per_launch": ms, "alg_bytes_per_launch": alg,
-                     "edges_per_s_kernel": e_loc / (ms * 1e-3)},
+                     "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms,
+                     "alg_bytes_per_launch": alg, "edges_per_s_kernel": e_loc / (ms * 1e-3)},
     }
-    return out
+    return out, pg

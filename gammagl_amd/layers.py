@@ -105,8 +105,11 @@ class MessagePassing(nn.Module):
               and x.dtype == torch.float32 and type(self).message is MessagePassing.message
               and type(self).aggregate is MessagePassing.aggregate
               # gspmm treats the edge weight as a constant (gspmm.cpp:30); a weight that needs a gradient
-              # must stay on the message() route, which differentiates through the multiply
-              and not (kwargs.get('edge_weight') is not None and kwargs['edge_weight'].requires_grad)):
+              # must stay on the message() route, which differentiates through the multiply — and so must a
+              # weight that is not one f32 value per edge (the message() route promotes / broadcasts it)
+              and not (kwargs.get('edge_weight') is not None and
+                       (kwargs['edge_weight'].requires_grad or kwargs['edge_weight'].dtype != torch.float32
+                        or kwargs['edge_weight'].numel() != edge_index.shape[1]))):
             # The default message() (gather * weight) + aggregate() pair IS an SpMM.  A big (full-graph) edge
             # list takes the fused rectangular kernel: no [E, K] message tensor (Reddit-sized SAGEConv layer:
             # 155 -> 14.7 ms forward+backward, 59 GB less HBM), same sums in the same order.  Sampled blocks stay
@@ -118,6 +121,8 @@ class MessagePassing(nn.Module):
             x = eng.spmm(gp, None if ew is None else ew.reshape(-1).contiguous(), x, aggr)
         elif (aggr == 'sum' and edge_index.shape[1] >= FUSED_MIN_EDGES and x.dim() == 3 and x.dtype == torch.float32
               and kwargs.get('edge_weight') is not None and kwargs['edge_weight'].dim() == 2
+              and kwargs['edge_weight'].dtype == torch.float32
+              and kwargs['edge_weight'].shape == (edge_index.shape[1], x.shape[1])
               and int(kwargs['num_nodes']) == x.shape[0] and type(self).message is MessagePassing.message
               and type(self).aggregate is MessagePassing.aggregate):
             # multi-head messages x[src,h,:] * w[e,h] summed per destination == bspmm (what GATConv's own
@@ -181,13 +186,17 @@ class GCNConv(MessagePassing):
         bias = self.bias
         if pad and bias is not None:
             bias = torch.nn.functional.pad(bias, (0, pad))
-        if weights.requires_grad:
+        if (weights.requires_grad or weights.dtype != torch.float32 or weights.dim() != 1
+                or weights.numel() != edge_index.shape[1]):
             # a learnable edge weight: gspmm treats weights as constants (gspmm.cpp:30), so stay on the
-            # message() * weight -> unsorted_segment_sum route, which differentiates through the multiply
+            # message() * weight -> unsorted_segment_sum route, which differentiates through the multiply; the
+            # same route takes weights that are not one f32 value per edge (a float64 edge_weight promotes the
+            # messages exactly as the reference's message() does, a mis-shaped one raises there as it does here)
             out = self.aggregate(self.message(x, edge_index, weights), edge_index, num_nodes, 'sum')
             if bias is not None or relu or p_drop > 0:
                 out = _engine().bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
-        elif x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0:
+        elif (x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0
+              and weights.dtype == torch.float32 and weights.numel() == edge_index.shape[1]):
             eng = _engine()
             out = eng.spmm_bias_act(eng.graph_plan(edge_index, num_nodes), weights, x, bias, relu=relu,
                                     p_drop=p_drop, training=training)

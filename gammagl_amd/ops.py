@@ -385,6 +385,40 @@ class Engine:
                                              int(bool(accumulate)), self._stream(dev)))
         return out
 
+    def gather_rows_into(self, src, idx, out):
+        """out[i, :] = src[idx[i], :] for 2-D f32 src / out that may be column blocks of wider matrices (one
+        kernel, no strided view + index_select + contiguous copy) — ggl_gather_rows_f32_ex."""
+        dev = src.device
+        n, K = int(idx.shape[0]), int(src.shape[1])
+        if out.shape[0] != n or out.shape[1] != K or idx.dtype != torch.int64:
+            raise RuntimeError("gather_rows_into: out must be [len(idx), columns of src], idx int64")
+        self._check(self.lib.ggl_gather_rows_f32_ex(_ptr(src), self._row_stride(src, "src"), _ptr(idx), n, K,
+                                                    _ptr(out), self._row_stride(out, "out"), self._stream(dev)))
+        return out
+
+    def spmm_epi_into(self, plan, col, w, x, out, accumulate=False, mean=False, add=None, bias=None, relu=False,
+                      p_drop=0.0, rng=None, epi_K=0, col0=0, advance_rng=True):
+        """out = dropout(relu(reduce(A x) (+ out) + add + bias)) on column blocks, no autograd — ggl_spmm_epi_ex.
+        `bias` [>= col0 + K] is the full-width bias; `add` a [N, K] block view."""
+        dev = x.device
+        K = int(x.shape[1])
+        if out.shape[1] != K or out.shape[0] != plan.N:
+            raise RuntimeError("out must be [plan rows, x columns]")
+        part = self._partial(plan, torch.float32, K, False, dev)
+        cs = plan.c_struct(part)
+        w_by_pos = 0
+        if w is not None and plan.perm is not None:
+            w, w_by_pos = self._sorted_weights(plan, w)
+        b = None
+        if bias is not None:
+            b = ctypes.c_void_p(bias.data_ptr() + 4 * int(col0))
+        self._check(self.lib.ggl_spmm_epi_ex(
+            ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), self._row_stride(x, "x"), K, _ptr(out),
+            self._row_stride(out, "out"), int(bool(accumulate)), int(bool(mean)), _ptr(add),
+            (self._row_stride(add, "add") if add is not None else 0), b, int(bool(relu)), float(p_drop),
+            _ptr(rng), int(epi_K), int(col0), int(bool(advance_rng)), self._stream(dev)))
+        return out
+
     def segment_sum_into(self, x, plan, out, accumulate=False):
         """out (+)= segment_sum(x) over `plan`, same strided / in-place conventions — ggl_segment_sum_ex."""
         dev = x.device
@@ -692,10 +726,12 @@ class Engine:
                 K = a.numel() // N if N > 0 else int(math.prod(a.shape[1:]))
                 y = torch.empty_like(a)
                 rng = eng._rng_state(dev) if p_drop > 0 else None
+                rng_used = rng.clone() if rng is not None else None  # the {seed, offset} this launch reads
                 b = bias.contiguous().reshape(-1) if bias is not None else None
                 eng._check(eng.lib.ggl_bias_act_fwd(_ptr(a), _ptr(b), N, K, int(relu), float(p_drop),
                                                     _ptr(rng), _ptr(y), eng._stream(dev)))
                 ctx.cfg = (N, K, int(relu), float(p_drop), None if bias is None else bias.shape)
+                ctx.rng_used = rng_used
                 ctx.save_for_backward(y)
                 return y
 
@@ -709,8 +745,8 @@ class Engine:
                 gb = torch.empty(K, dtype=torch.float32, device=dev) if bshape is not None else None
                 wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K)
                 ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
-                eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K, relu, p_drop, _ptr(ga), _ptr(gb),
-                                                    _ptr(ws), wsb, eng._stream(dev)))
+                eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K, relu, p_drop, _ptr(ctx.rng_used),
+                                                    _ptr(ga), _ptr(gb), _ptr(ws), wsb, eng._stream(dev)))
                 return ga, (gb.reshape(bshape) if gb is not None else None), None, None
 
         class SpMMSumBiasAct(torch.autograd.Function):
@@ -729,6 +765,7 @@ class Engine:
                 if w is not None and plan.perm is not None:
                     ww, w_by_pos = eng._sorted_weights(plan, w)
                 rng = eng._rng_state(dev) if p_drop > 0 else None
+                ctx.rng_used = rng.clone() if rng is not None else None
                 b = bias.contiguous().reshape(-1) if bias is not None else None
                 eng._check(eng.lib.ggl_spmm_sum_bias_act(ctypes.byref(cs), _ptr(gp.col), _ptr(ww), w_by_pos,
                                                          _ptr(x), K, _ptr(b), int(relu), float(p_drop),
@@ -748,8 +785,8 @@ class Engine:
                 gb = torch.empty(K, dtype=torch.float32, device=dev) if bshape is not None else None
                 wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K)
                 ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
-                eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K, relu, p_drop, _ptr(ga), _ptr(gb),
-                                                    _ptr(ws), wsb, eng._stream(dev)))
+                eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K, relu, p_drop, _ptr(ctx.rng_used),
+                                                    _ptr(ga), _ptr(gb), _ptr(ws), wsb, eng._stream(dev)))
                 gp = ctx.gp
                 gx = None
                 if ctx.needs_input_grad[2]:
@@ -839,8 +876,22 @@ class Engine:
         return self.GATFused.apply(gp, el.contiguous(), er.contiguous(), x.contiguous(),
                                    negative_slope, p)
 
+    def _check_weight(self, weight, gp):
+        """An edge-weight vector handed to a kernel as a raw pointer: f32 (spmm_sum_cpu.cpp:22 would raise
+        "expected scalar type Float"), one value per edge."""
+        if weight is None:
+            return None
+        self._check_f32("weight", weight)
+        if weight.numel() != gp.E:
+            raise RuntimeError(f"edge weight must hold one value per edge: got {tuple(weight.shape)} for "
+                               f"{gp.E} edges")
+        return weight.reshape(-1).contiguous()
+
     # rectangular / explicit-plan variants used by the harness and the multi-GPU layer
     def spmm(self, gp, weight, x, reduce="sum"):
+        self._dev(x, weight)
+        self._check_f32("x", x)
+        weight = self._check_weight(weight, gp)
         fn = {"sum": self.SpMMSum, "mean": self.SpMMMean, "max": self.SpMMMax}[reduce]
         return fn.apply(gp, weight, x.contiguous())
 
@@ -889,6 +940,9 @@ class Engine:
         (16-byte rows); otherwise the SpMM and the epilogue kernel run back to back — same values."""
         self._dev(x, weight, bias)
         self._check_f32("x", x)
+        weight = self._check_weight(weight, gp)
+        if bias is not None:
+            self._check_f32("bias", bias)
         p = float(p_drop) if training else 0.0
         if x.dim() == 2 and x.shape[1] % 4 == 0:
             return self.SpMMSumBiasAct.apply(gp, weight, x.contiguous(), bias, bool(relu), p)

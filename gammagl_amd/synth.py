@@ -16,6 +16,7 @@ DATASETS = {  # name: (nodes, directed edges without loops, input features, clas
     "arxiv": (169343, 2315598, 128, 40),
     "reddit": (232965, 114615892, 602, 41),
     "products": (2449029, 123718280, 100, 47),
+    "papers100M": (111059956, 3231371744, 128, 172),   # symmetrised edge count; needs >= 4 GPUs
 }
 
 
@@ -103,3 +104,243 @@ def homophilous_graph(n, f, c, deg=2, p_same=0.85, signal=0.5, seed=0, device="c
     ei = torch.cat([torch.stack([src, dst]), torch.stack([dst, src])], dim=1)
     x = torch.randn(n, f, generator=g, device=dev) + signal * torch.nn.functional.one_hot(y, f).float()
     return x, y, ei
+
+
+# ---------------------------------------------------------------------------------------------------
+# World-size-independent, per-rank construction of the same R-MAT graph
+# ---------------------------------------------------------------------------------------------------
+# `rmat_graph` above draws from torch's sequential generator, so only ONE process can build the graph
+# and everybody else has to receive the whole [2, E] edge list.  At the papers100M size (E = 3.23 G,
+# 52 GB of int64) no rank may hold that.  `rmat_partitioned` is counter-based instead: candidate pair
+# i of the stream is a pure function of (seed, i), so rank r of P generates only its slice of the
+# stream, routes every directed edge to the rank that owns it, and the ranks agree on the result
+# through a handful of small reductions.  The graph (edge set, node order, ownership bounds) is the
+# SAME for every world size — a world-2 run holds exactly the halves of the world-1 graph
+# (tests/test_dist_gloo.py) — and no rank ever holds more than ~its share of the edges.
+
+_U64 = (1 << 64) - 1
+
+
+def _s64(c):
+    """Python int (mod 2^64) -> the signed value torch's int64 arithmetic wraps to."""
+    c &= _U64
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _mix64_int(x):
+    """splitmix64 finaliser on a Python int (a bijection of 64-bit words)."""
+    x &= _U64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _U64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _U64
+    return x ^ (x >> 31)
+
+
+def _lsr(x, s):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def mix64(x):
+    """The same finaliser on an int64 tensor (wrap-around arithmetic; logical shifts spelled out)."""
+    x = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * _s64(0x94D049BB133111EB)
+    return x ^ _lsr(x, 31)
+
+
+def rmat_pairs_ctr(scale, idx, seed, a=0.57, b=0.19, c=0.19):
+    """R-MAT endpoints of the candidate pairs with stream positions `idx` (int64 tensor): quadrant of
+    level l from 32 bits of mix64(idx ^ salt(seed, l // 2)) — no generator state, any slice on any rank."""
+    u = torch.zeros_like(idx)
+    v = torch.zeros_like(idx)
+    t_a, t_ab, t_abc = int(a * 2**32), int((a + b) * 2**32), int((a + b + c) * 2**32)
+    h = None
+    for lvl in range(scale):
+        if lvl % 2 == 0:
+            h = mix64(idx ^ _s64(_mix64_int(seed * 0x9E3779B97F4A7C15 + 2 * (lvl // 2) + 1)))
+            t = _lsr(h, 32)
+        else:
+            t = h & 0xFFFFFFFF
+        ubit = (t >= t_ab).to(torch.int64)
+        vbit = (((t >= t_a) & (t < t_ab)) | (t >= t_abc)).to(torch.int64)
+        u = (u << 1) | ubit
+        v = (v << 1) | vbit
+    return u, v
+
+
+class _Comm:
+    """The few collectives the builder needs; world == 1 needs no process group."""
+
+    def __init__(self, rank, world, group):
+        self.rank, self.world, self.group = int(rank), int(world), group
+
+    def all_reduce(self, t, op="sum"):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def route(self, payload, owner):
+        """Send row i of `payload` ([m] or [m, c] int64) to rank owner[i]; returns what this rank receives."""
+        if self.world == 1:
+            return payload
+        import torch.distributed as dist
+
+        order = torch.argsort(owner, stable=True)
+        send = payload[order].contiguous()
+        sc = torch.bincount(owner, minlength=self.world)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        out = torch.empty((int(rc.sum()),) + tuple(payload.shape[1:]), dtype=payload.dtype, device=payload.device)
+        dist.all_to_all_single(out, send, rc.tolist(), sc.tolist(), group=self.group)
+        return out
+
+    def all_gather_var(self, t):
+        """Concatenation over ranks of 1-D tensors of different lengths (small ones only)."""
+        if self.world == 1:
+            return t
+        import torch.distributed as dist
+
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+        ns = [torch.empty_like(n) for _ in range(self.world)]
+        dist.all_gather(ns, n, group=self.group)
+        ns = [int(x) for x in ns]
+        cap = max(max(ns), 1)
+        buf = torch.zeros(cap, dtype=t.dtype, device=t.device)
+        buf[: t.numel()] = t
+        bufs = [torch.empty_like(buf) for _ in range(self.world)]
+        dist.all_gather(bufs, buf, group=self.group)
+        return torch.cat([b[:k] for b, k in zip(bufs, ns)])
+
+
+def bounds_from_degree(deg, world):
+    """Contiguous node ranges with ~equal numbers of in-edges, from the global in-degree vector
+    (identical on every rank; the distributed counterpart of dist.balanced_bounds)."""
+    n = int(deg.shape[0])
+    cum = torch.cumsum(deg, 0)
+    total = int(cum[-1]) if n > 0 else 0
+    targets = torch.arange(1, world, device=deg.device, dtype=torch.float64) * (total / world)
+    cuts = torch.searchsorted(cum.double(), targets).clamp(max=n)
+    return [0] + [int(c) for c in cuts.tolist()] + [n]
+
+
+def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, group=None, device="cpu",
+                     relabel="random", order="src", parts=None, stats=None):
+    """This rank's share of the R-MAT graph with `num_nodes` nodes and exactly `num_directed_edges`
+    directed edges (symmetrised, de-duplicated) + one self-loop per node, for a 1-D partition into `parts`
+    (default: `world`) contiguous node ranges balanced by in-edge count.
+
+    Returns a dict: src (global ids) / dst (LOCAL ids, dst - lo) / w (symmetric GCN norm
+    deg^-1/2[src] * deg^-1/2[dst], degrees counted on the looped edge list like calc_gcn_norm) of the
+    edges whose destination this rank owns; bounds [parts+1]; e_global (Python int, may exceed 2^31);
+    deg (global in-degree incl. the loop, float32 [N]).  With world == 1 and parts == P > 1 the process
+    plays rank `rank` of a P-way partition from the globally built graph (single-GPU share probes)."""
+    dev = torch.device(device)
+    N, P = int(num_nodes), int(world)
+    parts = int(parts or world)
+    comm = _Comm(rank if P > 1 else 0, P, group)   # (world == 1, parts > 1: `rank` only picks the share played)
+    T = int(num_directed_edges) // 2
+    scale = max(1, math.ceil(math.log2(max(N, 2))))
+    peak = 0
+    pi = None
+    if relabel == "random":
+        # the same permutation on every rank (CPU generator: identical whatever the device)
+        pi = torch.randperm(N, generator=torch.Generator().manual_seed(seed + 1)).to(dev)
+    keys = torch.empty(0, dtype=torch.int64, device=dev)    # directed edges held here: dst * N + src
+    U, base, rounds = 0, 0, 0
+    while U < T:
+        m = int((T - U) * 1.5) + 1024                        # candidates this round, over all ranks
+        i0, i1 = base + m * comm.rank // P, base + m * (comm.rank + 1) // P
+        idx = torch.arange(i0, i1, dtype=torch.int64, device=dev)
+        u, v = rmat_pairs_ctr(scale, idx, seed)
+        del idx
+        ok = (u < N) & (v < N) & (u != v)
+        u, v = u[ok], v[ok]
+        if pi is not None:
+            u, v = pi[u], pi[v]
+        dkey = torch.cat([v * N + u, u * N + v])             # both directions of every pair
+        del u, v, ok
+        # provisional owner = hash of the destination: balanced whatever the node order, and every copy
+        # of a directed edge meets at one rank, so the de-duplication there is complete
+        owner = (_lsr(mix64(dkey // N), 33) % P) if P > 1 else None
+        recv = comm.route(dkey, owner)
+        peak = max(peak, int(dkey.numel()), int(recv.numel()) + int(keys.numel()))
+        del dkey, owner
+        keys = torch.unique(torch.cat([keys, recv]))
+        del recv
+        cnt = ((keys % N) < (keys // N)).sum().reshape(1)    # canonical (src < dst) copies = undirected pairs
+        U = int(comm.all_reduce(cnt))
+        base += m
+        rounds += 1
+        if rounds > 64:
+            raise RuntimeError("R-MAT generator cannot reach the requested edge count")
+    src, dst = keys % N, keys // N
+    del keys
+    if U > T:
+        # keep the T pairs with the smallest hash of their canonical key (signed order; mix64 is a
+        # bijection, so there are no ties): a selection that does not depend on who holds what
+        lo, hi = torch.minimum(src, dst), torch.maximum(src, dst)
+        h = mix64((lo * N + hi) ^ _s64(_mix64_int(seed + 0x51ED27)))
+        del lo, hi
+        canon = src < dst
+        bucket = (h >> 44) + (1 << 19)                        # top 20 bits, 0 .. 2^20 - 1
+        hist = comm.all_reduce(torch.bincount(bucket[canon], minlength=1 << 20))
+        cum = torch.cumsum(hist, 0)
+        b = int(torch.searchsorted(cum, torch.tensor([T], device=dev, dtype=cum.dtype)))
+        below = int(cum[b - 1]) if b > 0 else 0
+        cand = comm.all_gather_var(h[canon & (bucket == b)])
+        thr = torch.sort(cand).values[T - below - 1]
+        keep = h <= thr
+        src, dst = src[keep], dst[keep]
+        del h, canon, bucket, keep
+    # global in-degree (the graph is symmetric: also the out-degree), without the loops yet
+    deg = comm.all_reduce(torch.bincount(dst, minlength=N))
+    if relabel == "degree":   # hubs first: the locality-friendly ordering
+        rk = torch.empty(N, dtype=torch.int64, device=dev)
+        o = torch.argsort(deg, descending=True, stable=True)
+        rk[o] = torch.arange(N, device=dev)
+        src, dst, deg = rk[src], rk[dst], deg[o]
+        del rk, o
+    deg = deg + 1                                             # add_self_loops: one loop per node
+    bounds = bounds_from_degree(deg, parts)
+    bt = torch.tensor(bounds[1:-1], device=dev, dtype=torch.int64)
+    own = torch.searchsorted(bt, dst, right=True) if parts > 1 else torch.zeros_like(dst)
+    if P > 1:
+        got = comm.route(torch.stack([src, dst], 1), own)
+        peak = max(peak, int(src.numel()) + int(got.shape[0]))
+        src, dst = got[:, 0].contiguous(), got[:, 1].contiguous()
+        del got
+        me = comm.rank
+    else:
+        me = int(rank)                                        # play one rank of a `parts`-way partition
+        mine = own == me
+        src_all, dst_all, own_all = src, dst, own
+        src, dst = src[mine], dst[mine]
+    lo_n, hi_n = bounds[me], bounds[me + 1]
+    key = (src * N + dst) if order == "src" else (dst * N + src)
+    o = torch.argsort(key)
+    src, dst = src[o], dst[o]
+    del key, o
+    loops = torch.arange(lo_n, hi_n, dtype=torch.int64, device=dev)
+    src, dst = torch.cat([src, loops]), torch.cat([dst, loops])   # loops appended last, as add_self_loops does
+    dis = deg.to(torch.float32).pow(-0.5)
+    w = (dis[src] * dis[dst]).contiguous()
+    e_loc = torch.tensor([src.numel()], dtype=torch.int64, device=dev)
+    out = {"src": src.contiguous(), "dst": (dst - lo_n).contiguous(), "w": w, "bounds": bounds,
+           "deg": deg.to(torch.float32), "num_nodes": N, "rank": me, "parts": parts}
+    if P > 1 or parts == 1:
+        out["e_global"] = int(comm.all_reduce(e_loc))
+    else:
+        out["e_global"] = int(src_all.numel()) + N
+        # which of my rows the other parts need (what they would request in a real P-rank run), per peer
+        send = []
+        for q in range(parts):
+            if q == me:
+                send.append(torch.empty(0, dtype=torch.int64, device=dev))
+                continue
+            sq = src_all[(own_all == q) & (src_all >= lo_n) & (src_all < hi_n)]
+            send.append(torch.unique(sq) - lo_n)
+        out["send_rows"] = send
+    peak = max(peak, int(src.numel()))
+    if stats is not None:
+        stats.update(peak_edges=peak, rounds=rounds, local_edges=int(src.numel()))
+    return out

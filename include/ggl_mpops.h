@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GGL_ABI_VERSION 3
+#define GGL_ABI_VERSION 4
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
 enum {
@@ -117,6 +117,11 @@ int ggl_gather_i64_to_i32(const int64_t *src, const int32_t *perm, int64_t E, in
 /* out[p, :] = src[perm[p], :] for rows of H floats (edge weights into sorted order) */
 int ggl_gather_rows_f32(const float *src, const int32_t *perm, int64_t E, int64_t H, float *out,
                         void *stream);
+/* out[i, 0:K] = src[idx[i], 0:K], row strides src_ld / out_ld (elements, >= K): the send buffer of one
+ * feature-column block of the halo exchange gathered straight from the activation matrix (no reference
+ * counterpart: SURVEY.md §8e; replaces h[:, c0:c1].index_select(0, idx).contiguous()) */
+int ggl_gather_rows_f32_ex(const float *src, int64_t src_ld, const int64_t *idx, int64_t n, int64_t K,
+                           float *out, int64_t out_ld, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Format conversion: device-side ind2ptr / ptr2ind (gammagl/ops/sparse,
@@ -232,8 +237,11 @@ int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *works
  *   fwd: y = keep * relu(a + bias) / (1 - p_drop); keep ~ Bernoulli(1 - p_drop) from Philox4x32-10 keyed
  *        on rng_state = {seed, offset} (device int64[2]; offset is advanced on the stream after the
  *        launch, so a captured graph draws a new mask per replay).  bias [K] or NULL; p_drop = 0: no RNG.
- *   bwd: ga = (y > 0) ? g / (1 - p_drop) : 0 when relu or dropout was applied (y == 0 exactly where
- *        either killed the value), else ga = g;  gbias[K] = column sums of ga (same pass; NULL to skip).
+ *        The word of element (r, k): Philox(counter = r * (K / v) + k / v)[k % v], v = 4 if K % 4 == 0 else 1.
+ *   bwd: ga = keep * [relu ? y > 0 : 1] * g / (1 - p_drop); `rng_used` = a copy of the {seed, offset} the
+ *        forward READ (taken before it advanced): the dropout mask is redrawn exactly.  rng_used == NULL:
+ *        the mask is rebuilt from y (y > 0 with ReLU, y != 0 without).  gbias[K] = column sums of ga
+ *        (same pass; NULL to skip).
  * ---------------------------------------------------------------------------------------------- */
 int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, int64_t K, int relu, float p_drop,
                      int64_t *rng_state, float *y, void *stream);
@@ -246,7 +254,27 @@ int ggl_spmm_sum_bias_act(const ggl_segplan_t *plan, const int32_t *col, const f
                           int64_t *rng_state, float *out, void *stream);
 size_t ggl_bias_act_bwd_workspace_bytes(int64_t N, int64_t K);
 int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64_t K, int relu, float p_drop,
-                     float *ga, float *gbias, void *workspace, size_t workspace_bytes, void *stream);
+                     const int64_t *rng_used, float *ga, float *gbias, void *workspace,
+                     size_t workspace_bytes, void *stream);
+/* General form of the fused epilogue (sage_conv.py:100-108, gcn_conv.py:105-106):
+ *   out[i, 0:K] = dropout(relu(reduce_{p in row i} w * x[col[p], 0:K] (+ out[i, 0:K] if accumulate)
+ *                              + add[i, 0:K] + bias[0:K]))
+ * reduce = sum, or mean (divide by the row's edge count; not with accumulate).  x / out / add rows are
+ * x_ld / out_ld / add_ld elements apart (0 = K): a column block [epi_col0, epi_col0 + K) of an epi_K-wide
+ * row (epi_K = 0: K), bias / add pointing at the block's first column, and the dropout word of element
+ * (i, epi_col0 + k) is the one the full-width launch draws.  accumulate: a second edge set (halo-source
+ * edges of the multi-GPU path) is added onto the partial result already in `out`, epilogue included.
+ * advance_rng != 0 steps rng_state afterwards (once per layer: on the last column block). */
+int ggl_spmm_epi_ex(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
+                    const float *x, int64_t x_ld, int64_t K, float *out, int64_t out_ld, int accumulate,
+                    int mean, const float *add, int64_t add_ld, const float *bias, int relu, float p_drop,
+                    int64_t *rng_state, int64_t epi_K, int64_t epi_col0, int advance_rng, void *stream);
+/* segment_sum / segment_mean of f32 messages x[E, K] with the same epilogue on each finished row (the
+ * message() + aggregate() route of a sampled SAGEConv block): bit-identical to ggl_segment_{sum,mean}
+ * followed by "+ add + bias, relu, dropout". */
+int ggl_segment_epi(const float *x, const ggl_segplan_t *plan, int64_t K, int mean, const float *add,
+                    int64_t add_ld, const float *bias, int relu, float p_drop, int64_t *rng_state, float *out,
+                    void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused GAT edge-softmax + weighted aggregate: ONE kernel per direction.  Replaces the external

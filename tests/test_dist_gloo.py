@@ -174,8 +174,9 @@ def _bench_worker(rank, world, port, tmp):
 
         args = types.SimpleNamespace(seed=0, relabel="random", order="src", hidden=16, layers=3, warmup=1,
                                      steps=2, workload="tiny")
-        out = run_distributed_bench(args, torch.device("cpu"), rank, world, 400, 6000, 10, 5, eng=_emul_engine())
+        out, pg = run_distributed_bench(args, torch.device("cpu"), rank, world, 400, 6000, 10, 5, eng=_emul_engine())
         assert out["n_gpus"] == world and out["value"] > 0 and out["scaling"] == "strong"
+        assert out["rccl_ranks"] == world and pg.e_global == 6400
         assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
         json.dumps(out)
         open(os.path.join(tmp, f"ok{rank}"), "w").close()
@@ -184,7 +185,7 @@ def _bench_worker(rank, world, port, tmp):
 
 
 def test_bench_body_runs_distributed(tmp_path):
-    """bench.py's body (graph broadcast from rank 0, partition, timed steps, max-over-ranks) on gloo."""
+    """bench.py's body (per-rank graph construction, partition, timed steps, max-over-ranks) on gloo."""
     subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, __file__, str(r), "2", str(port), str(tmp_path), "bench"])
@@ -249,9 +250,141 @@ def test_sage_minibatch_replicas_with_gradient_allreduce(tmp_path):
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
 
 
+def _edge_set(src, dst):
+    return set(zip(src.tolist(), dst.tolist()))
+
+
+def _shard_worker(rank, world, port, tmp):
+    """Config 5's construction path: every rank builds ONLY its share of the graph (no global edge list
+    anywhere), the shares are exactly the world-1 graph cut at the same bounds, the halo bookkeeping built from
+    them matches the one built by filtering the global list, a dry partition on one process reproduces this
+    rank's buffers, and the fused halo epilogue equals aggregate -> bias_act bit for bit."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = _emul_engine()
+        from gammagl_amd.dist import PartitionedGraph, build_partition
+        from gammagl_amd.synth import rmat_partitioned
+
+        N, E_dir = 2000, 30000
+        for relabel in ("random", "degree"):
+            st = {}
+            g = rmat_partitioned(N, E_dir, seed=5, rank=rank, world=world, relabel=relabel, stats=st)
+            E = g["e_global"]
+            assert E == E_dir + N
+            # no rank ever holds more than ~its share: the largest edge tensor alive at any point of the build
+            assert st["peak_edges"] <= 2.6 * E / world, (st, E, world)
+            assert abs(st["local_edges"] - E / world) <= 0.25 * E / world + 800, st
+            # the same graph for every world size: this share == the world-1 graph cut at the same bounds
+            g1 = rmat_partitioned(N, E_dir, seed=5, rank=0, world=1, relabel=relabel)
+            assert g1["e_global"] == E
+            full_src, full_dst = g1["src"], g1["dst"]
+            lo, hi = g["bounds"][rank], g["bounds"][rank + 1]
+            from gammagl_amd.synth import bounds_from_degree
+            assert g["bounds"] == bounds_from_degree(g1["deg"].long(), world)
+            mine = (full_dst >= lo) & (full_dst < hi)
+            assert _edge_set(g["src"], g["dst"] + lo) == _edge_set(full_src[mine], full_dst[mine])
+            assert g["src"].numel() == int(mine.sum())          # no duplicates either
+            torch.testing.assert_close(g["deg"], g1["deg"])
+            # weights: symmetric GCN norm on the looped graph
+            dis = g1["deg"].pow(-0.5)
+            torch.testing.assert_close(g["w"], dis[g["src"]] * dis[g["dst"] + lo])
+        # PartitionedGraph from the local share == PartitionedGraph from the filtered global list
+        g = rmat_partitioned(N, E_dir, seed=5, rank=rank, world=world)
+        g1 = rmat_partitioned(N, E_dir, seed=5)
+        pg = PartitionedGraph.from_local(g["src"], g["dst"], g["w"], g["bounds"], N, g["e_global"], rank, world, eng=eng)
+        ei1 = torch.stack([g1["src"], g1["dst"]])
+        pgg = PartitionedGraph(ei1, g1["w"], N, rank, world, eng=eng, bounds=g["bounds"])
+        assert pg.n_halo == pgg.n_halo and torch.equal(pg.halo_ids, pgg.halo_ids)
+        assert torch.equal(pg.send_idx, pgg.send_idx) and pg.send_splits == pgg.send_splits
+        assert pg.e_local == pgg.e_local and pg.e_global == pgg.e_global
+        # a dry partition (one process playing this rank of `world`) has the same buffers and send lists
+        pgd = build_partition(N, E_dir, 5, rank, 1, None, torch.device("cpu"), eng, parts=world)
+        assert pgd.dry and pgd.n_halo == pg.n_halo and torch.equal(pgd.halo_ids, pg.halo_ids)
+        assert pgd.send_splits == pg.send_splits and torch.equal(pgd.send_idx, pg.send_idx)
+        assert pgd.lo == pg.lo and pgd.hi == pg.hi and pgd.e_local == pg.e_local
+        hd = torch.randn(pgd.n_local, 8)
+        assert pgd.aggregate(hd).shape == (pgd.n_local, 8)      # runs without a process group behind it
+        # aggregate vs the unpartitioned op, and the fused halo epilogue vs aggregate -> bias_act
+        for K in (16, 256):
+            h = torch.randn(N, K, generator=torch.Generator().manual_seed(K))
+            go = torch.randn(N, K, generator=torch.Generator().manual_seed(K + 1))
+            bias = torch.randn(1, K, generator=torch.Generator().manual_seed(K + 2))
+            hf = h.clone().requires_grad_(True)
+            full = torch.relu(eng.c_spmm_sum(ei1, g1["w"], hf) + bias)
+            full.backward(go)
+            a = h[pg.lo:pg.hi].clone().requires_grad_(True)
+            b1 = bias.clone().requires_grad_(True)
+            ya = pg.aggregate(a, b1, relu=True)
+            ya.backward(go[pg.lo:pg.hi])
+            torch.testing.assert_close(ya.detach(), full.detach()[pg.lo:pg.hi], rtol=1e-5, atol=1e-4)
+            torch.testing.assert_close(a.grad, hf.grad[pg.lo:pg.hi], rtol=1e-5, atol=1e-4)
+            # dropout on: same rng state -> the fused form draws the mask of the two-pass form, bit for bit
+            for relu in (True, False):
+                eng.reseed(77)
+                st0 = eng._rng_state(a.device).clone()
+                a1 = h[pg.lo:pg.hi].clone().requires_grad_(True)
+                b2 = bias.clone().requires_grad_(True)
+                y1 = pg.aggregate(a1, b2, relu=relu, p_drop=0.4)
+                y1.backward(go[pg.lo:pg.hi])
+                eng._rng_state(a.device).copy_(st0)
+                a2 = h[pg.lo:pg.hi].clone().requires_grad_(True)
+                b3 = bias.clone().requires_grad_(True)
+                y2 = eng.bias_act(pg.aggregate(a2), b3, relu=relu, p_drop=0.4)
+                y2.backward(go[pg.lo:pg.hi])
+                assert torch.equal(y1, y2) and 0.3 < float((y1 == 0).float().mean()) < (0.8 if relu else 0.5)
+                assert torch.equal(a1.grad, a2.grad) and torch.equal(b2.grad, b3.grad)
+                assert torch.equal(eng._rng_state(a.device), st0 + torch.tensor([0, 1]))
+        open(os.path.join(tmp, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_per_rank_graph_construction_and_fused_halo_epilogue(world, tmp_path):
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, __file__, str(r), str(world), str(port), str(tmp_path), "shard"])
+             for r in range(world)]
+    assert [p.wait(timeout=600) for p in procs] == [0] * world
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it starts 2 ranks itself and reports n_gpus = 2
+    (gloo + host-emulated kernels behind GGL_BENCH_EMUL); under a launcher with a different world size it
+    refuses to print a line."""
+    import json
+
+    env = dict(os.environ, GGL_BENCH_EMUL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "tiny",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["engine"].startswith("host-emulation")
+    assert out["config"]["rank0_peak_edges_during_build"] < 420000      # < the whole edge list
+    # one rank, unchanged contract
+    r1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--workload", "tiny",
+                         "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    o1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert o1["n_gpus"] == 1 and o1["rccl_ranks"] == 1 and o1["config"]["parallelism"] == "1 GPU"
+    # a launcher that started a different number of ranks than --gpus: no line
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--workload", "tiny"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
+                         timeout=120)
+    assert bad.returncode != 0 and "{" not in bad.stdout
+
+
 if __name__ == "__main__":
     sys.path.insert(0, REPO)
     sys.path.insert(0, HERE)
     mode = sys.argv[5] if len(sys.argv) > 5 else ""
-    fn = {"bench": _bench_worker, "sage": _sage_worker}.get(mode, _worker)
+    fn = {"bench": _bench_worker, "sage": _sage_worker, "shard": _shard_worker}.get(mode, _worker)
     fn(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
