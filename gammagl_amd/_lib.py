@@ -79,6 +79,10 @@ SIGNATURES = {
     "ggl_gat_fused_bwd_dst": (c_int, [_P, _V, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64,
                                       c_float, _V, _V, _V, _V, _V, _V]),
     "ggl_gat_fused_bwd_src": (c_int, [_P, _V, _V, _V, _V, _V, c_int64, c_int64, _V, _V, _V]),
+    "ggl_gat_fast_supported": (c_int, [c_int64, c_int64]),
+    "ggl_gat_fast_fwd": (c_int, [_P, _V, _V, _V, _V, c_int64, c_float, c_int64, c_int64, c_float, _V, _V, _V, _V, _V]),
+    "ggl_gat_fast_bwd": (c_int, [_P, _V, _P, _V, _V, _V, _V, _V, _V, _V, _V, _V, c_float, c_int64, c_int64, c_float,
+                                 _V, _V, _V, _V, _V, _V]),
     "ggl_sample_count": (c_int, [_V, _V, c_int64, c_int64, c_int, _V, _V]),
     "ggl_sample_pick": (c_int, [_V, _V, _V, c_int64, c_int64, c_int, _V, _V, _V, _V, _V]),
     "ggl_set_option": (c_int, [c_char_p, c_int64]),

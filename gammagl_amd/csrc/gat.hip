@@ -629,6 +629,356 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src_final_kernel(
   }
 }
 
+
+// =====================================================================================================
+// Fast path (GPU build only): heads of C = 4, 8, 16, 32 or 64 channels, H * C <= 256.
+//
+// The kernels above spend their time in the VECTOR ALU, not in memory: the ISA of gat_fwd_kernel<4,false>
+// shows ~460 VALU instructions per 4-edge step (libm expf twice per edge, IEEE division, 64-bit address
+// arithmetic per load, a predicated rescale per edge) against 12 memory instructions, and the Reddit-sized
+// 60 MB feature panel is cache-resident — 114.8 M edges x 16 lanes of that is ~5 ms of issue time on its
+// own.  These variants do the same walks with an order of magnitude fewer VALU instructions:
+//   * exp through v_exp_f32 (exp2(x * log2 e), ~1e-6 relative on the operand range of a softmax; the GAT
+//     parity bar is 1e-5 relative against the oracle's three-pass restatement);
+//   * one rescale per block of 4 / 8 edges (block maximum first) instead of a predicated one per edge;
+//   * column indices as one 16-byte load per 4 edges (the walk is aligned to multiples of 4);
+//   * 32-bit byte offsets into the feature panels where they fit (saddr + voffset addressing);
+//   * FMA accumulation, reciprocal of the denominator once per row;
+//   * work items (hub chunks first, then rows) all handled by a lane group of H * C / 4 lanes — hub chunks
+//     used to get a whole wavefront of which K / 4 lanes worked.
+// Backward without the [E, H, 2] alpha / de round trip (7.3 GB written by one walk and gathered through
+// posT by the other on the Reddit-sized graph): both walks RECOMPUTE alpha and de from per-row constants —
+//   destination walk (forward plan):  stats[i,h] = {er, m, 1/(den + 1e-16), <g_i, out_i>};  ger[i,h] = sum_p de
+//   source walk (transposed plan):    gx[j,h,:] = sum_q alpha g_i,  gel[j,h] = sum_q de, with x_j, el_j in
+//                                     registers and g_i (needed anyway) + stats[i,h] (a 30 MB panel) gathered
+// with <g_i[h,:], x_j[h,:]> reduced over the C/4 lanes of a head by DPP / wave shuffles (gradients are held
+// to 1e-5 relative, not bit-exact).  The host-emulated test build cannot shuffle between its sequentially
+// executed lanes: it keeps the kernels above for every shape (they also remain the path for other shapes).
+// =====================================================================================================
+#ifndef GGL_EMULATE
+__device__ __forceinline__ float fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896340736f); }
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the LPH (power of two, aligned) lanes of a head; every lane of the head gets the total
+template <int LPH> __device__ __forceinline__ float head_sum(float v) {
+  if (LPH >= 2) v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]: lane ^ 1
+  if (LPH >= 4) v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]: lane ^ 2
+  if (LPH >= 8) v += __shfl_xor(v, 4, 64);
+  if (LPH >= 16) v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b) {
+  return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
+
+struct GatItem {
+  int64_t row, beg, end, cid;
+  bool is_chunk, first_chunk;
+};
+// work item -> (row, position range).  Items [0, n_chunks) are the chunks of long rows, then one per row slot.
+__device__ __forceinline__ bool gat_item(const GatDims &d, const int64_t *__restrict__ rowptr,
+                                         const int32_t *__restrict__ row_order,
+                                         const int32_t *__restrict__ long_rows,
+                                         const int64_t *__restrict__ chunk_ptr, int64_t item, GatItem &it) {
+  it.is_chunk = item < d.n_chunks;
+  it.cid = item;
+  it.first_chunk = false;
+  if (it.is_chunk) {
+    int64_t lo = 0, hi = d.n_long - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (chunk_ptr[mid] <= item) lo = mid; else hi = mid - 1;
+    }
+    it.row = long_rows[lo];
+    it.first_chunk = (item == chunk_ptr[lo]);
+    it.beg = rowptr[it.row] + (item - chunk_ptr[lo]) * d.chunk;
+    const int64_t rend = rowptr[it.row + 1];
+    it.end = (it.beg + d.chunk < rend) ? it.beg + d.chunk : rend;
+    return true;
+  }
+  const int64_t slot = item - d.n_chunks;
+  it.row = row_order ? (int64_t)row_order[slot] : slot;
+  it.beg = rowptr[it.row];
+  it.end = rowptr[it.row + 1];
+  return it.end - it.beg <= d.chunk;  // a long row is covered by its chunk items
+}
+
+// feature-panel addressing: byte offsets in 32 bits when the panel is < 4 GiB
+template <bool OFF32> struct RowAddr {
+  const char *base;
+  uint32_t stride;  // bytes per row
+  __device__ __forceinline__ const char *at(int32_t r) const {
+    if (OFF32) return base + (uint32_t)((uint32_t)r * stride);
+    return base + (int64_t)r * (int64_t)stride;
+  }
+};
+
+#define GGL_GAT2_PROLOGUE()                                                                           \
+  const int64_t item = thread_id() >> d.logL;                                                         \
+  const int li = (int)threadIdx.x & ((1 << d.logL) - 1);                                              \
+  if (item >= d.n_chunks + d.N) return;                                                               \
+  GatItem it;                                                                                         \
+  if (!gat_item(d, rowptr, row_order, long_rows, chunk_ptr, item, it)) return;                        \
+  const int H = (int)d.H;                                                                             \
+  const bool act = li < H * C4;      /* lanes past the last head idle along (H * C4 not a power of 2) */ \
+  const int h = act ? li / C4 : 0;                                                                    \
+  const int kk = act ? li * 4 : 0;                                                                    \
+  const bool lead = act && (li % C4) == 0
+
+template <int C4, bool DROP, bool OFF32>
+__global__ __launch_bounds__(kBlock) void gat_fwd2_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ er,
+    const float *__restrict__ x, float *__restrict__ y, float *__restrict__ rowmax,
+    float *__restrict__ rowden, float *__restrict__ pacc, float *__restrict__ pm,
+    float *__restrict__ pd, const int64_t *__restrict__ rng, const GatDims d) {
+  GGL_GAT2_PROLOGUE();
+  if (!act) return;  // no cross-lane traffic in the forward
+  const int64_t K = d.K;
+  const float slope = d.slope;
+  const float er_i = er[it.row * H + h];
+  const RowAddr<OFF32> xa{reinterpret_cast<const char *>(x) + kk * 4, (uint32_t)(K * 4)};
+  const RowAddr<OFF32> ea{reinterpret_cast<const char *>(el) + h * 4, (uint32_t)(H * 4)};
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  float m = -FLT_MAX, den = 0.0f;
+  float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  auto rescale = [&](float mx) {
+    if (mx > m) {
+      const float sc = fexp(m - mx);  // m = -FLT_MAX before the first edge: exp2(-inf) = 0
+      den *= sc;
+      a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+      m = mx;
+    }
+  };
+  auto add = [&](float s, const float4 &v, uint32_t word) {
+    const float w = fexp(s - m);
+    den += w;
+    float wk = w;
+    if (DROP) wk = (word >= d.drop_thresh) ? w * d.drop_scale : 0.0f;
+    a.x = __builtin_fmaf(v.x, wk, a.x); a.y = __builtin_fmaf(v.y, wk, a.y);
+    a.z = __builtin_fmaf(v.z, wk, a.z); a.w = __builtin_fmaf(v.w, wk, a.w);
+  };
+  auto single = [&](int64_t q) {
+    const int32_t c = col[q];
+    const float4 v = *reinterpret_cast<const float4 *>(xa.at(c));
+    const float s = lrelu(*reinterpret_cast<const float *>(ea.at(c)) + er_i, slope);
+    rescale(s);
+    add(s, v, DROP ? drop_word(q, H, h, offset, seed) : 0u);
+  };
+  int64_t p = it.beg;
+  for (; p < it.end && (p & 3) != 0; ++p) single(p);
+  for (; p + 8 <= it.end; p += 8) {  // 8 feature rows in flight, two 16-byte index loads
+    const int4 i0 = *reinterpret_cast<const int4 *>(col + p), i1 = *reinterpret_cast<const int4 *>(col + p + 4);
+    const int32_t c[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+    float4 v[8];
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(xa.at(c[u]));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = *reinterpret_cast<const float *>(ea.at(c[u]));
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s[u] = lrelu(s[u] + er_i, slope); mx = fmaxf(mx, s[u]); }
+    rescale(mx);
+    U4 r0{0u, 0u, 0u, 0u}, r1{0u, 0u, 0u, 0u};
+    if (DROP) {
+      r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+      r1 = philox4x32_10((uint64_t)(((p >> 2) + 1) * H + h), offset, seed);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add(s[u], v[u], pick_word(r0, u));
+#pragma unroll
+    for (int u = 4; u < 8; ++u) add(s[u], v[u], pick_word(r1, u - 4));
+  }
+  for (; p + 4 <= it.end; p += 4) {
+    const int4 i0 = *reinterpret_cast<const int4 *>(col + p);
+    const int32_t c[4] = {i0.x, i0.y, i0.z, i0.w};
+    float4 v[4];
+    float s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(xa.at(c[u]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = *reinterpret_cast<const float *>(ea.at(c[u]));
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s[u] = lrelu(s[u] + er_i, slope); mx = fmaxf(mx, s[u]); }
+    rescale(mx);
+    U4 r0{0u, 0u, 0u, 0u};
+    if (DROP) r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add(s[u], v[u], pick_word(r0, u));
+  }
+  for (; p < it.end; ++p) single(p);
+  if (it.is_chunk) {
+    *reinterpret_cast<float4 *>(pacc + it.cid * K + kk) = a;
+    if (lead) {
+      pm[it.cid * H + h] = m;
+      pd[it.cid * H + h] = den;
+    }
+    return;
+  }
+  const float rinv = 1.0f / (den + 1e-16f);  // softmax.py:35: exp / (sum + 1e-16)
+  a.x *= rinv; a.y *= rinv; a.z *= rinv; a.w *= rinv;
+  *reinterpret_cast<float4 *>(y + it.row * K + kk) = a;
+  if (lead) {
+    rowmax[it.row * H + h] = m;
+    rowden[it.row * H + h] = den;
+  }
+}
+
+// destination walk of the backward: stats[i,h] = {er, m, 1 / (den + 1e-16), <g_i, out_i>} and
+// ger[i,h] = sum_p de_p,  de_p = alpha_p (keep_p / (1 - p_drop) <g_i, x_j> - dot_i) LeakyReLU'(raw_p)
+template <int C4, bool DROP, bool OFF32>
+__global__ __launch_bounds__(kBlock) void gat_bwd_dst2_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ er,
+    const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ out,
+    const float *__restrict__ rowmax, const float *__restrict__ rowden, float *__restrict__ stats,
+    float *__restrict__ ger, float *__restrict__ pger, const int64_t *__restrict__ rng, const GatDims d) {
+  GGL_GAT2_PROLOGUE();
+  const int64_t K = d.K;
+  const float slope = d.slope;
+  float4 gi = make_float4(0.0f, 0.0f, 0.0f, 0.0f), oi = gi;
+  if (act) {
+    gi = *reinterpret_cast<const float4 *>(g + it.row * K + kk);
+    oi = *reinterpret_cast<const float4 *>(out + it.row * K + kk);
+  }
+  const float dot = head_sum<C4>(dot4(gi, oi));
+  const float er_i = er[it.row * H + h];
+  const float m = rowmax[it.row * H + h];
+  const float rinv = 1.0f / (rowden[it.row * H + h] + 1e-16f);
+  if (lead && (!it.is_chunk || it.first_chunk))
+    *reinterpret_cast<float4 *>(stats + (it.row * H + h) * 4) = make_float4(er_i, m, rinv, dot);
+  const RowAddr<OFF32> xa{reinterpret_cast<const char *>(x) + kk * 4, (uint32_t)(K * 4)};
+  const RowAddr<OFF32> ea{reinterpret_cast<const char *>(el) + h * 4, (uint32_t)(H * 4)};
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  float gsum = 0.0f;
+  auto edge = [&](float e, const float4 &v, uint32_t word) {
+    float da = head_sum<C4>(dot4(gi, v));
+    const float raw = e + er_i;
+    const float al = fexp(lrelu(raw, slope) - m) * rinv;
+    if (DROP) da = (word >= d.drop_thresh) ? da * d.drop_scale : 0.0f;  // d out / d alpha_p = keep / (1 - p) <g_i, x_j>
+    const float ds = al * (da - dot);
+    gsum += raw > 0.0f ? ds : ds * slope;
+  };
+  auto single = [&](int64_t q) {
+    const int32_t c = col[q];
+    const float4 v = *reinterpret_cast<const float4 *>(xa.at(c));
+    edge(*reinterpret_cast<const float *>(ea.at(c)), v, DROP ? drop_word(q, H, h, offset, seed) : 0u);
+  };
+  int64_t p = it.beg;
+  for (; p < it.end && (p & 3) != 0; ++p) single(p);
+  for (; p + 8 <= it.end; p += 8) {
+    const int4 i0 = *reinterpret_cast<const int4 *>(col + p), i1 = *reinterpret_cast<const int4 *>(col + p + 4);
+    const int32_t c[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+    float4 v[8];
+    float e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(xa.at(c[u]));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = *reinterpret_cast<const float *>(ea.at(c[u]));
+    U4 r0{0u, 0u, 0u, 0u}, r1{0u, 0u, 0u, 0u};
+    if (DROP) {
+      r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+      r1 = philox4x32_10((uint64_t)(((p >> 2) + 1) * H + h), offset, seed);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) edge(e[u], v[u], pick_word(r0, u));
+#pragma unroll
+    for (int u = 4; u < 8; ++u) edge(e[u], v[u], pick_word(r1, u - 4));
+  }
+  for (; p + 4 <= it.end; p += 4) {
+    const int4 i0 = *reinterpret_cast<const int4 *>(col + p);
+    const int32_t c[4] = {i0.x, i0.y, i0.z, i0.w};
+    float4 v[4];
+    float e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(xa.at(c[u]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = *reinterpret_cast<const float *>(ea.at(c[u]));
+    U4 r0{0u, 0u, 0u, 0u};
+    if (DROP) r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) edge(e[u], v[u], pick_word(r0, u));
+  }
+  for (; p < it.end; ++p) single(p);
+  if (lead) {
+    if (it.is_chunk) pger[it.cid * H + h] = gsum;
+    else ger[it.row * H + h] = gsum;
+  }
+}
+
+// source walk of the backward (transposed plan; row = source node j, d.N = number of source rows):
+//   gx[j,h,:] = sum_q alpha_q keep_q / (1 - p_drop) g[i_q,h,:],   gel[j,h] = sum_q de_q,   i_q = colT[q]
+template <int C4, bool DROP, bool OFF32>
+__global__ __launch_bounds__(kBlock) void gat_bwd_src2_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col /* colT */,
+    const int32_t *__restrict__ posT, const int32_t *__restrict__ row_order,
+    const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr,
+    const float *__restrict__ el, const float *__restrict__ x, const float *__restrict__ g,
+    const float *__restrict__ stats, float *__restrict__ gx, float *__restrict__ gel,
+    float *__restrict__ pacc, float *__restrict__ pgel, const int64_t *__restrict__ rng, const GatDims d) {
+  GGL_GAT2_PROLOGUE();
+  const int64_t K = d.K;
+  const float slope = d.slope;
+  float4 xj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (act) xj = *reinterpret_cast<const float4 *>(x + it.row * K + kk);
+  const float el_j = el[it.row * H + h];
+  const RowAddr<OFF32> ga{reinterpret_cast<const char *>(g) + kk * 4, (uint32_t)(K * 4)};
+  const RowAddr<OFF32> sa{reinterpret_cast<const char *>(stats) + h * 16, (uint32_t)(H * 16)};
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float gl = 0.0f;
+  auto edge = [&](const float4 &gi, const float4 &st, int64_t q) {
+    float da = head_sum<C4>(dot4(gi, xj));
+    const float raw = el_j + st.x;
+    const float al = fexp(lrelu(raw, slope) - st.y) * st.z;
+    float alk = al;
+    if (DROP) {  // the keep bit of the FORWARD position of this edge
+      const bool keep = drop_word((int64_t)posT[q], H, h, offset, seed) >= d.drop_thresh;
+      alk = keep ? al * d.drop_scale : 0.0f;
+      da = keep ? da * d.drop_scale : 0.0f;
+    }
+    const float ds = al * (da - st.w);
+    gl += raw > 0.0f ? ds : ds * slope;
+    a.x = __builtin_fmaf(gi.x, alk, a.x); a.y = __builtin_fmaf(gi.y, alk, a.y);
+    a.z = __builtin_fmaf(gi.z, alk, a.z); a.w = __builtin_fmaf(gi.w, alk, a.w);
+  };
+  auto single = [&](int64_t q) {
+    const int32_t c = col[q];
+    const float4 gi = *reinterpret_cast<const float4 *>(ga.at(c));
+    const float4 st = *reinterpret_cast<const float4 *>(sa.at(c));
+    edge(gi, st, q);
+  };
+  int64_t p = it.beg;
+  for (; p < it.end && (p & 3) != 0; ++p) single(p);
+  for (; p + 4 <= it.end; p += 4) {  // 4 gradient rows + 4 stats vectors in flight
+    const int4 i0 = *reinterpret_cast<const int4 *>(col + p);
+    const int32_t c[4] = {i0.x, i0.y, i0.z, i0.w};
+    float4 gi[4], st[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gi[u] = *reinterpret_cast<const float4 *>(ga.at(c[u]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st[u] = *reinterpret_cast<const float4 *>(sa.at(c[u]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) edge(gi[u], st[u], p + u);
+  }
+  for (; p < it.end; ++p) single(p);
+  if (!act) return;
+  if (it.is_chunk) {
+    *reinterpret_cast<float4 *>(pacc + it.cid * K + kk) = a;
+    if (lead) pgel[it.cid * H + h] = gl;
+    return;
+  }
+  *reinterpret_cast<float4 *>(gx + it.row * K + kk) = a;
+  if (lead) gel[it.row * H + h] = gl;
+}
+#endif  // !GGL_EMULATE
+
 static inline int pow2_log2(int64_t v) {
   int l = 0;
   while (l < 6 && ((int64_t)1 << l) < v) ++l;
@@ -849,4 +1199,174 @@ extern "C" int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *
     GGL_LAUNCH_CHECK();
   }
   return GGL_OK;
+}
+
+// ---- fast path entry points (see the block comment above gat_fwd2_kernel) ---------------------------------
+static int gat_fast_c4(int64_t H, int64_t C) {
+#ifdef GGL_EMULATE
+  (void)H; (void)C;
+  return 0;
+#else
+  if (H <= 0 || C <= 0 || C % 4 != 0) return 0;
+  const int64_t c4 = C / 4;
+  if (c4 != 1 && c4 != 2 && c4 != 4 && c4 != 8 && c4 != 16) return 0;
+  if (H * c4 > 64) return 0;
+  return (int)c4;
+#endif
+}
+
+extern "C" int ggl_gat_fast_supported(int64_t H, int64_t C) { return gat_fast_c4(H, C) ? 1 : 0; }
+
+#ifndef GGL_EMULATE
+static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// dispatch KERN<C4, DROP, OFF32> over the supported head widths
+#define GGL_GAT2_DISPATCH(KERN, c4, drop, off32, ...)                                                  \
+  do {                                                                                                 \
+    const int sel_ = ((drop) ? 2 : 0) | ((off32) ? 1 : 0);                                             \
+    switch ((c4) * 4 + sel_) {                                                                         \
+      GGL_GAT2_CASES(KERN, 1, __VA_ARGS__) GGL_GAT2_CASES(KERN, 2, __VA_ARGS__)                        \
+      GGL_GAT2_CASES(KERN, 4, __VA_ARGS__) GGL_GAT2_CASES(KERN, 8, __VA_ARGS__)                        \
+      GGL_GAT2_CASES(KERN, 16, __VA_ARGS__)                                                            \
+      default: break;                                                                                  \
+    }                                                                                                  \
+  } while (0)
+#define GGL_GAT2_CASES(KERN, C4, ...)                                                                  \
+  case C4 * 4 + 0: GGL_LAUNCH((KERN<C4, false, false>), grid, kBlock, s, __VA_ARGS__); break;          \
+  case C4 * 4 + 1: GGL_LAUNCH((KERN<C4, false, true>), grid, kBlock, s, __VA_ARGS__); break;           \
+  case C4 * 4 + 2: GGL_LAUNCH((KERN<C4, true, false>), grid, kBlock, s, __VA_ARGS__); break;           \
+  case C4 * 4 + 3: GGL_LAUNCH((KERN<C4, true, true>), grid, kBlock, s, __VA_ARGS__); break;
+#endif
+
+extern "C" int ggl_gat_fast_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
+                                const float *er, const float *x, int64_t N_src, float slope, int64_t H,
+                                int64_t C, float p_drop, int64_t *rng_state, float *out, float *rowmax,
+                                float *rowden, void *stream) {
+#ifdef GGL_EMULATE
+  (void)plan; (void)col; (void)el; (void)er; (void)x; (void)N_src; (void)slope; (void)H; (void)C; (void)p_drop;
+  (void)rng_state; (void)out; (void)rowmax; (void)rowden; (void)stream;
+  set_error("the fast GAT path needs the GPU build");
+  return GGL_EINVAL;
+#else
+  GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
+  const int c4 = gat_fast_c4(H, C);
+  GGL_REQUIRE(c4 > 0 && plan->chunk > 0, GGL_EINVAL, "head shape not supported by the fast GAT path");
+  const int64_t N = plan->N;
+  if (N == 0) return GGL_OK;
+  GGL_REQUIRE(er && out && rowmax && rowden, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE((col && el && x) || plan->E == 0, GGL_EINVAL, "NULL pointer");
+  GatDims d{};
+  d.slope = slope; d.N = N; d.H = H; d.C = C; d.K = H * C; d.E = plan->E;
+  d.chunk = plan->chunk; d.n_long = plan->n_long; d.n_chunks = plan->n_long > 0 ? plan->n_chunks : 0;
+  int rcd = set_dropout(d, p_drop, rng_state);
+  if (rcd) return rcd;
+  float *pacc = nullptr, *pm = nullptr, *pd = nullptr;
+  if (plan->n_long > 0) {
+    GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
+                "plan has long rows but long_rows/chunk_ptr/partial is NULL");
+    pacc = static_cast<float *>(plan->partial);
+    pm = pacc + plan->n_chunks * d.K;
+    pd = pm + plan->n_chunks * H;
+  }
+  GGL_REQUIRE(al16(x) && al16(out) && al16(pacc) && al16(col), GGL_EINVAL, "fast GAT path needs 16-byte aligned buffers");
+  d.logL = pow2_log2(H * c4);
+  const int64_t items = d.n_chunks + N;
+  const int64_t grid = ceil_div(items << d.logL, (int64_t)kBlock);
+  GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+  const int32_t *order = options().row_order ? plan->row_order : nullptr;
+  const bool off32 = N_src > 0 && N_src * d.K * 4 < ((int64_t)1 << 32);
+  hipStream_t s = as_stream(stream);
+  GGL_GAT2_DISPATCH(gat_fwd2_kernel, c4, d.drop_thresh != 0, off32, plan->rowptr, col, order, plan->long_rows,
+                    plan->chunk_ptr, el, er, x, out, rowmax, rowden, pacc, pm, pd, (const int64_t *)rng_state, d);
+  GGL_LAUNCH_CHECK();
+  if (plan->n_long > 0) {
+    GGL_LAUNCH((gat_long_final_kernel), plan->n_long, kBlock, s, plan->long_rows, plan->chunk_ptr,
+               (const float *)pacc, (const float *)pm, (const float *)pd, out, rowmax, rowden, d);
+    GGL_LAUNCH_CHECK();
+  }
+  if (d.drop_thresh) return rng_advance(rng_state, stream);
+  return GGL_OK;
+#endif
+}
+
+// Both walks of the backward.  stats: workspace of N_dst * H * 4 floats (16-byte aligned).  plan->partial:
+// >= n_chunks * H floats; planT->partial: ggl_partial_bytes(GGL_F32, n_chunksT, H*C + H, 0) bytes.
+extern "C" int ggl_gat_fast_bwd(const ggl_segplan_t *plan, const int32_t *col, const ggl_segplan_t *planT,
+                                const int32_t *colT, const int32_t *posT, const float *el, const float *er,
+                                const float *x, const float *g, const float *out, const float *rowmax,
+                                const float *rowden, float slope, int64_t H, int64_t C, float p_drop,
+                                const int64_t *rng_used, float *stats, float *gx, float *gel, float *ger,
+                                void *stream) {
+#ifdef GGL_EMULATE
+  (void)plan; (void)col; (void)planT; (void)colT; (void)posT; (void)el; (void)er; (void)x; (void)g; (void)out;
+  (void)rowmax; (void)rowden; (void)slope; (void)H; (void)C; (void)p_drop; (void)rng_used; (void)stats; (void)gx;
+  (void)gel; (void)ger; (void)stream;
+  set_error("the fast GAT path needs the GPU build");
+  return GGL_EINVAL;
+#else
+  GGL_REQUIRE(plan && plan->rowptr && planT && planT->rowptr, GGL_EINVAL, "plan is NULL");
+  const int c4 = gat_fast_c4(H, C);
+  GGL_REQUIRE(c4 > 0 && plan->chunk > 0 && planT->chunk > 0, GGL_EINVAL, "head shape not supported by the fast GAT path");
+  const int64_t N = plan->N, NT = planT->N, E = plan->E;
+  GGL_REQUIRE(planT->E == E, GGL_EINVAL, "forward and transposed plans disagree");
+  hipStream_t s = as_stream(stream);
+  GatDims d{};
+  d.slope = slope; d.H = H; d.C = C; d.K = H * C; d.E = E;
+  int rcd = set_dropout(d, p_drop, rng_used);
+  if (rcd) return rcd;
+  GGL_REQUIRE(p_drop == 0.0f || posT || E == 0, GGL_EINVAL, "attention dropout needs posT");
+  d.logL = pow2_log2(H * c4);
+  const bool off32 = (N > NT ? N : NT) * d.K * 4 < ((int64_t)1 << 32);
+  if (N > 0) {  // destination walk
+    GGL_REQUIRE(er && g && out && rowmax && rowden && ger && stats, GGL_EINVAL, "NULL pointer");
+    GGL_REQUIRE((col && el && x) || E == 0, GGL_EINVAL, "NULL pointer");
+    d.N = N; d.chunk = plan->chunk; d.n_long = plan->n_long; d.n_chunks = plan->n_long > 0 ? plan->n_chunks : 0;
+    float *pger = nullptr;
+    if (plan->n_long > 0) {
+      GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
+                  "plan has long rows but long_rows/chunk_ptr/partial is NULL");
+      pger = static_cast<float *>(plan->partial);
+    }
+    GGL_REQUIRE(al16(x) && al16(g) && al16(out) && al16(stats) && al16(col), GGL_EINVAL,
+                "fast GAT path needs 16-byte aligned buffers");
+    const int64_t grid = ceil_div((d.n_chunks + N) << d.logL, (int64_t)kBlock);
+    GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+    const int32_t *order = options().row_order ? plan->row_order : nullptr;
+    GGL_GAT2_DISPATCH(gat_bwd_dst2_kernel, c4, d.drop_thresh != 0, off32, plan->rowptr, col, order,
+                      plan->long_rows, plan->chunk_ptr, el, er, x, g, out, rowmax, rowden, stats, ger, pger,
+                      rng_used, d);
+    GGL_LAUNCH_CHECK();
+    if (plan->n_long > 0) {
+      GGL_LAUNCH((gat_bwd_dst_final_kernel), grid_for(plan->n_long * H), kBlock, s, plan->long_rows,
+                 plan->chunk_ptr, (const float *)pger, ger, plan->n_long, H);
+      GGL_LAUNCH_CHECK();
+    }
+  }
+  if (NT > 0) {  // source walk
+    GGL_REQUIRE(gx && gel && el && x, GGL_EINVAL, "NULL pointer");
+    GGL_REQUIRE((colT && g && stats) || E == 0, GGL_EINVAL, "NULL pointer");
+    d.N = NT; d.chunk = planT->chunk; d.n_long = planT->n_long; d.n_chunks = planT->n_long > 0 ? planT->n_chunks : 0;
+    float *pacc = nullptr, *pgel = nullptr;
+    if (planT->n_long > 0) {
+      GGL_REQUIRE(planT->long_rows && planT->chunk_ptr && planT->partial, GGL_EWORKSPACE,
+                  "transposed plan has long rows but long_rows/chunk_ptr/partial is NULL");
+      pacc = static_cast<float *>(planT->partial);
+      pgel = pacc + planT->n_chunks * d.K;
+    }
+    GGL_REQUIRE(al16(x) && al16(g) && al16(gx) && al16(pacc) && al16(colT), GGL_EINVAL,
+                "fast GAT path needs 16-byte aligned buffers");
+    const int64_t grid = ceil_div((d.n_chunks + NT) << d.logL, (int64_t)kBlock);
+    GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+    const int32_t *order = options().row_order ? planT->row_order : nullptr;
+    GGL_GAT2_DISPATCH(gat_bwd_src2_kernel, c4, d.drop_thresh != 0, off32, planT->rowptr, colT, posT, order,
+                      planT->long_rows, planT->chunk_ptr, el, x, g, (const float *)stats, gx, gel, pacc, pgel,
+                      rng_used, d);
+    GGL_LAUNCH_CHECK();
+    if (planT->n_long > 0) {
+      GGL_LAUNCH((gat_bwd_src_final_kernel), planT->n_long, kBlock, s, planT->long_rows, planT->chunk_ptr,
+                 (const float *)pacc, (const float *)pgel, gx, gel, d);
+      GGL_LAUNCH_CHECK();
+    }
+  }
+  return GGL_OK;
+#endif
 }

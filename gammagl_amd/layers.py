@@ -66,6 +66,7 @@ def add_self_loops(edge_index, num_nodes):
 
 
 FUSED_MIN_EDGES = 2_000_000  # default message()+aggregate() pairs take the fused SpMM from this many edges up
+SAGE_FUSE_EPILOGUE = True    # SAGEConv(mean): "+ fc_self(x_dst) + bias -> act" in the aggregate's store (A/B switch)
 
 
 class MessagePassing(nn.Module):
@@ -193,7 +194,11 @@ class GCNConv(MessagePassing):
             # same route takes weights that are not one f32 value per edge (a float64 edge_weight promotes the
             # messages exactly as the reference's message() does, a mis-shaped one raises there as it does here)
             out = self.aggregate(self.message(x, edge_index, weights), edge_index, num_nodes, 'sum')
-            if bias is not None or relu or p_drop > 0:
+            if out.dtype != torch.float32:   # promoted messages: the epilogue in torch, as the reference runs it
+                out = out + bias if bias is not None else out
+                out = torch.relu(out) if relu else out
+                out = torch.nn.functional.dropout(out, p_drop, training) if p_drop > 0 else out
+            elif bias is not None or relu or p_drop > 0:
                 out = _engine().bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
         elif (x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0
               and weights.dtype == torch.float32 and weights.numel() == edge_index.shape[1]):
@@ -229,6 +234,20 @@ class SAGEConv(MessagePassing):
         num_nodes = int(dst_feat.shape[0])
         if self.aggr == 'mean':
             src_feat = self.fc_neigh(src_feat)
+            fused_act = self.act is None or self.act is torch.relu or self.act is torch.nn.functional.relu
+            if SAGE_FUSE_EPILOGUE and src_feat.dim() == 2 and src_feat.dtype == torch.float32 and fused_act:
+                # "mean + fc_self(x_dst) + bias -> act" (sage_conv.py:100-108) rides on the aggregate's store:
+                # the fused rectangular SpMM-mean for big edge lists, the segment route for sampled blocks
+                eng = _engine()
+                self_term = self.fc_self(dst_feat)
+                if edge.shape[1] >= FUSED_MIN_EDGES:
+                    gp = eng.graph_plan(edge, num_nodes, int(src_feat.shape[0]))
+                    return eng.spmm_epi(gp, None, src_feat, "mean", add=self_term, bias=self.bias,
+                                        relu=self.act is not None)
+                msg = src_feat.index_select(0, edge[0])
+                if src_feat.shape[1] % 4 == 0:
+                    return eng.segment_epi(msg, edge[1], num_nodes, "mean", add=self_term, bias=self.bias,
+                                           relu=self.act is not None)
             # (propagate picks the fused SpMM-mean for big edge lists, the segment route for sampled blocks)
             out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='mean')
         elif self.aggr == 'gcn':

@@ -152,6 +152,7 @@ class Engine:
         self._rng = {}
         self.stats = {"plans_built": 0, "plan_hits": 0}
         self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk; 0 = auto_chunk(E)
+        self.gat_fast = True        # fused GAT: the low-VALU kernels where the head shape allows (GPU build only)
         self._make_functions()
 
     # ---- plumbing ----------------------------------------------------------------------------
@@ -666,9 +667,16 @@ class Engine:
                 if p_drop > 0:
                     rng = eng._rng_state(dev)
                     rng_used = rng.clone()  # the {seed, offset} this launch reads; the backward redraws the mask
-                eng._check(eng.lib.ggl_gat_fused_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er),
-                                                     _ptr(x), float(slope), H, C, float(p_drop), _ptr(rng),
-                                                     _ptr(out), _ptr(rmax), _ptr(rden), eng._stream(dev)))
+                fast = bool(eng.gat_fast and eng.lib.ggl_gat_fast_supported(H, C))
+                if fast:
+                    eng._check(eng.lib.ggl_gat_fast_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er), _ptr(x),
+                                                        int(x.shape[0]), float(slope), H, C, float(p_drop), _ptr(rng),
+                                                        _ptr(out), _ptr(rmax), _ptr(rden), eng._stream(dev)))
+                else:
+                    eng._check(eng.lib.ggl_gat_fused_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er),
+                                                         _ptr(x), float(slope), H, C, float(p_drop), _ptr(rng),
+                                                         _ptr(out), _ptr(rmax), _ptr(rden), eng._stream(dev)))
+                ctx.fast = fast
                 ctx.gp, ctx.slope, ctx.p_drop, ctx.rng_used = gp, float(slope), float(p_drop), rng_used
                 ctx.save_for_backward(el, er, x, out, rmax, rden)
                 return out
@@ -681,6 +689,21 @@ class Engine:
                 dev = g.device
                 H, C = int(x.shape[1]), int(x.shape[2])
                 st = eng._stream(dev)
+                if ctx.fast:  # both walks recompute alpha / de from per-row constants: no [E, H, 2] buffer
+                    bwd = gp.bwd
+                    stats = torch.empty((gp.N_dst, H, 4), dtype=torch.float32, device=dev)
+                    ger = torch.empty_like(er)
+                    gx = torch.empty((gp.N_src, H, C), dtype=torch.float32, device=dev)
+                    gel = torch.empty((gp.N_src, H), dtype=torch.float32, device=dev)
+                    part_f = eng._partial(gp.fwd, torch.float32, H, False, dev)
+                    part_t = eng._partial(bwd, torch.float32, H * C + H, False, dev)
+                    cs, csT = gp.fwd.c_struct(part_f), bwd.c_struct(part_t)
+                    posT = gp.posT if ctx.p_drop > 0 else None
+                    eng._check(eng.lib.ggl_gat_fast_bwd(
+                        ctypes.byref(cs), _ptr(gp.col), ctypes.byref(csT), _ptr(gp.colT), _ptr(posT), _ptr(el),
+                        _ptr(er), _ptr(x), _ptr(g), _ptr(out), _ptr(rmax), _ptr(rden), ctx.slope, H, C, ctx.p_drop,
+                        _ptr(ctx.rng_used), _ptr(stats), _ptr(gx), _ptr(gel), _ptr(ger), st))
+                    return None, gel, ger, gx, None, None
                 # alpha and de interleaved [E, H, 2]: the source-side walk fetches both with one 64-byte line
                 ad = torch.empty((max(gp.E, 1), H, 2), dtype=torch.float32, device=dev)
                 alpha, de = ad.data_ptr(), ad.data_ptr() + 4
@@ -793,6 +816,94 @@ class Engine:
                     gx, _ = eng._spmm_fwd("sum", gp.bwd, gp.colT, ctx.w, ga, gp.N_src)
                 return None, None, gx, (gb.reshape(bshape) if gb is not None else None), None, None
 
+        def _epi_backward(ctx, g, y):
+            """Through dropout / ReLU / + bias / + add in one pass: returns (ga, gbias)."""
+            N, K, relu, p_drop, bshape = ctx.cfg
+            g = g.contiguous()
+            dev = g.device
+            if not (relu or p_drop > 0 or bshape is not None):
+                return g, None
+            ga = torch.empty_like(g)
+            gb = torch.empty(K, dtype=torch.float32, device=dev) if bshape is not None else None
+            wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K)
+            ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+            eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K, relu, p_drop, _ptr(ctx.rng_used),
+                                                _ptr(ga), _ptr(gb), _ptr(ws), wsb, eng._stream(dev)))
+            return ga, (gb.reshape(bshape) if gb is not None else None)
+
+        class SpMMEpi(torch.autograd.Function):
+            """y = dropout(relu(reduce(A x) + add + bias)), reduce = sum | mean, in ONE kernel (ggl_spmm_epi_ex):
+            GCNConv's "+ bias" (gcn_conv.py:105-106) and SAGEConv's "mean + fc_self(x_dst) + bias -> act"
+            (sage_conv.py:100-108) applied to each finished row in registers."""
+
+            @staticmethod
+            def forward(ctx, gp, w, x, mean, add, bias, relu, p_drop):
+                dev = x.device
+                K = int(x.shape[1])
+                y = torch.empty((gp.N_dst, K), dtype=torch.float32, device=dev)
+                rng = eng._rng_state(dev) if p_drop > 0 else None
+                ctx.rng_used = rng.clone() if rng is not None else None
+                b = bias.contiguous().reshape(-1) if bias is not None else None
+                a = add.contiguous() if add is not None else None
+                eng.spmm_epi_into(gp.fwd, gp.col, w, x, y, mean=mean, add=a, bias=b, relu=relu, p_drop=p_drop, rng=rng)
+                ctx.gp, ctx.w, ctx.mean, ctx.has_add = gp, w, bool(mean), add is not None
+                ctx.cfg = (int(gp.N_dst), K, int(relu), float(p_drop), None if bias is None else bias.shape)
+                ctx.save_for_backward(y)
+                return y
+
+            @staticmethod
+            def backward(ctx, g):
+                (y,) = ctx.saved_tensors
+                ga, gb = _epi_backward(ctx, g, y)
+                gp = ctx.gp
+                gx = None
+                if ctx.needs_input_grad[2]:
+                    if ctx.mean:
+                        gx, _ = eng._spmm_fwd("mean_bwd", gp.bwd, gp.colT, ctx.w, ga, gp.N_src, aux=gp.fwd.rowptr)
+                    else:
+                        gx, _ = eng._spmm_fwd("sum", gp.bwd, gp.colT, ctx.w, ga, gp.N_src)
+                return None, None, gx, None, (ga if ctx.has_add else None), gb, None, None
+
+        class SegmentEpi(torch.autograd.Function):
+            """The same epilogue on segment_sum / segment_mean of f32 messages x[E, K] (ggl_segment_epi): the
+            message() + aggregate() route of a sampled SAGEConv block."""
+
+            @staticmethod
+            def forward(ctx, x, ids, N, mean, add, bias, relu):
+                dev = x.device
+                plan = eng.seg_plan(ids, N)
+                K = int(x.shape[1])
+                if int(x.shape[0]) != plan.E:
+                    raise IndexError("fisrt dimension of x and index should be same")
+                y = torch.empty((plan.N, K), dtype=torch.float32, device=dev)
+                part = eng._partial(plan, torch.float32, K, False, dev)
+                cs = plan.c_struct(part)
+                b = bias.contiguous().reshape(-1) if bias is not None else None
+                a = add.contiguous() if add is not None else None
+                eng._check(eng.lib.ggl_segment_epi(_ptr(x), ctypes.byref(cs), K, int(bool(mean)), _ptr(a), 0, _ptr(b),
+                                                   int(bool(relu)), 0.0, None, _ptr(y), eng._stream(dev)))
+                ctx.mean, ctx.has_add, ctx.x_shape, ctx.rng_used = bool(mean), add is not None, x.shape, None
+                ctx.cfg = (int(plan.N), K, int(relu), 0.0, None if bias is None else bias.shape)
+                ctx.save_for_backward(y, ids, plan.rowptr)
+                return y
+
+            @staticmethod
+            def backward(ctx, g):
+                y, ids, rowptr = ctx.saved_tensors
+                ga, gb = _epi_backward(ctx, g, y)
+                gx = None
+                if ctx.needs_input_grad[0]:
+                    E, K = int(ctx.x_shape[0]), int(ctx.x_shape[1])
+                    gx = torch.empty(ctx.x_shape, dtype=ga.dtype, device=ga.device)
+                    if ctx.mean:
+                        eng._check(eng.lib.ggl_segment_mean_bwd(eng._code(ga), _ptr(ga), _ptr(ids), _ptr(rowptr), E, K,
+                                                                _ptr(gx), eng._stream(ga.device)))
+                    else:
+                        eng._check(eng.lib.ggl_segment_sum_bwd(eng._code(ga), _ptr(ga), _ptr(ids), E, K, _ptr(gx),
+                                                               eng._stream(ga.device)))
+                return gx, None, None, None, (ga if ctx.has_add else None), gb, None
+
+        self.SpMMEpi, self.SegmentEpi = SpMMEpi, SegmentEpi
         self.SpMMSumBiasAct = SpMMSumBiasAct
         self.BiasAct = BiasAct
         self.BiasAdd = BiasAdd
@@ -947,6 +1058,39 @@ class Engine:
         if x.dim() == 2 and x.shape[1] % 4 == 0:
             return self.SpMMSumBiasAct.apply(gp, weight, x.contiguous(), bias, bool(relu), p)
         return self.BiasAct.apply(self.SpMMSum.apply(gp, weight, x.contiguous()), bias, bool(relu), p)
+
+    def spmm_epi(self, gp, weight, x, reduce="sum", add=None, bias=None, relu=False, p_drop=0.0, training=True):
+        """dropout(relu(reduce_{j->i} w x_j + add_i + bias)), reduce in {'sum', 'mean'}: one kernel for 16-byte
+        rows (feature width a multiple of 4), the reduce op followed by the adds and the epilogue pass otherwise."""
+        self._dev(x, weight, bias, add)
+        self._check_f32("x", x)
+        weight = self._check_weight(weight, gp)
+        for n, t in (("bias", bias), ("add", add)):
+            if t is not None:
+                self._check_f32(n, t)
+        if add is not None and tuple(add.shape) != (gp.N_dst, x.shape[1]):
+            raise RuntimeError("add must be [destination rows, feature width]")
+        p = float(p_drop) if training else 0.0
+        if x.dim() == 2 and x.shape[1] % 4 == 0:
+            return self.SpMMEpi.apply(gp, weight, x.contiguous(), reduce == "mean", add, bias, bool(relu), p)
+        out = self.spmm(gp, weight, x, reduce)
+        if add is not None:
+            out = out + add
+        return self.BiasAct.apply(out, bias, bool(relu), p)
+
+    def segment_epi(self, msg, ids, N, reduce="mean", add=None, bias=None, relu=False):
+        """relu(segment_{sum,mean}(msg, ids, N) + add + bias) for f32 messages [E, K] — one kernel."""
+        self._dev(msg, ids, bias, add)
+        self._check_f32("msg", msg)
+        msg, ids, N = self._seg_args(msg, ids, N)
+        if msg.dim() != 2:
+            raise RuntimeError("segment_epi expects [E, K] messages")
+        for n, t in (("bias", bias), ("add", add)):
+            if t is not None:
+                self._check_f32(n, t)
+        if add is not None and tuple(add.shape) != (N, msg.shape[1]):
+            raise RuntimeError("add must be [num_segments, feature width]")
+        return self.SegmentEpi.apply(msg, ids, N, reduce == "mean", add, bias, bool(relu))
 
     def set_option(self, name, value):
         self._check(self.lib.ggl_set_option(name.encode(), int(value)))

@@ -819,3 +819,156 @@ def check_plan_cache(eng, dev):
     b1 = eng.stats["plans_built"]
     eng.c_segment_sum(x, ei[1], 3)
     assert eng.stats["plans_built"] == b1
+
+
+def check_dropout_without_relu_gradient(eng, dev):
+    """relu=False with p_drop > 0: a KEPT negative activation must receive its gradient (the first version
+    rebuilt the mask as y > 0 and zeroed all of them).  The backward redraws the Philox mask from the rng state
+    the forward read, so it is exact also for kept activations that are exactly zero."""
+    g = torch.Generator(device="cpu").manual_seed(31)
+    for (N, K) in ((200, 64), (131, 47)):
+        a0 = torch.randn(N, K, generator=g)
+        a0[::7] = 0.0                                    # exact zeros that the mask keeps or drops
+        b0 = torch.zeros(1, K)
+        go = torch.randn(N, K, generator=g).to(dev)
+        a = a0.to(dev).requires_grad_(True)
+        b = b0.to(dev).requires_grad_(True)
+        p = 0.5
+        st = eng._rng_state(dev).clone()
+        y = eng.bias_act(a, b, relu=False, p_drop=p)
+        y.backward(go)
+        # the mask, independently: a second draw from the same state on an input without zeros
+        eng._rng_state(dev).copy_(st)
+        keep = eng.bias_act(torch.ones(N, K, device=dev), None, relu=False, p_drop=p) != 0
+        assert 0.4 < float(keep.float().mean()) < 0.6
+        assert torch.equal(y.detach(), torch.where(keep, (a.detach() + b.detach()) * (1 / (1 - p)), torch.zeros_like(y)))
+        want = torch.where(keep, go * (1 / (1 - p)), torch.zeros_like(go))
+        assert torch.equal(a.grad, want)
+        neg_kept = keep & (a.detach() < 0)
+        assert int(neg_kept.sum()) > 100 and bool((a.grad[neg_kept] != 0).all())
+        zero_kept = keep & (a.detach() == 0)
+        assert int(zero_kept.sum()) > 0 and bool((a.grad[zero_kept] != 0).all())
+        torch.testing.assert_close(b.grad, want.sum(0, keepdim=True), rtol=1e-5, atol=1e-5)
+        # the same through the SpMM-fused epilogue
+        E = 900
+        ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+        gp = eng.graph_plan(ei, N)
+        x = torch.randn(N, K, generator=g).to(dev).requires_grad_(True)
+        eng._rng_state(dev).copy_(st)
+        y2 = eng.spmm_bias_act(gp, None, x, None, relu=False, p_drop=p)
+        y2.backward(go)
+        gx_ref = eng.spmm(eng.graph_plan(ei.flip(0).contiguous(), N), None, want)
+        assert torch.equal(x.grad, gx_ref) or torch.allclose(x.grad, gx_ref, rtol=1e-5, atol=1e-6)
+
+
+def check_epilogue_forms(eng, dev):
+    """ggl_spmm_epi_ex / ggl_segment_epi / ggl_gather_rows_f32_ex: sum and mean with "+ add + bias -> ReLU"
+    applied in the aggregate's store (SAGEConv: mean + fc_self(x_dst) + bias -> act, sage_conv.py:100-108) ==
+    the aggregate followed by the adds in torch, values and every gradient bit for bit; column blocks of a wider
+    matrix assemble the full-width result (same dropout mask); the send-row gather == index_select."""
+    g = torch.Generator(device="cpu").manual_seed(41)
+    old = eng.chunk
+    try:
+        for chunk in (0, 8):
+            eng.chunk = chunk
+            eng.graph_cache.clear(); eng.seg_cache.clear()
+            for (Nd, Ns, E, K) in ((40, 70, 600, 8), (64, 64, 900, 64), (50, 90, 700, 256), (6, 9, 0, 12)):
+                ei = torch.stack([torch.randint(0, Ns, (E,), generator=g), torch.randint(0, Nd, (E,), generator=g)])
+                if E:
+                    ei[1, : E // 3] = 3
+                ei = ei.to(dev)
+                gp = eng.graph_plan(ei, Nd, Ns)
+                go = torch.randn(Nd, K, generator=g).to(dev)
+                for reduce in ("sum", "mean"):
+                    for relu in (False, True):
+                        mk = lambda *s: torch.randn(*s, generator=g).to(dev).requires_grad_(True)  # noqa: E731
+                        x, add, bias = mk(Ns, K), mk(Nd, K), mk(1, K)
+                        x2, add2, bias2 = (t.detach().clone().requires_grad_(True) for t in (x, add, bias))
+                        y = eng.spmm_epi(gp, None, x, reduce, add=add, bias=bias, relu=relu)
+                        ref = eng.spmm(gp, None, x2, reduce) + add2
+                        ref = ref + bias2
+                        ref = torch.relu(ref) if relu else ref
+                        assert torch.equal(y, ref), (chunk, Nd, E, K, reduce, relu)
+                        if Nd * K:
+                            y.backward(go)
+                            ref.backward(go)
+                            assert torch.equal(x.grad, x2.grad) and torch.equal(add.grad, add2.grad)
+                            torch.testing.assert_close(bias.grad, bias2.grad, rtol=1e-5, atol=1e-5)
+                        # the segment route on pre-gathered messages
+                        m1 = x.detach()[ei[0]].clone().requires_grad_(True)
+                        m2 = m1.detach().clone().requires_grad_(True)
+                        a1, a2 = add.detach().clone().requires_grad_(True), add.detach().clone().requires_grad_(True)
+                        ys = eng.segment_epi(m1, ei[1].contiguous(), Nd, reduce, add=a1, bias=bias.detach(), relu=relu)
+                        seg = eng.c_segment_mean if reduce == "mean" else eng.c_segment_sum
+                        rs = seg(m2, ei[1].contiguous(), Nd) + a2
+                        rs = rs + bias.detach()
+                        rs = torch.relu(rs) if relu else rs
+                        assert torch.equal(ys, rs), (chunk, Nd, E, K, reduce, relu, "segment")
+                        if Nd * K and E:
+                            ys.backward(go)
+                            rs.backward(go)
+                            assert torch.equal(m1.grad, m2.grad) and torch.equal(a1.grad, a2.grad)
+        eng.chunk = old
+        eng.graph_cache.clear(); eng.seg_cache.clear()
+        # column blocks: two edge sets added block by block, epilogue (with dropout) on the last one == full width
+        N, E, K = 60, 800, 32
+        e1 = torch.randint(0, N, (2, E), generator=g).to(dev)
+        e2 = torch.randint(0, N, (2, E // 2), generator=g).to(dev)
+        g1, g2 = eng.graph_plan(e1, N), eng.graph_plan(e2, N)
+        w1, w2 = torch.rand(E, generator=g).to(dev), torch.rand(E // 2, generator=g).to(dev)
+        x = torch.randn(N, K, generator=g).to(dev)
+        bias = torch.randn(K, generator=g).to(dev)
+        for p in (0.0, 0.4):
+            rng = eng._rng_state(dev)
+            st = rng.clone()
+            full = torch.empty(N, K, device=dev)
+            eng.spmm_sum_into(g1.fwd, g1.col, w1, x, full)
+            eng.spmm_epi_into(g2.fwd, g2.col, w2, x, full, accumulate=True, bias=bias, relu=True, p_drop=p, rng=rng,
+                              epi_K=K)
+            rng.copy_(st)
+            blk = torch.empty(N, K, device=dev)
+            eng.spmm_sum_into(g1.fwd, g1.col, w1, x, blk)
+            for c0 in (0, 8, 16, 24):
+                eng.spmm_epi_into(g2.fwd, g2.col, w2, x[:, c0:c0 + 8], blk[:, c0:c0 + 8], accumulate=True, bias=bias,
+                                  relu=True, p_drop=p, rng=rng, epi_K=K, col0=c0, advance_rng=(c0 == 24))
+            assert torch.equal(full, blk), p
+            assert torch.equal(rng, st + torch.tensor([0, 1 if p > 0 else 0], device=dev))
+            rng.copy_(st)
+            two = eng.bias_act(eng.spmm(g1, w1, x) + 0, None)  # (plain composition for the values)
+            ref = torch.empty(N, K, device=dev)
+            eng.spmm_sum_into(g1.fwd, g1.col, w1, x, ref)
+            eng.spmm_sum_into(g2.fwd, g2.col, w2, x, ref, accumulate=True)
+            rng.copy_(st)
+            ref = eng.bias_act(ref, bias.reshape(1, K), relu=True, p_drop=p)
+            assert torch.equal(full, ref) and two.shape == ref.shape
+        # gather of send rows out of a column block
+        src = torch.randn(50, 40, generator=g).to(dev)
+        idx = torch.randint(0, 50, (77,), generator=g).to(dev)
+        for (c0, c1) in ((0, 40), (8, 24), (3, 10)):
+            out = torch.empty(77, c1 - c0, device=dev)
+            eng.gather_rows_into(src[:, c0:c1], idx, out)
+            assert torch.equal(out, src[:, c0:c1].index_select(0, idx))
+        wide = torch.zeros(77, 64, device=dev)
+        eng.gather_rows_into(src[:, 8:24], idx, wide[:, 32:48])
+        assert torch.equal(wide[:, 32:48], src[:, 8:24][idx]) and float(wide[:, :32].abs().sum()) == 0
+    finally:
+        eng.chunk = old
+        eng.graph_cache.clear(); eng.seg_cache.clear()
+
+
+def check_weight_dtype_guard(eng, dev):
+    """A float64 / mis-shaped edge weight must never reach a kernel as a raw f32 pointer (it produced values
+    off by 1e38): the explicit-plan ops raise like the reference's data_ptr<float>() would, and GCNConv with a
+    float64 edge_weight takes the message() route, which promotes exactly as the reference layer does."""
+    import pytest
+
+    g = torch.Generator(device="cpu").manual_seed(51)
+    N, E, K = 30, 200, 8
+    ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+    x = torch.randn(N, K, generator=g).to(dev)
+    w64 = torch.rand(E, generator=g, dtype=torch.float64).to(dev)
+    gp = eng.graph_plan(ei, N)
+    for call in (lambda: eng.spmm(gp, w64, x), lambda: eng.spmm_bias_act(gp, w64, x, None),
+                 lambda: eng.spmm(gp, torch.rand(E, K).to(dev), x), lambda: eng.spmm_bias_act(gp, torch.rand(E + 1).to(dev), x)):
+        with pytest.raises(RuntimeError):
+            call()

@@ -117,3 +117,15 @@ def test_fused_bias_relu_dropout(eng):
 
 def test_neighbor_sampler(eng, oracle):
     pc.check_sampler(eng, DEV, oracle)
+
+
+def test_dropout_without_relu_gradient(eng):
+    pc.check_dropout_without_relu_gradient(eng, DEV)
+
+
+def test_epilogue_forms_sage_and_column_blocks(eng):
+    pc.check_epilogue_forms(eng, DEV)
+
+
+def test_weight_dtype_guard(eng):
+    pc.check_weight_dtype_guard(eng, DEV)

@@ -598,3 +598,15 @@ def test_degree_from_plan_equals_segment_sum_of_ones(eng, dev):
             assert got.dtype == dt and torch.equal(got, ref), dt
     row = torch.tensor([0, 1, 0, 2, 0], device=dev)  # tests/utils/test_degree.py:5-9
     assert layers.degree(row, 3, dtype=torch.int64).tolist() == [3, 1, 1]
+
+
+def test_dropout_without_relu_gradient(eng, dev):
+    pc.check_dropout_without_relu_gradient(eng, dev)
+
+
+def test_epilogue_forms_sage_and_column_blocks(eng, dev):
+    pc.check_epilogue_forms(eng, dev)
+
+
+def test_weight_dtype_guard(eng, dev):
+    pc.check_weight_dtype_guard(eng, dev)

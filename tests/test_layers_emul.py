@@ -77,7 +77,33 @@ def _body():
         hs = sage.fc_neigh(x)
         ref = torch.zeros(nd, 6).index_add_(0, blk[1], hs[blk[0]]) / cnt + sage.fc_self(x[:nd]) + sage.bias
         torch.testing.assert_close(sage((x, x[:nd]), blk), ref, rtol=1e-5, atol=1e-5)
+    # "+ fc_self(x_dst) + bias -> act" fused into the aggregate's store == the three-pass form, bit for bit,
+    # values and gradients, on both routes (segment route for sampled blocks, fused SpMM-mean for big lists)
+    for thr in (10**12, 0):
+        layers.FUSED_MIN_EDGES = thr
+        for act in (torch.relu, None):
+            sage = layers.SAGEConv(10, 8, activation=act, aggr="mean")
+            torch.nn.init.normal_(sage.bias)
+            outs = []
+            for fuse in (True, False):
+                layers.SAGE_FUSE_EPILOGUE = fuse
+                xa = x.clone().requires_grad_(True)
+                y = sage((xa, xa[:nd]), blk)
+                gr = torch.autograd.grad(y.square().sum(), [xa] + list(sage.parameters()))
+                outs.append([y.detach()] + list(gr))
+            for a, b in zip(*outs):
+                torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+            assert torch.equal(outs[0][0], outs[1][0])
+    layers.SAGE_FUSE_EPILOGUE = True
     layers.FUSED_MIN_EDGES = 2_000_000
+    # a float64 edge_weight promotes the messages exactly as the reference's message() route does
+    conv = layers.GCNConv(10, 8, norm="none")
+    ew64 = torch.rand(ei.shape[1], generator=g, dtype=torch.float64)
+    y64 = conv(x, ei, ew64)
+    ref64 = agg((x @ conv.linear.weight.t()).double(), ew64) if False else \
+        torch.zeros(N, 8, dtype=torch.float64).index_add_(0, dst, (x @ conv.linear.weight.t())[src] * ew64.unsqueeze(1)) + conv.bias
+    assert y64.dtype == torch.float64
+    torch.testing.assert_close(y64, ref64, rtol=1e-9, atol=1e-9)
     pool = layers.SAGEConv(10, 6, aggr="pool")
     hp = torch.relu(pool.pool(x))
     mx = torch.full((nd, 10), -3.4028234663852886e38).scatter_reduce(0, blk[1].view(-1, 1).expand(-1, 10), hp[blk[0]], "amax")
