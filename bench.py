@@ -119,7 +119,7 @@ def cpu_baseline(hidden, classes, seed, full_graph=None):
     # second baseline: the reference's pure-torch formulation of the same aggregate
     # (mpops/torch.py:16-18,335-342: x[src] * w -> zeros().scatter_add_), all host threads, smaller sample
     torch.set_num_threads(cores)
-    e_t = min(E, 3_000_000)
+    e_t = min(E, 1_000_000)
     src, dst, wt = ei[0, :e_t], ei[1, :e_t], w[:e_t]
     t1 = time.perf_counter()
     for x in feats:

@@ -13,6 +13,14 @@
 // is done by the host layer with device sorts (gammagl_amd/sampler.py).
 #include "common.hpp"
 
+#ifndef GGL_EMULATE
+#include <rocprim/rocprim.hpp>
+#else
+#include <algorithm>
+#include <numeric>
+#include <vector>
+#endif
+
 namespace ggl {
 
 // Counter = (row a, draw b, call offset): every word of the counter block is its own coordinate, so draws of
@@ -130,6 +138,254 @@ static inline int64_t grid_for(int64_t n) {
   return g < 1 ? 1 : g;
 }
 
+// =====================================================================================================
+// One hop with DEVICE-side sizes (ggl_sample_hop): every buffer has a fixed capacity, the number of
+// seeds / sampled edges / nodes met lives in device memory and nothing is read back, so sampling, the
+// feature gather, both SAGEConv layers, the loss, backward and Adam of a mini-batch step capture into ONE
+// hipGraph (the dynamic-shape path above costs two host reads per hop and ~210 launches per mini-batch with
+// the GPU idle half of the time).  Relabelling as sample.cpp:24-55,104-130: seeds keep 0..B-1 verbatim
+// (duplicates included), new nodes follow in first-seen order, each row's columns ascend by local id.
+//   first occurrence of a node = atomicMin of its position into a per-node scratch (order-independent),
+//   local ids = exclusive scan over the first-occurrence flags.
+// =====================================================================================================
+constexpr long long kBigPos = (long long)1 << 62;
+
+__global__ __launch_bounds__(kBlock) void hop_count_kernel(const int64_t *__restrict__ rowptr,
+                                                           const int64_t *__restrict__ seeds,
+                                                           const int64_t *__restrict__ n_seeds, int64_t B_cap,
+                                                           int64_t fanout, int64_t *__restrict__ cnt) {
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i <= B_cap; i += stride) {
+    int64_t k = 0;
+    if (i < nb) {
+      const int64_t s = seeds[i];
+      const int64_t deg = rowptr[s + 1] - rowptr[s];
+      k = deg < fanout ? deg : fanout;
+    }
+    cnt[i] = k;  // cnt[B_cap] = 0: the exclusive scan leaves the total there
+  }
+}
+
+// thread per seed row: Floyd's algorithm (sample.cpp:75-83) or the whole neighbourhood when deg <= fanout
+__global__ __launch_bounds__(kBlock) void hop_pick_kernel(const int64_t *__restrict__ rowptr,
+                                                          const int64_t *__restrict__ col,
+                                                          const int64_t *__restrict__ seeds,
+                                                          const int64_t *__restrict__ n_seeds, int64_t B_cap,
+                                                          int64_t fanout, const int64_t *__restrict__ out_rowptr,
+                                                          const int64_t *__restrict__ rng, int64_t *__restrict__ e_pos,
+                                                          int64_t *__restrict__ nbr) {
+  const uint64_t seed = (uint64_t)rng[0], offset = (uint64_t)rng[1];
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < nb; i += stride) {
+    const int64_t n = seeds[i];
+    const int64_t beg = rowptr[n], deg = rowptr[n + 1] - beg;
+    const int64_t o = out_rowptr[i], k = out_rowptr[i + 1] - o;
+    if (deg <= fanout) {
+      for (int64_t j = 0; j < k; ++j) e_pos[o + j] = beg + j;
+    } else {
+      for (int64_t j = deg - k, s = 0; j < deg; ++j, ++s) {
+        const int64_t t = bounded(philox_u32((uint64_t)i, (uint64_t)s, seed, offset), j + 1);
+        bool taken = false;
+        for (int64_t q = 0; q < s; ++q) taken |= (e_pos[o + q] == beg + t);
+        e_pos[o + s] = beg + (taken ? j : t);
+      }
+    }
+    for (int64_t j = 0; j < k; ++j) nbr[o + j] = col[e_pos[o + j]];
+  }
+}
+
+// keys: seed i -> -(i + 1), sampled neighbour q -> B_cap + q.  The minimum per node is the LAST seed position
+// when the node is a seed (a seed listed twice maps to its last position: operator[] overwrite, sample.cpp:27)
+// and otherwise the first sampled occurrence.
+__global__ __launch_bounds__(kBlock) void hop_mark_kernel(const int64_t *__restrict__ seeds,
+                                                          const int64_t *__restrict__ n_seeds, int64_t B_cap,
+                                                          const int64_t *__restrict__ nbr,
+                                                          const int64_t *__restrict__ out_rowptr,
+                                                          long long *__restrict__ first_pos) {
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t ne = out_rowptr[B_cap];
+  const int64_t stride = grid_threads();
+  for (int64_t t = thread_id(); t < nb + ne; t += stride) {
+    if (t < nb) atomicMin(&first_pos[seeds[t]], -(long long)(t + 1));
+    else atomicMin(&first_pos[nbr[t - nb]], (long long)(B_cap + (t - nb)));
+  }
+}
+
+// flag[pos] = this position introduces a node: every seed (verbatim, sample.cpp:24-29) and the first
+// occurrence of every node that is not a seed
+__global__ __launch_bounds__(kBlock) void hop_flag_kernel(const int64_t *__restrict__ n_seeds, int64_t B_cap,
+                                                          int64_t E_cap, const int64_t *__restrict__ nbr,
+                                                          const int64_t *__restrict__ out_rowptr,
+                                                          const long long *__restrict__ first_pos,
+                                                          int64_t *__restrict__ flag) {
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t ne = out_rowptr[B_cap];
+  const int64_t stride = grid_threads();
+  for (int64_t t = thread_id(); t <= B_cap + E_cap; t += stride) {
+    int64_t f = 0;
+    if (t < B_cap) f = t < nb ? 1 : 0;
+    else if (t < B_cap + E_cap) {
+      const int64_t q = t - B_cap;
+      f = (q < ne && first_pos[nbr[q]] == (long long)t) ? 1 : 0;
+    }
+    flag[t] = f;  // flag[B_cap + E_cap] = 0: the exclusive scan leaves the node count there
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hop_emit_kernel(const int64_t *__restrict__ seeds,
+                                                          const int64_t *__restrict__ n_seeds, int64_t B_cap,
+                                                          int64_t E_cap, const int64_t *__restrict__ nbr,
+                                                          const int64_t *__restrict__ out_rowptr,
+                                                          const long long *__restrict__ first_pos,
+                                                          const int64_t *__restrict__ flag,
+                                                          const int64_t *__restrict__ new_id,
+                                                          int64_t *__restrict__ out_nid, int64_t *__restrict__ local,
+                                                          int64_t *__restrict__ counts) {
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t ne = out_rowptr[B_cap];
+  const int64_t n_nodes = new_id[B_cap + E_cap];
+  const int64_t stride = grid_threads();
+  if (thread_id() == 0) {
+    counts[0] = n_nodes;
+    counts[1] = ne;
+  }
+  for (int64_t t = thread_id(); t < B_cap + E_cap; t += stride) {
+    if (t >= n_nodes) out_nid[t] = 0;  // padding rows gather node 0 (any valid row: nothing reads them)
+  }
+  for (int64_t t = thread_id(); t < B_cap + E_cap; t += stride) {
+    if (t < B_cap) {
+      if (t < nb) out_nid[new_id[t]] = seeds[t];
+    } else {
+      const int64_t q = t - B_cap;
+      if (q < ne) {
+        const int64_t node = nbr[q];
+        if (flag[t]) out_nid[new_id[t]] = node;
+        const long long key = first_pos[node];
+        local[q] = key < 0 ? (int64_t)(-key - 1) : new_id[key];  // a seed keeps its own (last) position
+      } else {
+        local[q] = 0;
+      }
+    }
+  }
+}
+// (out_nid is written by two loops of the same launch: a padding slot j >= n_nodes is never a new_id target,
+//  so the two never touch the same element)
+
+__global__ __launch_bounds__(kBlock) void hop_reset_kernel(const int64_t *__restrict__ seeds,
+                                                           const int64_t *__restrict__ n_seeds, int64_t B_cap,
+                                                           const int64_t *__restrict__ nbr,
+                                                           const int64_t *__restrict__ out_rowptr,
+                                                           long long *__restrict__ first_pos) {
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t ne = out_rowptr[B_cap];
+  const int64_t stride = grid_threads();
+  for (int64_t t = thread_id(); t < nb + ne; t += stride) first_pos[t < nb ? seeds[t] : nbr[t - nb]] = kBigPos;
+}
+
+// thread per row: columns ascending by local id (sample.cpp:112-118), e_pos carried along; rows hold <= fanout
+// entries, so an in-place insertion sort is a handful of steps
+__global__ __launch_bounds__(kBlock) void hop_rowsort_kernel(const int64_t *__restrict__ out_rowptr, int64_t B_cap,
+                                                             int64_t E_cap, int64_t *__restrict__ local,
+                                                             int64_t *__restrict__ e_pos,
+                                                             int32_t *__restrict__ out_col,
+                                                             int64_t *__restrict__ out_eid) {
+  const int64_t ne = out_rowptr[B_cap];
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < B_cap; i += stride) {
+    const int64_t b = out_rowptr[i], e = out_rowptr[i + 1];
+    for (int64_t a = b + 1; a < e; ++a) {
+      const int64_t lv = local[a], ev = e_pos[a];
+      int64_t c = a - 1;
+      while (c >= b && local[c] > lv) {
+        local[c + 1] = local[c];
+        e_pos[c + 1] = e_pos[c];
+        --c;
+      }
+      local[c + 1] = lv;
+      e_pos[c + 1] = ev;
+    }
+    for (int64_t a = b; a < e; ++a) {
+      out_col[a] = (int32_t)local[a];
+      if (out_eid) out_eid[a] = e_pos[a];
+    }
+  }
+  for (int64_t q = ne + thread_id(); q < E_cap; q += stride) {  // padding past the sampled edges
+    out_col[q] = 0;
+    if (out_eid) out_eid[q] = 0;
+  }
+}
+
+// ---- transposed structure of a block, asynchronously (for the backward of its aggregate) --------------
+// key[q] = source column of edge q (N_src_cap for the padding past n_edges: sorts to the end),
+// val[q] = destination row of q (binary search in rowptr)
+__global__ __launch_bounds__(kBlock) void block_keys_kernel(const int64_t *__restrict__ rowptr, int64_t N_dst,
+                                                            const int32_t *__restrict__ col, int64_t E_cap,
+                                                            int64_t N_src_cap, uint32_t *__restrict__ keys,
+                                                            int32_t *__restrict__ vals) {
+  const int64_t ne = rowptr[N_dst];
+  const int64_t stride = grid_threads();
+  for (int64_t q = thread_id(); q < E_cap; q += stride) {
+    if (q >= ne) {
+      keys[q] = (uint32_t)N_src_cap;
+      vals[q] = 0;
+      continue;
+    }
+    int64_t lo = 0, hi = N_dst;  // first r with rowptr[r + 1] > q
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rowptr[mid + 1] <= q) lo = mid + 1; else hi = mid;
+    }
+    keys[q] = (uint32_t)col[q];
+    vals[q] = (int32_t)lo;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void block_rowptrT_kernel(const uint32_t *__restrict__ keys, int64_t E_cap,
+                                                               int64_t N_src_cap, int64_t *__restrict__ rowptrT) {
+  const int64_t stride = grid_threads();
+  for (int64_t s = thread_id(); s <= N_src_cap; s += stride) {
+    int64_t lo = 0, hi = E_cap;  // first position with key >= s
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)keys[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    rowptrT[s] = lo;
+  }
+}
+
+static inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+static inline int bits_for(int64_t n) {
+  int b = 1;
+  while (b < 32 && ((int64_t)1 << b) <= n) ++b;
+  return b;
+}
+#ifndef GGL_EMULATE
+static size_t scan_temp_bytes(int64_t n) {
+  size_t tmp = 0;
+  (void)rocprim::exclusive_scan(nullptr, tmp, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)n,
+                                rocprim::plus<int64_t>(), (hipStream_t)0);
+  return tmp;
+}
+static size_t sortpairs_temp_bytes(int64_t n, int bits) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)nullptr,
+                                  (int32_t *)nullptr, (size_t)n, 0u, (unsigned)bits, (hipStream_t)0);
+  return tmp;
+}
+#endif
+static int scan_i64(void *tmp, size_t tmp_bytes, const int64_t *in, int64_t *out, int64_t n, hipStream_t s) {
+#ifndef GGL_EMULATE
+  GGL_HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s));
+#else
+  (void)tmp; (void)tmp_bytes; (void)s;
+  int64_t acc = 0;
+  for (int64_t i = 0; i < n; ++i) { const int64_t v = in[i]; out[i] = acc; acc += v; }
+#endif
+  return GGL_OK;
+}
+
 }  // namespace ggl
 
 using namespace ggl;
@@ -166,6 +422,123 @@ extern "C" int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const 
              e_pos, nbr);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((sample_rng_advance_kernel), 1, 64, s, rng_state);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+// ---- static-shape hop -------------------------------------------------------------------------------
+extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t fanout) {
+  if (B_cap < 0 || fanout <= 0) return 0;
+  const int64_t E_cap = B_cap * fanout, T = B_cap + E_cap + 1;
+  size_t b = up256((size_t)(B_cap + 1) * 8);          // cnt
+  b += 3 * up256((size_t)(E_cap > 0 ? E_cap : 1) * 8);  // e_pos, nbr, local
+  b += 2 * up256((size_t)T * 8);                      // flag, new_id
+#ifndef GGL_EMULATE
+  b += up256(scan_temp_bytes(T > B_cap + 1 ? T : B_cap + 1));
+#endif
+  return b + 256;
+}
+
+extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds,
+                              const int64_t *n_seeds_dev, int64_t B_cap, int64_t fanout, int64_t *rng_state,
+                              int64_t *first_pos, int64_t *out_rowptr, int32_t *out_col, int64_t *out_eid,
+                              int64_t *out_nid, int64_t *out_counts, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+  GGL_REQUIRE(B_cap >= 0 && fanout > 0, GGL_EINVAL, "the static-shape hop needs a positive fan-out");
+  GGL_REQUIRE(B_cap < ((int64_t)1 << 31) && B_cap * fanout < ((int64_t)1 << 31), GGL_EINVAL, "block too large");
+  if (B_cap == 0) return GGL_OK;
+  GGL_REQUIRE(rowptr && seeds && n_seeds_dev && rng_state && first_pos && out_rowptr && out_col && out_nid &&
+                  out_counts, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_sample_hop_workspace_bytes(B_cap, fanout), GGL_EWORKSPACE,
+              "sample_hop workspace too small");
+  hipStream_t s = as_stream(stream);
+  const int64_t E_cap = B_cap * fanout, T = B_cap + E_cap + 1;
+  char *ws = static_cast<char *>(workspace);
+  size_t off = 0;
+  int64_t *cnt = reinterpret_cast<int64_t *>(ws + off); off += up256((size_t)(B_cap + 1) * 8);
+  int64_t *e_pos = reinterpret_cast<int64_t *>(ws + off); off += up256((size_t)E_cap * 8);
+  int64_t *nbr = reinterpret_cast<int64_t *>(ws + off); off += up256((size_t)E_cap * 8);
+  int64_t *local = reinterpret_cast<int64_t *>(ws + off); off += up256((size_t)E_cap * 8);
+  int64_t *flag = reinterpret_cast<int64_t *>(ws + off); off += up256((size_t)T * 8);
+  int64_t *new_id = reinterpret_cast<int64_t *>(ws + off); off += up256((size_t)T * 8);
+  void *tmp = ws + off;
+  const size_t tmp_bytes = workspace_bytes - off;
+  long long *fp = reinterpret_cast<long long *>(first_pos);
+  GGL_LAUNCH((hop_count_kernel), grid_for(B_cap + 1), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap, fanout, cnt);
+  GGL_LAUNCH_CHECK();
+  int rc = scan_i64(tmp, tmp_bytes, cnt, out_rowptr, B_cap + 1, s);
+  if (rc) return rc;
+  GGL_LAUNCH((hop_pick_kernel), grid_for(B_cap), kBlock, s, rowptr, col, seeds, n_seeds_dev, B_cap, fanout,
+             (const int64_t *)out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((hop_mark_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
+             (const int64_t *)out_rowptr, fp);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((hop_flag_kernel), grid_for(T), kBlock, s, n_seeds_dev, B_cap, E_cap, (const int64_t *)nbr,
+             (const int64_t *)out_rowptr, (const long long *)fp, flag);
+  GGL_LAUNCH_CHECK();
+  rc = scan_i64(tmp, tmp_bytes, flag, new_id, T, s);
+  if (rc) return rc;
+  GGL_LAUNCH((hop_emit_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, E_cap,
+             (const int64_t *)nbr, (const int64_t *)out_rowptr, (const long long *)fp, (const int64_t *)flag,
+             (const int64_t *)new_id, out_nid, local, out_counts);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((hop_reset_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
+             (const int64_t *)out_rowptr, fp);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((hop_rowsort_kernel), grid_for(B_cap), kBlock, s, (const int64_t *)out_rowptr, B_cap, E_cap, local, e_pos,
+             out_col, out_eid);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((sample_rng_advance_kernel), 1, 64, s, rng_state);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+extern "C" size_t ggl_block_transpose_workspace_bytes(int64_t E_cap, int64_t N_src_cap) {
+  if (E_cap < 0 || N_src_cap < 0) return 0;
+  size_t b = 3 * up256((size_t)(E_cap > 0 ? E_cap : 1) * 4);  // keys in / out, vals in
+#ifndef GGL_EMULATE
+  b += up256(sortpairs_temp_bytes(E_cap > 0 ? E_cap : 1, bits_for(N_src_cap)));
+#endif
+  return b + 256;
+}
+
+// rowptrT[N_src_cap + 1] / dstT[E_cap]: for source row j the destination rows of its block edges, ascending —
+// the CSC of a sampled block, built without reading anything back (graph-capture safe).
+extern "C" int ggl_block_transpose(const int64_t *rowptr, const int32_t *col, int64_t N_dst, int64_t N_src_cap,
+                                   int64_t E_cap, int64_t *rowptrT, int32_t *dstT, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+  GGL_REQUIRE(N_dst >= 0 && N_src_cap >= 0 && E_cap >= 0 && E_cap < ((int64_t)1 << 31) &&
+                  N_src_cap < ((int64_t)1 << 31) - 1, GGL_EINVAL, "bad sizes");
+  GGL_REQUIRE(rowptr && rowptrT, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_block_transpose_workspace_bytes(E_cap, N_src_cap), GGL_EWORKSPACE,
+              "block_transpose workspace too small");
+  hipStream_t s = as_stream(stream);
+  char *ws = static_cast<char *>(workspace);
+  const size_t seg = up256((size_t)(E_cap > 0 ? E_cap : 1) * 4);
+  uint32_t *keys_in = reinterpret_cast<uint32_t *>(ws), *keys_out = reinterpret_cast<uint32_t *>(ws + seg);
+  int32_t *vals_in = reinterpret_cast<int32_t *>(ws + 2 * seg);
+  if (E_cap > 0) {
+    GGL_REQUIRE(col && dstT, GGL_EINVAL, "NULL pointer");
+    GGL_LAUNCH((block_keys_kernel), grid_for(E_cap), kBlock, s, rowptr, N_dst, col, E_cap, N_src_cap, keys_in, vals_in);
+    GGL_LAUNCH_CHECK();
+#ifndef GGL_EMULATE
+    const int bits = bits_for(N_src_cap);
+    size_t tmp = sortpairs_temp_bytes(E_cap, bits);
+    GGL_HIP_CHECK(rocprim::radix_sort_pairs(ws + 3 * seg, tmp, (const uint32_t *)keys_in, keys_out,
+                                            (const int32_t *)vals_in, dstT, (size_t)E_cap, 0u, (unsigned)bits, s));
+#else
+    std::vector<int32_t> order((size_t)E_cap);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return keys_in[a] < keys_in[b]; });
+    for (int64_t i = 0; i < E_cap; ++i) {
+      keys_out[i] = keys_in[order[(size_t)i]];
+      dstT[i] = vals_in[order[(size_t)i]];
+    }
+#endif
+  }
+  GGL_LAUNCH((block_rowptrT_kernel), grid_for(N_src_cap + 1), kBlock, s, (const uint32_t *)keys_out, E_cap, N_src_cap,
+             rowptrT);
   GGL_LAUNCH_CHECK();
   return GGL_OK;
 }

@@ -21,6 +21,7 @@ from torch import nn
 
 from . import engine as _engine
 from .dense import Linear, _LinearFn
+from .sampler import Block
 from .mpops import (bspmm, gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
                     unsorted_segment_sum, use_ext)
 
@@ -232,6 +233,13 @@ class SAGEConv(MessagePassing):
     def forward(self, feat, edge):
         src_feat, dst_feat = feat if isinstance(feat, tuple) else (feat, feat)
         num_nodes = int(dst_feat.shape[0])
+        if isinstance(edge, Block):   # a static-shape block of the BlockSampler (graph-capturable step)
+            if self.aggr != 'mean':
+                raise NotImplementedError("sampler Blocks carry the mean aggregator")
+            fused_act = self.act is None or self.act is torch.relu or self.act is torch.nn.functional.relu
+            out = edge.eng.block_mean_epi(self.fc_neigh(src_feat), edge, add=self.fc_self(dst_feat), bias=self.bias,
+                                           relu=fused_act and self.act is not None)
+            return out if fused_act else self.act(out)
         if self.aggr == 'mean':
             src_feat = self.fc_neigh(src_feat)
             fused_act = self.act is None or self.act is torch.relu or self.act is torch.nn.functional.relu
@@ -420,7 +428,7 @@ class GraphSAGESampleModel(nn.Module):
     def forward(self, x, adjs):
         adjs = adjs if isinstance(adjs, (list, tuple)) else [adjs]
         for i, (conv, adj) in enumerate(zip(self.convs, adjs)):
-            x = conv((x, x[: adj.size[1]]), adj.edge_index)
+            x = conv((x, x[: adj.size[1]]), adj if isinstance(adj, Block) else adj.edge_index)
             if i != len(self.convs) - 1:
                 x = self.dropout(x)
         return x

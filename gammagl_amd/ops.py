@@ -903,6 +903,38 @@ class Engine:
                                                                eng._stream(ga.device)))
                 return gx, None, None, None, (ga if ctx.has_add else None), gb, None
 
+        class BlockMeanEpi(torch.autograd.Function):
+            """relu(mean_{j in block row i} x[j] + add_i + bias) over a sampler Block (static capacities,
+            device-side sizes): forward = the rectangular SpMM-mean with the epilogue in its store; backward
+            = the MEANBWD walk of the block's CSC, which is built on the device without a host read."""
+
+            @staticmethod
+            def forward(ctx, x, blk, add, bias, relu):
+                dev = x.device
+                K = int(x.shape[1])
+                if int(x.shape[0]) != blk.n_src_cap:
+                    raise RuntimeError(f"block expects {blk.n_src_cap} source rows, got {x.shape[0]}")
+                y = torch.empty((blk.n_dst_cap, K), dtype=torch.float32, device=dev)
+                b = bias.contiguous().reshape(-1) if bias is not None else None
+                a = add.contiguous() if add is not None else None
+                eng.spmm_epi_into(blk.plan, blk.col, None, x, y, mean=True, add=a, bias=b, relu=relu)
+                ctx.blk, ctx.has_add, ctx.rng_used = blk, add is not None, None
+                ctx.cfg = (blk.n_dst_cap, K, int(relu), 0.0, None if bias is None else bias.shape)
+                ctx.save_for_backward(y)
+                return y
+
+            @staticmethod
+            def backward(ctx, g):
+                (y,) = ctx.saved_tensors
+                ga, gb = _epi_backward(ctx, g, y)
+                gx = None
+                if ctx.needs_input_grad[0]:
+                    blk = ctx.blk
+                    planT, dstT = blk.transposed()
+                    gx, _ = eng._spmm_fwd("mean_bwd", planT, dstT, None, ga, blk.n_src_cap, aux=blk.rowptr)
+                return gx, None, (ga if ctx.has_add else None), gb, None
+
+        self.BlockMeanEpi = BlockMeanEpi
         self.SpMMEpi, self.SegmentEpi = SpMMEpi, SegmentEpi
         self.SpMMSumBiasAct = SpMMSumBiasAct
         self.BiasAct = BiasAct
@@ -1091,6 +1123,12 @@ class Engine:
         if add is not None and tuple(add.shape) != (N, msg.shape[1]):
             raise RuntimeError("add must be [num_segments, feature width]")
         return self.SegmentEpi.apply(msg, ids, N, reduce == "mean", add, bias, bool(relu))
+
+    def block_mean_epi(self, x, blk, add=None, bias=None, relu=False):
+        """SAGEConv(mean) over a sampler Block: relu(mean of the sampled neighbours + add + bias), one kernel."""
+        self._dev(x, add, bias)
+        self._check_f32("x", x)
+        return self.BlockMeanEpi.apply(x.contiguous(), blk, add, bias, bool(relu))
 
     def set_option(self, name, value):
         self._check(self.lib.ggl_set_option(name.encode(), int(value)))

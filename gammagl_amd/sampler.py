@@ -124,4 +124,110 @@ class NeighborSampler:
         return batch, n_id, adjs
 
 
-__all__ = ["sample_adj", "NeighborSampler", "EdgeIndex"]
+class Block:
+    """One sampled hop with FIXED capacities and device-side sizes (ggl_sample_hop): a CSR over `n_dst_cap`
+    destination rows (the hop's seeds, of which counts-of-the-previous-hop are valid; the rest are empty) with
+    LOCAL int32 source ids < n_src_cap, `e_cap` = n_dst_cap * fanout edge slots of which rowptr[n_dst_cap] are
+    used.  `counts` (device int64 [2]) = {nodes in n_id, sampled edges}.  Nothing about a Block needs a host
+    read, so the aggregate over it and its backward capture into a hipGraph."""
+
+    def __init__(self, eng, rowptr, col, e_pos, counts, n_dst_cap, n_src_cap, fanout):
+        from .ops import SegPlan
+
+        self.eng, self.rowptr, self.col, self.e_pos, self.counts = eng, rowptr, col, e_pos, counts
+        self.n_dst_cap, self.n_src_cap, self.fanout = int(n_dst_cap), int(n_src_cap), int(fanout)
+        self.e_cap = int(col.shape[0])
+        self.size = (self.n_src_cap, self.n_dst_cap)           # EdgeIndex.size convention: (sources, targets)
+        p = SegPlan()
+        p.N, p.E, p.rowptr, p.perm, p.is_sorted = self.n_dst_cap, self.e_cap, rowptr, None, True
+        p.max_len, p.chunk, p.n_long, p.n_chunks = self.fanout, 1 << 62, 0, 0
+        p.long_rows = p.chunk_ptr = p.row_order = None
+        p.device, p.uid = rowptr.device, -1
+        self.plan = p
+        self._T = None
+
+    def transposed(self):
+        """(planT, dstT): the block's CSC — for every source row the destination rows of its edges — built on the
+        device without a host read (ggl_block_transpose); hub sources are walked in one piece (no long-row table:
+        its size would have to be read back)."""
+        if self._T is None:
+            from .ops import SegPlan
+
+            eng, dev = self.eng, self.rowptr.device
+            rowptrT = torch.empty(self.n_src_cap + 1, dtype=torch.int64, device=dev)
+            dstT = torch.empty(max(self.e_cap, 1), dtype=torch.int32, device=dev)
+            wsb = eng.lib.ggl_block_transpose_workspace_bytes(self.e_cap, self.n_src_cap)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            eng._check(eng.lib.ggl_block_transpose(_ptr(self.rowptr), _ptr(self.col), self.n_dst_cap, self.n_src_cap,
+                                                   self.e_cap, _ptr(rowptrT), _ptr(dstT), _ptr(ws), wsb,
+                                                   eng._stream(dev)))
+            p = SegPlan()
+            p.N, p.E, p.rowptr, p.perm, p.is_sorted = self.n_src_cap, self.e_cap, rowptrT, None, True
+            p.max_len, p.chunk, p.n_long, p.n_chunks = self.e_cap, 1 << 62, 0, 0
+            p.long_rows = p.chunk_ptr = p.row_order = None
+            p.device, p.uid = dev, -1
+            self._T = (p, dstT)
+        return self._T
+
+
+class BlockSampler:
+    """NeighborSampler with static shapes: `sample(seeds)` runs every hop on the device with fixed-capacity
+    buffers and device-side counts — no host read, ~10 launches per hop — so a training step built on it
+    captures into one hipGraph (trainer.SAGEBlockTrainer).  Same blocks as loader/neighbor_sampler.py:74-109 +
+    sample.cpp:10-135 produce (seeds first and verbatim, new nodes in first-seen order, rows sorted by local id,
+    min(deg, fanout) distinct neighbours per row), padded to capacity."""
+
+    def __init__(self, edge_index, sample_lists, num_nodes=None, eng=None):
+        self.eng = eng or _engine()
+        self.sizes = [int(s) for s in sample_lists]
+        if any(s <= 0 for s in self.sizes):
+            raise ValueError("BlockSampler needs positive fan-outs (use NeighborSampler for full neighbourhoods)")
+        ei = edge_index.contiguous().to(torch.int64)
+        if num_nodes is None:
+            num_nodes = int(ei.max()) + 1
+        self.num_nodes = int(num_nodes)
+        plan = self.eng.seg_plan(ei[1].contiguous(), self.num_nodes)
+        self.rowptr = plan.rowptr
+        self.col = ei[0].contiguous() if plan.perm is None else ei[0][plan.perm.long()].contiguous()
+        self.value = (torch.arange(ei.shape[1], device=ei.device) if plan.perm is None else plan.perm.long())
+        self._first_pos = torch.full((self.num_nodes,), _BIG, dtype=torch.int64, device=ei.device)
+
+    def capacities(self, batch_size):
+        """[(n_dst_cap, n_src_cap, e_cap)] per hop, innermost (the seeds' own block) first."""
+        caps, b = [], int(batch_size)
+        for f in self.sizes:
+            caps.append((b, b + b * f, b * f))
+            b = b + b * f
+        return caps
+
+    def sample(self, seeds, n_seeds=None):
+        """seeds: int64 device tensor [B]; n_seeds: optional device int64 [1] (<= B valid seeds).
+        Returns (n_id [cap], blocks outermost hop first, counts of the outermost hop)."""
+        eng = self.eng
+        dev = self.rowptr.device
+        seeds = seeds.to(device=dev, dtype=torch.int64).contiguous().reshape(-1)
+        if n_seeds is None:
+            n_seeds = torch.full((1,), seeds.shape[0], dtype=torch.int64, device=dev)
+        st = eng._stream(dev)
+        blocks = []
+        cur, n_cur = seeds, n_seeds
+        for f in self.sizes:
+            b_cap = int(cur.shape[0])
+            e_cap = b_cap * f
+            rowptr = torch.empty(b_cap + 1, dtype=torch.int64, device=dev)
+            col = torch.empty(max(e_cap, 1), dtype=torch.int32, device=dev)
+            e_pos = torch.empty(max(e_cap, 1), dtype=torch.int64, device=dev)
+            nid = torch.empty(b_cap + e_cap, dtype=torch.int64, device=dev)
+            counts = torch.empty(2, dtype=torch.int64, device=dev)
+            wsb = eng.lib.ggl_sample_hop_workspace_bytes(b_cap, f)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            eng._check(eng.lib.ggl_sample_hop(_ptr(self.rowptr), _ptr(self.col), _ptr(cur), _ptr(n_cur), b_cap, f,
+                                              _ptr(eng._rng_state(dev)), _ptr(self._first_pos), _ptr(rowptr),
+                                              _ptr(col), _ptr(e_pos), _ptr(nid), _ptr(counts), _ptr(ws), wsb, st))
+            blocks.append(Block(eng, rowptr, col[:e_cap], e_pos[:e_cap], counts, b_cap, b_cap + e_cap, f))
+            blocks[-1].n_id, blocks[-1].seeds, blocks[-1].n_seeds = nid, cur, n_cur   # global ids of its rows
+            cur, n_cur = nid, counts[0:1]
+        return cur, blocks[::-1], blocks[-1].counts
+
+
+__all__ = ["sample_adj", "NeighborSampler", "EdgeIndex", "Block", "BlockSampler"]

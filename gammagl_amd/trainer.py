@@ -95,3 +95,39 @@ class SAGETrainer:
                 o += n
         self.opt.step()
         return loss.detach()
+
+
+class SAGEBlockTrainer:
+    """The same mini-batch GraphSAGE step on the static-shape BlockSampler: sampling, the feature gather, the
+    SAGEConv layers (aggregate + "+ fc_self + bias -> ReLU" in one kernel each), the loss on the seed rows,
+    backward (block CSC built on the device) and Adam run without a single host read — `capture()` records the
+    whole step into one hipGraph that is replayed per batch with the seeds updated in place."""
+
+    def __init__(self, sampler, in_feat, hid_feat, num_class, num_layers=2, drop_rate=0.0, lr=0.005, seed=0,
+                 device="cuda", capturable=None):
+        self.sampler = sampler
+        torch.manual_seed(seed)
+        self.net = GraphSAGESampleModel(in_feat, hid_feat, num_class, drop_rate, num_layers).to(device)
+        cap = torch.device(device).type == "cuda" if capturable is None else capturable
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, capturable=cap)
+        self.graph = None
+
+    def step(self, x, y, seeds):
+        self.net.train()
+        self.opt.zero_grad(set_to_none=False)
+        n_id, blocks, _ = self.sampler.sample(seeds)
+        logits = self.net(x.index_select(0, n_id), blocks)
+        loss = F.cross_entropy(logits[: seeds.shape[0]], y.index_select(0, seeds))
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def capture(self, x, y, seeds, warmup=3):
+        """Record step(x, y, seeds) into a hipGraph.  Afterwards: seeds.copy_(new_batch); trainer.replay()."""
+        for p in self.net.parameters():
+            p.grad = torch.zeros_like(p)
+        self.graph = GraphedStep(lambda: self.step(x, y, seeds), warmup=warmup)
+        return self.graph
+
+    def replay(self):
+        return self.graph()

@@ -352,6 +352,25 @@ int ggl_sample_count(const int64_t *rowptr, const int64_t *seeds, int64_t B, int
 int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const int64_t *seeds, int64_t B,
                     int64_t fanout, int replace, const int64_t *out_rowptr, int64_t *rng_state,
                     int64_t *e_pos, int64_t *nbr, void *stream);
+/* One hop with DEVICE-side sizes and fixed capacities — nothing is read back, so a whole mini-batch step
+ * (sampling, feature gather, layers, loss, backward, optimizer) captures into one hipGraph.
+ *   seeds[B_cap] of which the first *n_seeds_dev are valid; fanout > 0 (min(deg, fanout) distinct neighbours per
+ *   seed, Floyd's algorithm as sample.cpp:75-83); first_pos: int64 scratch of one entry per graph node, every
+ *   entry == 2^62 on entry and again on exit.
+ *   out_rowptr[B_cap + 1] (rows past the valid seeds are empty), out_col[B_cap * fanout] int32 LOCAL ids, each
+ *   row ascending (sample.cpp:112-118), out_eid[B_cap * fanout] CSR positions of the sampled edges (or NULL),
+ *   out_nid[B_cap + B_cap * fanout]: the seeds verbatim, then the new nodes in first-seen order (sample.cpp:24-55),
+ *   zero-padded; out_counts[2] = {nodes in out_nid, sampled edges} (device). */
+size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t fanout);
+int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds, const int64_t *n_seeds_dev,
+                   int64_t B_cap, int64_t fanout, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
+                   int32_t *out_col, int64_t *out_eid, int64_t *out_nid, int64_t *out_counts, void *workspace,
+                   size_t workspace_bytes, void *stream);
+/* CSC of such a block without a host read: rowptrT[N_src_cap + 1], dstT[E_cap] = destination rows of each source
+ * row's block edges (ascending); E_cap entries of col of which rowptr[N_dst] are valid. */
+size_t ggl_block_transpose_workspace_bytes(int64_t E_cap, int64_t N_src_cap);
+int ggl_block_transpose(const int64_t *rowptr, const int32_t *col, int64_t N_dst, int64_t N_src_cap, int64_t E_cap,
+                        int64_t *rowptrT, int32_t *dstT, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tuning knobs (process-wide; also read once from the environment: GGL_UNROLL, GGL_XCD_SWIZZLE,

@@ -1,8 +1,10 @@
 // tests/emul/emul_shim.hpp — minimal host stand-in for the HIP device environment.
 //
-// TEST INFRASTRUCTURE ONLY.  The round-1 kernels use no LDS, no cross-lane shuffles, no barriers
-// and no atomics, so running their bodies one thread at a time on the host executes exactly the
-// same arithmetic in the same order.  tests/emul/build.sh compiles gammagl_amd/csrc/*.hip with
+// TEST INFRASTRUCTURE ONLY.  The kernels compiled here use no LDS, no cross-lane shuffles, no barriers
+// and no order-dependent atomics (the sampler's first-occurrence atomicMin is order-independent), so running
+// their bodies one thread at a time on the host executes exactly the same arithmetic in the same order.
+// Kernels that DO shuffle (the fast GAT path, the wide-head GAT backward) are GPU-build only and are checked
+// by the -m gpu suite alone.  tests/emul/build.sh compiles gammagl_amd/csrc/*.hip with
 // -DGGL_EMULATE into tests/emul/libggl_emul.so so the `-m "not gpu"` suite can check kernel LOGIC
 // (indexing, row splitting, tie-breaking, dtype semantics) in a container that has no GPU.  The
 // product package never loads this library (gammagl_amd/_lib.py loads libggl_mpops_hip.so only
@@ -47,6 +49,9 @@ static inline double __ddiv_rn(double a, double b) { return a / b; }
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 template <typename T> static inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
+
+// order-independent atomics only (min): one host thread at a time, so a plain update is the same result
+static inline long long atomicMin(long long *p, long long v) { const long long o = *p; if (v < o) *p = v; return o; }
 
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };

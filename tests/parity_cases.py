@@ -335,8 +335,23 @@ def _check_gat_separate_buffers(eng, dev, index, N, H, C, rng):
     el, er = (to_t(rng.standard_normal((N, H)).astype(np.float32), dev).requires_grad_(True) for _ in range(2))
     x = to_t(rng.standard_normal((N, H, C)).astype(np.float32), dev).requires_grad_(True)
     go = to_t(rng.standard_normal((N, H, C)).astype(np.float32), dev)
-    y = eng.gat_fused(it, el, er, x, 0.2)
-    y.backward(go)
+    fast_was = eng.gat_fast
+    eng.gat_fast = False        # the Engine on the generic kernels: what the direct C-ABI calls below run
+    try:
+        y = eng.gat_fused(it, el, er, x, 0.2)
+        y.backward(go)
+    finally:
+        eng.gat_fast = fast_was
+    if fast_was and eng.lib.ggl_gat_fast_supported(H, C):
+        # the fast kernels (v_exp_f32, block rescale, FMA, alpha / de recomputed in both backward walks) agree with
+        # the generic ones to the GAT parity bar, forward and all three gradients
+        el2, er2, x2 = (t.detach().clone().requires_grad_(True) for t in (el, er, x))
+        y2 = eng.gat_fused(it, el2, er2, x2, 0.2)
+        y2.backward(go)
+        torch.testing.assert_close(y2.detach(), y.detach(), rtol=1e-5, atol=1e-5)
+        for a, b in ((x2.grad, x.grad), (el2.grad, el.grad), (er2.grad, er.grad)):
+            tol = 1e-4 * float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= tol, (H, C, float((a - b).abs().max()), tol)
     gp = eng.graph_plan(it, N)
     E = gp.E
     st = eng._stream(dev)
@@ -972,3 +987,116 @@ def check_weight_dtype_guard(eng, dev):
                  lambda: eng.spmm(gp, torch.rand(E, K).to(dev), x), lambda: eng.spmm_bias_act(gp, torch.rand(E + 1).to(dev), x)):
         with pytest.raises(RuntimeError):
             call()
+
+
+def check_block_sampler(eng, dev, oracle):
+    """The static-shape sampler (ggl_sample_hop / ggl_block_transpose / BlockMeanEpi): with a fan-out >= the
+    largest degree it IS sample_adj without sampling -> bit-for-bit vs the restated reference (duplicate seeds
+    included); sampled hops through the reference's invariants; padding rows empty; scratch restored; the block
+    aggregate and its backward vs the written-out formula; draws of consecutive calls independent."""
+    from gammagl_amd import sampler
+    from gammagl_amd.layers import GraphSAGESampleModel
+
+    rng = np.random.default_rng(5)
+    N, E = 300, 2400
+    ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
+    ei[1, :64] = 7                                     # one heavy row (deg >= 64)
+    ei = np.unique(ei, axis=1)                         # no multi-edges: distinct positions = distinct neighbours
+    order = np.argsort(ei[1], kind="stable")
+    rowptr = np.concatenate(([0], np.cumsum(np.bincount(ei[1], minlength=N)))).astype(np.int64)
+    col = ei[0][order]
+    deg = np.diff(rowptr)
+    eit = to_t(ei, dev)
+    seeds = np.array([7, 3, 9, 3, 100, 42, 7, 250], np.int64)     # duplicates stay, as in sample.cpp:24-29
+    # (1) fan-out >= max degree: the deterministic branch, bit for bit
+    big = int(deg.max())
+    bs = sampler.BlockSampler(eit, [big], num_nodes=N, eng=eng)
+    n_id, (blk,), counts = bs.sample(to_t(seeds, dev))
+    ref_rp, ref_col, ref_nid, ref_eid = oracle.sample_adj_full(rowptr, col, seeds)
+    nn, ne = (int(v) for v in to_np(counts))
+    assert nn == len(ref_nid) and ne == len(ref_col)
+    assert_same(to_np(blk.rowptr), ref_rp, "block rowptr")
+    assert_same(to_np(blk.col)[:ne].astype(np.int64), ref_col, "block col")
+    assert_same(to_np(n_id)[:nn], ref_nid, "block n_id")
+    assert_same(to_np(blk.e_pos)[:ne], ref_eid, "block e_pos")
+    assert (to_np(n_id)[nn:] == 0).all() and (to_np(blk.col)[ne:] == 0).all()
+    assert bool((bs._first_pos == sampler._BIG).all())            # scratch handed back clean
+    # fewer valid seeds than capacity: the rest of the rows are empty
+    n_id2, (blk2,), c2 = bs.sample(to_t(seeds, dev), n_seeds=torch.tensor([3], device=dev))
+    r2 = oracle.sample_adj_full(rowptr, col, seeds[:3])
+    assert int(c2[0]) == len(r2[2]) and int(c2[1]) == len(r2[1])
+    assert_same(to_np(blk2.rowptr)[:4], r2[0], "short rowptr") and None
+    assert (to_np(blk2.rowptr)[3:] == r2[0][-1]).all()
+    assert_same(to_np(n_id2)[: len(r2[2])], r2[2], "short n_id")
+    # (2) sampled hops: invariants of sample.cpp (min(deg, fanout) distinct neighbours, rows sorted, seeds first)
+    bs = sampler.BlockSampler(eit, [5, 3], num_nodes=N, eng=eng)
+    sd = np.concatenate(([7], rng.permutation(N)[:15])).astype(np.int64)
+    sd = sd[np.sort(np.unique(sd, return_index=True)[1])]
+    n_id, blocks, counts = bs.sample(to_t(sd, dev))
+    assert [b.fanout for b in blocks] == [3, 5] and blocks[1].n_dst_cap == len(sd)
+    assert blocks[0].n_dst_cap == blocks[1].n_src_cap and n_id.shape[0] == blocks[0].n_src_cap
+    for blk in blocks[::-1]:                                      # innermost first, as sampled
+        nn, ne = (int(v) for v in to_np(blk.counts))
+        nv = int(to_np(blk.n_seeds)[0])
+        rp, cl, ep = to_np(blk.rowptr), to_np(blk.col).astype(np.int64), to_np(blk.e_pos)
+        hop_seeds, hop_nid = to_np(blk.seeds), to_np(blk.n_id)
+        k = np.diff(rp)
+        assert (k[:nv] == np.minimum(deg[hop_seeds[:nv]], blk.fanout)).all() and (k[nv:] == 0).all() and rp[-1] == ne
+        assert (hop_nid[:nv] == hop_seeds[:nv]).all() and len(np.unique(hop_nid[:nn])) == nn and (hop_nid[nn:] == 0).all()
+        assert (cl[:ne] < nn).all() and (hop_nid[cl[:ne]] == col[ep[:ne]]).all()
+        for i in range(nv):
+            s0 = int(hop_seeds[i])
+            pos = ep[rp[i]:rp[i + 1]]
+            assert ((pos >= rowptr[s0]) & (pos < rowptr[s0 + 1])).all() and len(np.unique(pos)) == len(pos)
+            assert (np.diff(cl[rp[i]:rp[i + 1]]) > 0).all()
+    assert blocks[0].seeds is blocks[1].n_id and torch.equal(blocks[0].n_id, n_id)
+    assert int(to_np(blocks[0].n_seeds)[0]) == int(to_np(blocks[1].counts)[0])
+    assert bool((bs._first_pos == sampler._BIG).all())
+    # (3) the block aggregate + fused epilogue and its backward (device-built CSC) vs the formula
+    bs = sampler.BlockSampler(eit, [6], num_nodes=N, eng=eng)
+    n_id, (blk,), counts = bs.sample(to_t(sd, dev))
+    nn, ne = (int(v) for v in to_np(counts))
+    K = 8
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(blk.n_src_cap, K, generator=g).to(dev).requires_grad_(True)
+    add = torch.randn(blk.n_dst_cap, K, generator=g).to(dev).requires_grad_(True)
+    bias = torch.randn(1, K, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(blk.n_dst_cap, K, generator=g).to(dev)
+    y = eng.block_mean_epi(xs, blk, add=add, bias=bias, relu=True)
+    y.backward(go)
+    rp, cl = blk.rowptr, blk.col[:ne].long()
+    rows = torch.repeat_interleave(torch.arange(blk.n_dst_cap, device=dev), rp[1:] - rp[:-1])
+    xr, ar, br = (t.detach().clone().requires_grad_(True) for t in (xs, add, bias))
+    cnt = (rp[1:] - rp[:-1]).clamp(min=1).unsqueeze(1).float()
+    ref = torch.relu(torch.zeros(blk.n_dst_cap, K, device=dev).index_add_(0, rows, xr[cl]) / cnt + ar + br)
+    ref.backward(go)
+    torch.testing.assert_close(y.detach(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xs.grad, xr.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(add.grad, ar.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bias.grad, br.grad, rtol=1e-5, atol=1e-5)
+    planT, dstT = blk.transposed()
+    rpT = to_np(planT.rowptr)
+    cln = to_np(cl)
+    assert rpT[-1] == ne and (np.diff(rpT) == np.bincount(cln, minlength=blk.n_src_cap)).all()
+    o = np.argsort(cln, kind="stable")
+    assert (to_np(dstT)[:ne] == to_np(rows)[o]).all()
+    # (4) consecutive calls draw independently (fan-out 4 of 64+ neighbours: ~4 * 4 / deg shared picks expected)
+    bs = sampler.BlockSampler(eit, [4], num_nodes=N, eng=eng)
+    s7 = torch.full((1500,), 7, dtype=torch.int64, device=dev)
+    _, (b1,), _ = bs.sample(s7)
+    _, (b2,), _ = bs.sample(s7)
+    p1, p2 = to_np(b1.e_pos).reshape(1500, 4), to_np(b2.e_pos).reshape(1500, 4)
+    shared = np.mean([len(set(a) & set(b)) for a, b in zip(p1, p2)])
+    identical = sum(set(a) == set(b) for a, b in zip(p1, p2))
+    assert shared < 0.5 and identical <= 3, (shared, identical)       # 0.25 expected; the XOR layout gave 1.55 / 57
+    cnt7 = np.bincount(p1.reshape(-1) - rowptr[7], minlength=deg[7])
+    assert np.abs(cnt7 - 6000 / deg[7]).max() < 6 * np.sqrt(6000 / deg[7])
+    # (5) the model runs on blocks end to end (shapes by capacity, loss on the seed rows)
+    bs = sampler.BlockSampler(eit, [5, 3], num_nodes=N, eng=eng)
+    n_id, blocks, _ = bs.sample(to_t(sd, dev))
+    net = GraphSAGESampleModel(10, 8, 4, 0.0, 2).to(dev)
+    xall = torch.randn(N, 10, generator=g).to(dev)
+    out = net(xall.index_select(0, n_id), blocks)
+    assert out.shape == (blocks[1].n_dst_cap, 4) and bool(torch.isfinite(out).all())
+    out[: len(sd)].sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())

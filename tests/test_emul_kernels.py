@@ -129,3 +129,7 @@ def test_epilogue_forms_sage_and_column_blocks(eng):
 
 def test_weight_dtype_guard(eng):
     pc.check_weight_dtype_guard(eng, DEV)
+
+
+def test_static_shape_block_sampler(eng, oracle):
+    pc.check_block_sampler(eng, DEV, oracle)
