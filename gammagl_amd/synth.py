@@ -224,7 +224,7 @@ def bounds_from_degree(deg, world):
 
 
 def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, group=None, device="cpu",
-                     relabel="random", order="src", parts=None, stats=None):
+                     relabel="random", order="src", parts=None, stats=None, buckets=None, slab=1 << 27):
     """This rank's share of the R-MAT graph with `num_nodes` nodes and exactly `num_directed_edges`
     directed edges (symmetrised, de-duplicated) + one self-loop per node, for a 1-D partition into `parts`
     (default: `world`) contiguous node ranges balanced by in-edge count.
@@ -233,89 +233,150 @@ def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, gro
     deg^-1/2[src] * deg^-1/2[dst], degrees counted on the looped edge list like calc_gcn_norm) of the
     edges whose destination this rank owns; bounds [parts+1]; e_global (Python int, may exceed 2^31);
     deg (global in-degree incl. the loop, float32 [N]).  With world == 1 and parts == P > 1 the process
-    plays rank `rank` of a P-way partition from the globally built graph (single-GPU share probes)."""
+    plays rank `rank` of a P-way partition (single-GPU share probes, dry partitions).
+
+    Memory: candidates are generated in slabs of `slab` stream positions, and the directed edges a process
+    holds are kept in `buckets` hash buckets (1 per rank in a distributed run; with world == 1 as many as
+    keeps a bucket under 2^29 keys), so no sort / unique ever runs on more than a bucket — a single GPU can
+    build the papers100M-sized graph (3.2 G edges) piecewise to cut one rank's share out of it."""
     dev = torch.device(device)
     N, P = int(num_nodes), int(world)
     parts = int(parts or world)
     comm = _Comm(rank if P > 1 else 0, P, group)   # (world == 1, parts > 1: `rank` only picks the share played)
     T = int(num_directed_edges) // 2
+    if buckets is None:
+        buckets = 1 if P > 1 else max(1, -(-int(2.6 * T) // (1 << 29)))
+    nb = int(buckets)
     scale = max(1, math.ceil(math.log2(max(N, 2))))
     peak = 0
     pi = None
     if relabel == "random":
         # the same permutation on every rank (CPU generator: identical whatever the device)
         pi = torch.randperm(N, generator=torch.Generator().manual_seed(seed + 1)).to(dev)
-    keys = torch.empty(0, dtype=torch.int64, device=dev)    # directed edges held here: dst * N + src
+    # directed edges held here, as keys dst * N + src, in nb hash buckets of the destination (every copy of a
+    # directed edge meets in one bucket of one rank, so the de-duplication there is complete; hashing keeps
+    # the provisional load balanced whatever the node order)
+    keys = [torch.empty(0, dtype=torch.int64, device=dev) for _ in range(nb)]
+
+    def bucket_id(dk):
+        return _lsr(mix64(dk // N), 33) % (P * nb)
+
     U, base, rounds = 0, 0, 0
     while U < T:
         m = int((T - U) * 1.5) + 1024                        # candidates this round, over all ranks
         i0, i1 = base + m * comm.rank // P, base + m * (comm.rank + 1) // P
-        idx = torch.arange(i0, i1, dtype=torch.int64, device=dev)
-        u, v = rmat_pairs_ctr(scale, idx, seed)
-        del idx
-        ok = (u < N) & (v < N) & (u != v)
-        u, v = u[ok], v[ok]
-        if pi is not None:
-            u, v = pi[u], pi[v]
-        dkey = torch.cat([v * N + u, u * N + v])             # both directions of every pair
-        del u, v, ok
-        # provisional owner = hash of the destination: balanced whatever the node order, and every copy
-        # of a directed edge meets at one rank, so the de-duplication there is complete
-        owner = (_lsr(mix64(dkey // N), 33) % P) if P > 1 else None
-        recv = comm.route(dkey, owner)
-        peak = max(peak, int(dkey.numel()), int(recv.numel()) + int(keys.numel()))
-        del dkey, owner
-        keys = torch.unique(torch.cat([keys, recv]))
-        del recv
-        cnt = ((keys % N) < (keys // N)).sum().reshape(1)    # canonical (src < dst) copies = undirected pairs
+        pending = [[] for _ in range(nb)]
+        for s0 in range(i0, max(i1, i0 + 1), slab):
+            idx = torch.arange(s0, min(s0 + slab, i1), dtype=torch.int64, device=dev)
+            u, v = rmat_pairs_ctr(scale, idx, seed)
+            del idx
+            ok = (u < N) & (v < N) & (u != v)
+            u, v = u[ok], v[ok]
+            if pi is not None:
+                u, v = pi[u], pi[v]
+            dkey = torch.cat([v * N + u, u * N + v])         # both directions of every pair
+            del u, v, ok
+            if P > 1:
+                recv = comm.route(dkey, bucket_id(dkey) // nb)
+                peak = max(peak, int(dkey.numel()) + int(recv.numel()))
+                dkey = recv
+            if nb == 1:
+                pending[0].append(dkey)
+            else:
+                b = bucket_id(dkey) % nb
+                o = torch.argsort(b)
+                dkey, cnt = dkey[o], torch.bincount(b, minlength=nb).tolist()
+                del b, o
+                for j, piece in enumerate(torch.split(dkey, cnt)):
+                    pending[j].append(piece.clone())
+            del dkey
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        for j in range(nb):
+            keys[j] = torch.unique(torch.cat([keys[j]] + pending[j]))
+            pending[j] = None
+            cnt += ((keys[j] % N) < (keys[j] // N)).sum()    # canonical (src < dst) copies = undirected pairs
+        peak = max(peak, sum(int(k.numel()) for k in keys))
         U = int(comm.all_reduce(cnt))
         base += m
         rounds += 1
         if rounds > 64:
             raise RuntimeError("R-MAT generator cannot reach the requested edge count")
-    src, dst = keys % N, keys // N
-    del keys
+    salt = _s64(_mix64_int(seed + 0x51ED27))
+
+    def pair_hash(k):
+        sr, ds = k % N, k // N
+        return mix64((torch.minimum(sr, ds) * N + torch.maximum(sr, ds)) ^ salt)
+
     if U > T:
         # keep the T pairs with the smallest hash of their canonical key (signed order; mix64 is a
         # bijection, so there are no ties): a selection that does not depend on who holds what
-        lo, hi = torch.minimum(src, dst), torch.maximum(src, dst)
-        h = mix64((lo * N + hi) ^ _s64(_mix64_int(seed + 0x51ED27)))
-        del lo, hi
-        canon = src < dst
-        bucket = (h >> 44) + (1 << 19)                        # top 20 bits, 0 .. 2^20 - 1
-        hist = comm.all_reduce(torch.bincount(bucket[canon], minlength=1 << 20))
+        hist = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+        for k in keys:
+            h = pair_hash(k)
+            hist += torch.bincount(((h >> 44) + (1 << 19))[(k % N) < (k // N)], minlength=1 << 20)
+        hist = comm.all_reduce(hist)
         cum = torch.cumsum(hist, 0)
         b = int(torch.searchsorted(cum, torch.tensor([T], device=dev, dtype=cum.dtype)))
         below = int(cum[b - 1]) if b > 0 else 0
-        cand = comm.all_gather_var(h[canon & (bucket == b)])
+        cand = []
+        for k in keys:
+            h = pair_hash(k)
+            cand.append(h[((k % N) < (k // N)) & (((h >> 44) + (1 << 19)) == b)])
+        cand = comm.all_gather_var(torch.cat(cand))
         thr = torch.sort(cand).values[T - below - 1]
-        keep = h <= thr
-        src, dst = src[keep], dst[keep]
-        del h, canon, bucket, keep
+        keys = [k[pair_hash(k) <= thr] for k in keys]
     # global in-degree (the graph is symmetric: also the out-degree), without the loops yet
-    deg = comm.all_reduce(torch.bincount(dst, minlength=N))
+    deg = torch.zeros(N, dtype=torch.int64, device=dev)
+    for k in keys:
+        deg += torch.bincount(k // N, minlength=N)
+    deg = comm.all_reduce(deg)
+    rk = None
     if relabel == "degree":   # hubs first: the locality-friendly ordering
         rk = torch.empty(N, dtype=torch.int64, device=dev)
         o = torch.argsort(deg, descending=True, stable=True)
         rk[o] = torch.arange(N, device=dev)
-        src, dst, deg = rk[src], rk[dst], deg[o]
-        del rk, o
+        deg = deg[o]
+        del o
     deg = deg + 1                                             # add_self_loops: one loop per node
     bounds = bounds_from_degree(deg, parts)
     bt = torch.tensor(bounds[1:-1], device=dev, dtype=torch.int64)
-    own = torch.searchsorted(bt, dst, right=True) if parts > 1 else torch.zeros_like(dst)
-    if P > 1:
-        got = comm.route(torch.stack([src, dst], 1), own)
-        peak = max(peak, int(src.numel()) + int(got.shape[0]))
-        src, dst = got[:, 0].contiguous(), got[:, 1].contiguous()
-        del got
-        me = comm.rank
-    else:
-        me = int(rank)                                        # play one rank of a `parts`-way partition
-        mine = own == me
-        src_all, dst_all, own_all = src, dst, own
-        src, dst = src[mine], dst[mine]
+    me = comm.rank if P > 1 else int(rank)
     lo_n, hi_n = bounds[me], bounds[me + 1]
+    e_total = sum(int(k.numel()) for k in keys)
+    srcs, dsts, send = [], [], None
+    dry = P == 1 and parts > 1
+    if dry:
+        send = [[] for _ in range(parts)]
+    for j in range(nb):
+        k = keys[j]
+        keys[j] = None
+        sr, ds = k % N, k // N
+        del k
+        if rk is not None:
+            sr, ds = rk[sr], rk[ds]
+        if P > 1:
+            own = torch.searchsorted(bt, ds, right=True)
+            got = comm.route(torch.stack([sr, ds], 1), own)
+            peak = max(peak, int(sr.numel()) + int(got.shape[0]))
+            srcs.append(got[:, 0].contiguous())
+            dsts.append(got[:, 1].contiguous())
+            del got, own
+        else:
+            mine = (ds >= lo_n) & (ds < hi_n)
+            srcs.append(sr[mine])
+            dsts.append(ds[mine])
+            if dry:   # which of my rows the other parts need (what they would request in a real P-rank run)
+                out = (sr >= lo_n) & (sr < hi_n) & ~mine
+                own = torch.searchsorted(bt, ds[out], right=True)
+                so = sr[out]
+                for q in range(parts):
+                    if q != me:
+                        send[q].append(torch.unique(so[own == q]))
+                del out, own, so
+            del mine
+        del sr, ds
+    src, dst = torch.cat(srcs), torch.cat(dsts)
+    del srcs, dsts
     key = (src * N + dst) if order == "src" else (dst * N + src)
     o = torch.argsort(key)
     src, dst = src[o], dst[o]
@@ -330,17 +391,10 @@ def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, gro
     if P > 1 or parts == 1:
         out["e_global"] = int(comm.all_reduce(e_loc))
     else:
-        out["e_global"] = int(src_all.numel()) + N
-        # which of my rows the other parts need (what they would request in a real P-rank run), per peer
-        send = []
-        for q in range(parts):
-            if q == me:
-                send.append(torch.empty(0, dtype=torch.int64, device=dev))
-                continue
-            sq = src_all[(own_all == q) & (src_all >= lo_n) & (src_all < hi_n)]
-            send.append(torch.unique(sq) - lo_n)
-        out["send_rows"] = send
+        out["e_global"] = e_total + N
+        out["send_rows"] = [(torch.unique(torch.cat(t)) - lo_n) if t else torch.empty(0, dtype=torch.int64, device=dev)
+                            for t in send]
     peak = max(peak, int(src.numel()))
     if stats is not None:
-        stats.update(peak_edges=peak, rounds=rounds, local_edges=int(src.numel()))
+        stats.update(peak_edges=peak, rounds=rounds, local_edges=int(src.numel()), buckets=nb)
     return out
