@@ -8,19 +8,20 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gammagl_amd import engine  # noqa: E402
-from gammagl_amd.layers import calc_gcn_norm  # noqa: E402
-from gammagl_amd.synth import DATASETS, rmat_graph  # noqa: E402
+from gammagl_amd.synth import DATASETS, rmat_partitioned  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "products"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device("cuda", 0)
 eng = engine()
 n, e, _, _ = DATASETS[wl]
-ei = rmat_graph(n, e, seed=0, device=dev)
-w = calc_gcn_norm(ei, n).contiguous()
+g = rmat_partitioned(n, e, seed=0, device=dev)          # the bench's own graph (bench.py defaults)
+ei = torch.stack([g["src"], g["dst"]])
+w = g["w"]
 gp = eng.graph_plan(ei, n)
 x = torch.randn(n, K, device=dev)
 torch.cuda.synchronize()
+eng._sorted_weights(gp.fwd, w)
 for _ in range(4):
     eng._spmm_fwd("sum", gp.fwd, gp.col, w, x, n)
 torch.cuda.synchronize()
