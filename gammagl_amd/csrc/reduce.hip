@@ -208,22 +208,37 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
 #pragma unroll
     for (int u = 0; u < U; ++u) accumulate(raw[u], xrow[u], wv[u], who[u]);
   }
-  // the last end - p < U elements as ONE partial batch: their loads are issued together and consumed in order
-  // (a row of 7 used to pay 1 + 3 dependent round trips — its tail walked one element at a time; with
-  // average degrees of 10-50 and sampled blocks of 10 / 25 edges per row most of a row IS tail)
+  // the remaining end - p < U elements: whole batches of 4 first (the narrow kernels walk with U = 16; measured:
+  // a 15-way predicated tail costs them 14 %), then ONE partial batch of <= 3 whose loads are issued together
+  // and consumed in order (a row of 7 used to pay 1 + 3 dependent round trips — its tail walked one element at
+  // a time; with average degrees of 10-50 and sampled blocks of 10 / 25 edges per row most of a row IS tail)
+  constexpr int TB = U > 4 ? 4 : U;
+  if (U > 4) {
+    for (; p + TB <= end; p += TB) {
+      int64_t xrow[TB], who[TB];
+      float wv[TB];
+      S raw[TB][VEC];
+#pragma unroll
+      for (int u = 0; u < TB; ++u) element(p + u, xrow[u], wv[u], who[u]);
+#pragma unroll
+      for (int u = 0; u < TB; ++u) VecIO<S, VEC>::load(q.x + xrow[u] * d.x_ld + kk, raw[u]);
+#pragma unroll
+      for (int u = 0; u < TB; ++u) accumulate(raw[u], xrow[u], wv[u], who[u]);
+    }
+  }
   const int rem = (int)(end - p);
   if (rem > 0) {
-    int64_t xrow[U], who[U];
-    float wv[U];
-    S raw[U][VEC];
+    int64_t xrow[TB], who[TB];
+    float wv[TB];
+    S raw[TB][VEC];
 #pragma unroll
-    for (int u = 0; u < U - 1; ++u)
+    for (int u = 0; u < TB - 1; ++u)
       if (u < rem) element(p + u, xrow[u], wv[u], who[u]);
 #pragma unroll
-    for (int u = 0; u < U - 1; ++u)
+    for (int u = 0; u < TB - 1; ++u)
       if (u < rem) VecIO<S, VEC>::load(q.x + xrow[u] * d.x_ld + kk, raw[u]);
 #pragma unroll
-    for (int u = 0; u < U - 1; ++u)
+    for (int u = 0; u < TB - 1; ++u)
       if (u < rem) accumulate(raw[u], xrow[u], wv[u], who[u]);
   }
 }

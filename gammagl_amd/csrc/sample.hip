@@ -241,17 +241,20 @@ __global__ __launch_bounds__(kBlock) void hop_emit_kernel(const int64_t *__restr
                                                           const long long *__restrict__ first_pos,
                                                           const int64_t *__restrict__ flag,
                                                           const int64_t *__restrict__ new_id,
-                                                          int64_t *__restrict__ out_nid, int64_t *__restrict__ local,
+                                                          int64_t S_cap, int64_t *__restrict__ out_nid,
+                                                          int64_t *__restrict__ local,
                                                           int64_t *__restrict__ counts) {
   const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
   const int64_t ne = out_rowptr[B_cap];
-  const int64_t n_nodes = new_id[B_cap + E_cap];
+  const int64_t n_all = new_id[B_cap + E_cap];
+  const int64_t n_nodes = n_all < S_cap ? n_all : S_cap;   // S_cap >= B_cap: the seeds always fit
   const int64_t stride = grid_threads();
   if (thread_id() == 0) {
     counts[0] = n_nodes;
     counts[1] = ne;
+    if (n_all > S_cap) counts[2] = 1;  // more nodes met than the caller's capacity: the block is truncated
   }
-  for (int64_t t = thread_id(); t < B_cap + E_cap; t += stride) {
+  for (int64_t t = thread_id(); t < S_cap; t += stride) {
     if (t >= n_nodes) out_nid[t] = 0;  // padding rows gather node 0 (any valid row: nothing reads them)
   }
   for (int64_t t = thread_id(); t < B_cap + E_cap; t += stride) {
@@ -261,14 +264,28 @@ __global__ __launch_bounds__(kBlock) void hop_emit_kernel(const int64_t *__restr
       const int64_t q = t - B_cap;
       if (q < ne) {
         const int64_t node = nbr[q];
-        if (flag[t]) out_nid[new_id[t]] = node;
+        if (flag[t] && new_id[t] < S_cap) out_nid[new_id[t]] = node;
         const long long key = first_pos[node];
-        local[q] = key < 0 ? (int64_t)(-key - 1) : new_id[key];  // a seed keeps its own (last) position
+        const int64_t l = key < 0 ? (int64_t)(-key - 1) : new_id[key];  // a seed keeps its own (last) position
+        local[q] = l < S_cap ? l : S_cap - 1;  // (only on overflow, which the caller must check)
       } else {
         local[q] = 0;
       }
     }
   }
+}
+
+// after the scan: rows that would run past the edge capacity are cut (and the overflow flag raised)
+__global__ __launch_bounds__(kBlock) void hop_clamp_kernel(int64_t *__restrict__ out_rowptr, int64_t B_cap,
+                                                           int64_t E_cap, int64_t *__restrict__ counts) {
+  const int64_t stride = grid_threads();
+  const bool over = out_rowptr[B_cap] > E_cap;  // (read before any thread of this launch clamps it: see below)
+  for (int64_t i = thread_id(); i < B_cap; i += stride)
+    if (out_rowptr[i] > E_cap) out_rowptr[i] = E_cap;
+  if (thread_id() == 0) counts[2] = over ? 1 : 0;
+}
+__global__ void hop_clamp_last_kernel(int64_t *__restrict__ out_rowptr, int64_t B_cap, int64_t E_cap) {
+  if (block_id() == 0 && threadIdx.x == 0 && out_rowptr[B_cap] > E_cap) out_rowptr[B_cap] = E_cap;
 }
 // (out_nid is written by two loops of the same launch: a padding slot j >= n_nodes is never a new_id target,
 //  so the two never touch the same element)
@@ -427,9 +444,9 @@ extern "C" int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const 
 }
 
 // ---- static-shape hop -------------------------------------------------------------------------------
-extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t fanout) {
-  if (B_cap < 0 || fanout <= 0) return 0;
-  const int64_t E_cap = B_cap * fanout, T = B_cap + E_cap + 1;
+extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t E_cap) {
+  if (B_cap < 0 || E_cap < 0) return 0;
+  const int64_t T = B_cap + E_cap + 1;
   size_t b = up256((size_t)(B_cap + 1) * 8);          // cnt
   b += 3 * up256((size_t)(E_cap > 0 ? E_cap : 1) * 8);  // e_pos, nbr, local
   b += 2 * up256((size_t)T * 8);                      // flag, new_id
@@ -440,19 +457,21 @@ extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t fanout) 
 }
 
 extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds,
-                              const int64_t *n_seeds_dev, int64_t B_cap, int64_t fanout, int64_t *rng_state,
-                              int64_t *first_pos, int64_t *out_rowptr, int32_t *out_col, int64_t *out_eid,
-                              int64_t *out_nid, int64_t *out_counts, void *workspace, size_t workspace_bytes,
-                              void *stream) {
+                              const int64_t *n_seeds_dev, int64_t B_cap, int64_t fanout, int64_t E_cap,
+                              int64_t S_cap, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
+                              int32_t *out_col, int64_t *out_eid, int64_t *out_nid, int64_t *out_counts,
+                              void *workspace, size_t workspace_bytes, void *stream) {
   GGL_REQUIRE(B_cap >= 0 && fanout > 0, GGL_EINVAL, "the static-shape hop needs a positive fan-out");
-  GGL_REQUIRE(B_cap < ((int64_t)1 << 31) && B_cap * fanout < ((int64_t)1 << 31), GGL_EINVAL, "block too large");
+  GGL_REQUIRE(E_cap > 0 && E_cap <= B_cap * fanout && S_cap >= B_cap && S_cap <= B_cap + E_cap, GGL_EINVAL,
+              "capacities: 0 < E_cap <= B_cap * fanout, B_cap <= S_cap <= B_cap + E_cap");
+  GGL_REQUIRE(B_cap < ((int64_t)1 << 31) && E_cap < ((int64_t)1 << 31), GGL_EINVAL, "block too large");
   if (B_cap == 0) return GGL_OK;
   GGL_REQUIRE(rowptr && seeds && n_seeds_dev && rng_state && first_pos && out_rowptr && out_col && out_nid &&
                   out_counts, GGL_EINVAL, "NULL pointer");
-  GGL_REQUIRE(workspace && workspace_bytes >= ggl_sample_hop_workspace_bytes(B_cap, fanout), GGL_EWORKSPACE,
+  GGL_REQUIRE(workspace && workspace_bytes >= ggl_sample_hop_workspace_bytes(B_cap, E_cap), GGL_EWORKSPACE,
               "sample_hop workspace too small");
   hipStream_t s = as_stream(stream);
-  const int64_t E_cap = B_cap * fanout, T = B_cap + E_cap + 1;
+  const int64_t T = B_cap + E_cap + 1;
   char *ws = static_cast<char *>(workspace);
   size_t off = 0;
   int64_t *cnt = reinterpret_cast<int64_t *>(ws + off); off += up256((size_t)(B_cap + 1) * 8);
@@ -468,6 +487,10 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   GGL_LAUNCH_CHECK();
   int rc = scan_i64(tmp, tmp_bytes, cnt, out_rowptr, B_cap + 1, s);
   if (rc) return rc;
+  GGL_LAUNCH((hop_clamp_kernel), grid_for(B_cap), kBlock, s, out_rowptr, B_cap, E_cap, out_counts);
+  GGL_LAUNCH_CHECK();
+  GGL_LAUNCH((hop_clamp_last_kernel), 1, 64, s, out_rowptr, B_cap, E_cap);
+  GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_pick_kernel), grid_for(B_cap), kBlock, s, rowptr, col, seeds, n_seeds_dev, B_cap, fanout,
              (const int64_t *)out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
   GGL_LAUNCH_CHECK();
@@ -481,7 +504,7 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   if (rc) return rc;
   GGL_LAUNCH((hop_emit_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, E_cap,
              (const int64_t *)nbr, (const int64_t *)out_rowptr, (const long long *)fp, (const int64_t *)flag,
-             (const int64_t *)new_id, out_nid, local, out_counts);
+             (const int64_t *)new_id, S_cap, out_nid, local, out_counts);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_reset_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
              (const int64_t *)out_rowptr, fp);

@@ -109,11 +109,20 @@ class GraphPlan:
 
 
 class _PlanCache:
-    """LRU keyed on the identity of the id tensor's storage + its version counter."""
+    """LRU keyed on the identity of the id tensor's storage + its version counter, bounded by entry count AND
+    by the bytes its plans hold (a products-sized GraphPlan is ~2.5 GB of HBM: a caller that builds a fresh
+    edge_index every epoch must not accumulate 16 of them).  An entry dies with its id tensor's storage.
 
-    def __init__(self, cap=16):
+    Identity + version cannot see a mutation made behind autograd's back (`.data`, numpy-shared memory): set
+    GGL_VERIFY_PLANS=1 to keep a (first, last, sum) checksum of the ids with every plan and verify it on each
+    hit (one device reduction + a host read per call: a debugging aid, off by default)."""
+
+    def __init__(self, cap=16, max_bytes=None):
         self.cap = cap
+        self.max_bytes = int(float(os.environ.get("GGL_PLAN_CACHE_GB", "48")) * 2**30) if max_bytes is None else max_bytes
         self.d = OrderedDict()
+        self.bytes = 0
+        self.verify = os.environ.get("GGL_VERIFY_PLANS", "0") == "1"
 
     @staticmethod
     def key(t, extra):
@@ -121,25 +130,67 @@ class _PlanCache:
         return (st._cdata, t.storage_offset(), tuple(t.shape), tuple(t.stride()), t._version,
                 t.dtype, str(t.device)) + tuple(extra)
 
+    @staticmethod
+    def _checksum(t):
+        if t.numel() == 0:
+            return (0, 0, 0)
+        f = t.reshape(-1)
+        return (int(f[0]), int(f[-1]), int(f.sum()))
+
+    @staticmethod
+    def _nbytes(val):
+        """HBM held by a cached value (SegPlan / GraphPlan / tensor), for the byte bound."""
+        seen, total = set(), 0
+
+        def visit(o, depth=0):
+            nonlocal total
+            if isinstance(o, torch.Tensor):
+                k = o.untyped_storage()._cdata
+                if k not in seen:
+                    seen.add(k)
+                    total += o.untyped_storage().nbytes()
+            elif depth < 3 and hasattr(o, "__slots__"):
+                for a in o.__slots__:
+                    if a not in ("engine", "index"):      # (the caller's own edge_index is not ours to count)
+                        visit(getattr(o, a, None), depth + 1)
+            elif depth < 3 and isinstance(o, dict):
+                for v in o.values():
+                    visit(v, depth + 1)
+
+        visit(val)
+        return total
+
     def get(self, t, extra):
         k = self.key(t, extra)
         hit = self.d.get(k)
         if hit is not None:
-            ref, val = hit
+            ref, val, nb, chk = hit
             if not ref.expired():
+                if chk is not None and chk != self._checksum(t):
+                    raise RuntimeError("gammagl_amd: an id tensor was modified in place behind its version counter "
+                                       "(.data / shared memory) after its plan was cached; call "
+                                       "Engine.clear_caches() after such edits")
                 self.d.move_to_end(k)
                 return val
+            self.bytes -= nb
             del self.d[k]
         return None
 
     def put(self, t, extra, val):
         k = self.key(t, extra)
-        self.d[k] = (StorageWeakRef(t.untyped_storage()), val)
-        while len(self.d) > self.cap:
-            self.d.popitem(last=False)
+        old = self.d.pop(k, None)
+        if old is not None:
+            self.bytes -= old[2]
+        nb = self._nbytes(val)
+        self.d[k] = (StorageWeakRef(t.untyped_storage()), val, nb, self._checksum(t) if self.verify else None)
+        self.bytes += nb
+        while len(self.d) > 1 and (len(self.d) > self.cap or self.bytes > self.max_bytes):
+            _, (_, _, onb, _) = self.d.popitem(last=False)
+            self.bytes -= onb
 
     def clear(self):
         self.d.clear()
+        self.bytes = 0
 
 
 class Engine:
@@ -154,6 +205,14 @@ class Engine:
         self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk; 0 = auto_chunk(E)
         self.gat_fast = True        # fused GAT: the low-VALU kernels where the head shape allows (GPU build only)
         self._make_functions()
+
+    def clear_caches(self):
+        """Drop every cached plan, sorted-weight copy and graph-constant (e.g. GCN norms).  Plans are keyed on
+        the identity + version counter of the id tensor: call this after editing an edge list through `.data`
+        or memory shared with numpy, or to hand the HBM back."""
+        self.seg_cache.clear()
+        self.graph_cache.clear()
+        self.w_cache.clear()
 
     # ---- plumbing ----------------------------------------------------------------------------
     def _check(self, rc):

@@ -191,17 +191,47 @@ class BlockSampler:
         self.col = ei[0].contiguous() if plan.perm is None else ei[0][plan.perm.long()].contiguous()
         self.value = (torch.arange(ei.shape[1], device=ei.device) if plan.perm is None else plan.perm.long())
         self._first_pos = torch.full((self.num_nodes,), _BIG, dtype=torch.int64, device=ei.device)
+        self._overflow = torch.zeros((), dtype=torch.int64, device=ei.device)
 
     def capacities(self, batch_size):
-        """[(n_dst_cap, n_src_cap, e_cap)] per hop, innermost (the seeds' own block) first."""
+        """Worst-case [(n_src_cap, e_cap)] per hop, innermost (the seeds' own block) first."""
         caps, b = [], int(batch_size)
         for f in self.sizes:
-            caps.append((b, b + b * f, b * f))
+            caps.append((b + b * f, b * f))
             b = b + b * f
         return caps
 
-    def sample(self, seeds, n_seeds=None):
-        """seeds: int64 device tensor [B]; n_seeds: optional device int64 [1] (<= B valid seeds).
+    def calibrate(self, batch_size, trials=8, slack=1.25, seed=0):
+        """Capacities from measured batches: `trials` random batches at worst-case capacity, then
+        slack x the largest counts seen, rounded up to 256 (the worst case — every seed with `fanout`
+        distinct, previously unseen neighbours — is several times what a power-law graph produces, and every
+        dense layer would run on the padding).  A batch that still exceeds them raises the block's overflow
+        flag (`overflow_count()`); the caller re-runs it with `capacities(batch_size)`."""
+        dev = self.rowptr.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        mx = [[0, 0] for _ in self.sizes]
+        for _ in range(trials):
+            sd = torch.randint(0, self.num_nodes, (batch_size,), generator=g, device=dev)
+            _, blocks, _ = self.sample(sd)
+            for h, blk in enumerate(blocks[::-1]):
+                c = blk.counts.tolist()
+                mx[h] = [max(mx[h][0], c[0]), max(mx[h][1], c[1])]
+        caps, b = [], int(batch_size)
+        for (f, (nn, ne)) in zip(self.sizes, mx):
+            r256 = lambda v: -(-int(v) // 256) * 256 if v >= 4096 else -(-int(v) // 16) * 16  # noqa: E731
+            e_cap = max(1, min(b * f, r256(ne * slack)))
+            s_cap = max(b, min(b + e_cap, r256(nn * slack)))
+            caps.append((s_cap, e_cap))
+            b = s_cap
+        return caps
+
+    def overflow_count(self):
+        """How many sampled hops hit a capacity since the sampler was built (one host read)."""
+        return int(self._overflow)
+
+    def sample(self, seeds, n_seeds=None, caps=None):
+        """seeds: int64 device tensor [B]; n_seeds: optional device int64 [1] (<= B valid seeds); caps: optional
+        [(n_src_cap, e_cap)] per hop, innermost first (default: the worst case).
         Returns (n_id [cap], blocks outermost hop first, counts of the outermost hop)."""
         eng = self.eng
         dev = self.rowptr.device
@@ -211,21 +241,25 @@ class BlockSampler:
         st = eng._stream(dev)
         blocks = []
         cur, n_cur = seeds, n_seeds
-        for f in self.sizes:
+        for h, f in enumerate(self.sizes):
             b_cap = int(cur.shape[0])
-            e_cap = b_cap * f
+            s_cap, e_cap = caps[h] if caps is not None else (b_cap + b_cap * f, b_cap * f)
+            s_cap, e_cap = int(s_cap), int(e_cap)
             rowptr = torch.empty(b_cap + 1, dtype=torch.int64, device=dev)
-            col = torch.empty(max(e_cap, 1), dtype=torch.int32, device=dev)
-            e_pos = torch.empty(max(e_cap, 1), dtype=torch.int64, device=dev)
-            nid = torch.empty(b_cap + e_cap, dtype=torch.int64, device=dev)
-            counts = torch.empty(2, dtype=torch.int64, device=dev)
-            wsb = eng.lib.ggl_sample_hop_workspace_bytes(b_cap, f)
+            col = torch.empty(e_cap, dtype=torch.int32, device=dev)
+            e_pos = torch.empty(e_cap, dtype=torch.int64, device=dev)
+            nid = torch.empty(s_cap, dtype=torch.int64, device=dev)
+            counts = torch.zeros(3, dtype=torch.int64, device=dev)
+            wsb = eng.lib.ggl_sample_hop_workspace_bytes(b_cap, e_cap)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             eng._check(eng.lib.ggl_sample_hop(_ptr(self.rowptr), _ptr(self.col), _ptr(cur), _ptr(n_cur), b_cap, f,
-                                              _ptr(eng._rng_state(dev)), _ptr(self._first_pos), _ptr(rowptr),
-                                              _ptr(col), _ptr(e_pos), _ptr(nid), _ptr(counts), _ptr(ws), wsb, st))
-            blocks.append(Block(eng, rowptr, col[:e_cap], e_pos[:e_cap], counts, b_cap, b_cap + e_cap, f))
-            blocks[-1].n_id, blocks[-1].seeds, blocks[-1].n_seeds = nid, cur, n_cur   # global ids of its rows
+                                              e_cap, s_cap, _ptr(eng._rng_state(dev)), _ptr(self._first_pos),
+                                              _ptr(rowptr), _ptr(col), _ptr(e_pos), _ptr(nid), _ptr(counts), _ptr(ws),
+                                              wsb, st))
+            self._overflow += counts[2]
+            blk = Block(eng, rowptr, col, e_pos, counts, b_cap, s_cap, f)
+            blk.n_id, blk.seeds, blk.n_seeds = nid, cur, n_cur   # global ids of its rows / of its seeds
+            blocks.append(blk)
             cur, n_cur = nid, counts[0:1]
         return cur, blocks[::-1], blocks[-1].counts
 

@@ -104,8 +104,10 @@ class SAGEBlockTrainer:
     whole step into one hipGraph that is replayed per batch with the seeds updated in place."""
 
     def __init__(self, sampler, in_feat, hid_feat, num_class, num_layers=2, drop_rate=0.0, lr=0.005, seed=0,
-                 device="cuda", capturable=None):
-        self.sampler = sampler
+                 device="cuda", capturable=None, caps=None):
+        """`caps`: block capacities from `sampler.calibrate(batch_size)` (default: the worst case, on which
+        every dense layer runs several times more padding than data); check `sampler.overflow_count()`."""
+        self.sampler, self.caps = sampler, caps
         torch.manual_seed(seed)
         self.net = GraphSAGESampleModel(in_feat, hid_feat, num_class, drop_rate, num_layers).to(device)
         cap = torch.device(device).type == "cuda" if capturable is None else capturable
@@ -115,7 +117,7 @@ class SAGEBlockTrainer:
     def step(self, x, y, seeds):
         self.net.train()
         self.opt.zero_grad(set_to_none=False)
-        n_id, blocks, _ = self.sampler.sample(seeds)
+        n_id, blocks, _ = self.sampler.sample(seeds, caps=self.caps)
         logits = self.net(x.index_select(0, n_id), blocks)
         loss = F.cross_entropy(logits[: seeds.shape[0]], y.index_select(0, seeds))
         loss.backward()

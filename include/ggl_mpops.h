@@ -357,15 +357,18 @@ int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const int64_t *se
  *   seeds[B_cap] of which the first *n_seeds_dev are valid; fanout > 0 (min(deg, fanout) distinct neighbours per
  *   seed, Floyd's algorithm as sample.cpp:75-83); first_pos: int64 scratch of one entry per graph node, every
  *   entry == 2^62 on entry and again on exit.
- *   out_rowptr[B_cap + 1] (rows past the valid seeds are empty), out_col[B_cap * fanout] int32 LOCAL ids, each
- *   row ascending (sample.cpp:112-118), out_eid[B_cap * fanout] CSR positions of the sampled edges (or NULL),
- *   out_nid[B_cap + B_cap * fanout]: the seeds verbatim, then the new nodes in first-seen order (sample.cpp:24-55),
- *   zero-padded; out_counts[2] = {nodes in out_nid, sampled edges} (device). */
-size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t fanout);
+ *   Capacities: E_cap <= B_cap * fanout edge slots, S_cap in [B_cap, B_cap + E_cap] node slots (the worst
+ *   case is rarely met: a caller sizes them from measured batches and checks the overflow flag).
+ *   out_rowptr[B_cap + 1] (rows past the valid seeds are empty), out_col[E_cap] int32 LOCAL ids, each row
+ *   ascending (sample.cpp:112-118), out_eid[E_cap] CSR positions of the sampled edges (or NULL),
+ *   out_nid[S_cap]: the seeds verbatim, then the new nodes in first-seen order (sample.cpp:24-55), zero-padded;
+ *   out_counts[3] = {nodes in out_nid, sampled edges, overflow} (device): overflow = 1 when a capacity was
+ *   hit (rows cut at E_cap / nodes past S_cap dropped — memory-safe, but the block is incomplete). */
+size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t E_cap);
 int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds, const int64_t *n_seeds_dev,
-                   int64_t B_cap, int64_t fanout, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
-                   int32_t *out_col, int64_t *out_eid, int64_t *out_nid, int64_t *out_counts, void *workspace,
-                   size_t workspace_bytes, void *stream);
+                   int64_t B_cap, int64_t fanout, int64_t E_cap, int64_t S_cap, int64_t *rng_state,
+                   int64_t *first_pos, int64_t *out_rowptr, int32_t *out_col, int64_t *out_eid, int64_t *out_nid,
+                   int64_t *out_counts, void *workspace, size_t workspace_bytes, void *stream);
 /* CSC of such a block without a host read: rowptrT[N_src_cap + 1], dstT[E_cap] = destination rows of each source
  * row's block edges (ascending); E_cap entries of col of which rowptr[N_dst] are valid. */
 size_t ggl_block_transpose_workspace_bytes(int64_t E_cap, int64_t N_src_cap);

@@ -834,6 +834,30 @@ def check_plan_cache(eng, dev):
     b1 = eng.stats["plans_built"]
     eng.c_segment_sum(x, ei[1], 3)
     assert eng.stats["plans_built"] == b1
+    # the caches are bounded by the bytes their plans hold, not only by entry count, and can be dropped
+    from gammagl_amd.ops import _PlanCache
+    small = _PlanCache(cap=16, max_bytes=3000)
+    keep = []
+    for i in range(6):
+        t = torch.arange(100, device=dev) + i
+        keep.append(t)
+        small.put(t, (i,), torch.zeros(200, dtype=torch.float32, device=dev))   # 800 bytes each
+    assert len(small.d) == 3 and small.bytes <= 3000 and small.get(keep[-1], (5,)) is not None
+    assert small.get(keep[0], (0,)) is None
+    eng.clear_caches()
+    assert len(eng.seg_cache.d) == 0 and eng.seg_cache.bytes == 0 and len(eng.graph_cache.d) == 0
+    # an edit behind the version counter (.data) is invisible to the key: the opt-in checksum catches it
+    v = _PlanCache(cap=4)
+    v.verify = True
+    t = torch.tensor([3, 1, 2], device=dev)
+    v.put(t, (), "plan")
+    assert v.get(t, ()) == "plan"
+    t.data[0] = 0
+    try:
+        v.get(t, ())
+        raise AssertionError("stale plan returned")
+    except RuntimeError as ex:
+        assert "clear_caches" in str(ex)
 
 
 def check_dropout_without_relu_gradient(eng, dev):
@@ -1013,7 +1037,7 @@ def check_block_sampler(eng, dev, oracle):
     bs = sampler.BlockSampler(eit, [big], num_nodes=N, eng=eng)
     n_id, (blk,), counts = bs.sample(to_t(seeds, dev))
     ref_rp, ref_col, ref_nid, ref_eid = oracle.sample_adj_full(rowptr, col, seeds)
-    nn, ne = (int(v) for v in to_np(counts))
+    nn, ne = (int(v) for v in to_np(counts)[:2])
     assert nn == len(ref_nid) and ne == len(ref_col)
     assert_same(to_np(blk.rowptr), ref_rp, "block rowptr")
     assert_same(to_np(blk.col)[:ne].astype(np.int64), ref_col, "block col")
@@ -1036,7 +1060,7 @@ def check_block_sampler(eng, dev, oracle):
     assert [b.fanout for b in blocks] == [3, 5] and blocks[1].n_dst_cap == len(sd)
     assert blocks[0].n_dst_cap == blocks[1].n_src_cap and n_id.shape[0] == blocks[0].n_src_cap
     for blk in blocks[::-1]:                                      # innermost first, as sampled
-        nn, ne = (int(v) for v in to_np(blk.counts))
+        nn, ne = (int(v) for v in to_np(blk.counts)[:2])
         nv = int(to_np(blk.n_seeds)[0])
         rp, cl, ep = to_np(blk.rowptr), to_np(blk.col).astype(np.int64), to_np(blk.e_pos)
         hop_seeds, hop_nid = to_np(blk.seeds), to_np(blk.n_id)
@@ -1055,7 +1079,7 @@ def check_block_sampler(eng, dev, oracle):
     # (3) the block aggregate + fused epilogue and its backward (device-built CSC) vs the formula
     bs = sampler.BlockSampler(eit, [6], num_nodes=N, eng=eng)
     n_id, (blk,), counts = bs.sample(to_t(sd, dev))
-    nn, ne = (int(v) for v in to_np(counts))
+    nn, ne = (int(v) for v in to_np(counts)[:2])
     K = 8
     g = torch.Generator().manual_seed(0)
     xs = torch.randn(blk.n_src_cap, K, generator=g).to(dev).requires_grad_(True)
@@ -1091,6 +1115,29 @@ def check_block_sampler(eng, dev, oracle):
     assert shared < 0.5 and identical <= 3, (shared, identical)       # 0.25 expected; the XOR layout gave 1.55 / 57
     cnt7 = np.bincount(p1.reshape(-1) - rowptr[7], minlength=deg[7])
     assert np.abs(cnt7 - 6000 / deg[7]).max() < 6 * np.sqrt(6000 / deg[7])
+    # (4b) capacities below the worst case: calibrated ones fit (no overflow, same invariants); too small ones
+    # raise the overflow flag and stay memory-safe (rows cut at the edge capacity, ids below the node capacity)
+    bs = sampler.BlockSampler(eit, [5, 3], num_nodes=N, eng=eng)
+    caps = bs.calibrate(16, trials=6, slack=1.25)
+    worst = bs.capacities(16)
+    assert all(c[0] <= w[0] and c[1] <= w[1] for c, w in zip(caps, worst)) and caps[1][0] < worst[1][0]
+    before = bs.overflow_count()
+    n_id, blocks, _ = bs.sample(to_t(sd, dev), caps=caps)
+    assert bs.overflow_count() == before and n_id.shape[0] == caps[1][0]
+    assert blocks[1].n_src_cap == caps[0][0] and blocks[1].e_cap == caps[0][1] and blocks[0].n_dst_cap == caps[0][0]
+    for blk in blocks:
+        nn, ne, ov = (int(v) for v in to_np(blk.counts))
+        assert ov == 0 and nn <= blk.n_src_cap and ne <= blk.e_cap and int(to_np(blk.rowptr)[-1]) == ne
+        assert (to_np(blk.n_id)[to_np(blk.col).astype(np.int64)[:ne]] == col[to_np(blk.e_pos)[:ne]]).all()
+    tiny = [(len(sd) + 8, 24), (len(sd) + 8 + 16, 40)]
+    n_id, blocks, _ = bs.sample(to_t(sd, dev), caps=tiny)
+    assert bs.overflow_count() > before
+    for blk in blocks:
+        nn, ne, ov = (int(v) for v in to_np(blk.counts))
+        rp = to_np(blk.rowptr)
+        assert nn <= blk.n_src_cap and ne <= blk.e_cap and rp[-1] == ne and (np.diff(rp) >= 0).all()
+        assert (to_np(blk.col) >= 0).all() and (to_np(blk.col) < blk.n_src_cap).all()
+    assert any(int(to_np(b.counts)[2]) == 1 for b in blocks) and bool((bs._first_pos == sampler._BIG).all())
     # (5) the model runs on blocks end to end (shapes by capacity, loss on the seed rows)
     bs = sampler.BlockSampler(eit, [5, 3], num_nodes=N, eng=eng)
     n_id, blocks, _ = bs.sample(to_t(sd, dev))

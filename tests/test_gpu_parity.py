@@ -627,8 +627,10 @@ def test_minibatch_step_captures_into_one_hipgraph(eng, dev):
     n, f, c = 20000, 32, 5
     x, y, ei = homophilous_graph(n, f, c, deg=4, seed=1, device=dev)
     bs = BlockSampler(ei, [10, 5], num_nodes=n, eng=eng)
-    tr = SAGEBlockTrainer(bs, f, 32, c, lr=0.01, seed=0, device=dev)
     B = 512
+    caps = bs.calibrate(B, trials=6, slack=1.4)
+    assert caps[1][0] < bs.capacities(B)[1][0]
+    tr = SAGEBlockTrainer(bs, f, 32, c, lr=0.01, seed=0, device=dev, caps=caps)
     g = torch.Generator(device=dev).manual_seed(0)
     seeds = torch.randperm(n, generator=g, device=dev)[:B].contiguous()
     tr.capture(x, y, seeds)
@@ -642,6 +644,6 @@ def test_minibatch_step_captures_into_one_hipgraph(eng, dev):
     assert bool(torch.isfinite(losses).all())
     assert float(losses[-10:].mean()) < 0.7 * float(losses[:5].mean()), losses
     assert first_edges[1] > first_edges[0]                      # the device-resident RNG offset advanced per replay
-    assert bool((bs._first_pos == (1 << 62)).all())
+    assert bool((bs._first_pos == (1 << 62)).all()) and bs.overflow_count() == 0
     # eager step on the same trainer still works after capture (same code path, no graph)
     assert bool(torch.isfinite(tr.step(x, y, seeds)))

@@ -42,7 +42,9 @@ dyn = SAGETrainer(NeighborSampler(ei, [25, 10], num_nodes=n, eng=eng), f, 256, c
 wall(lambda b: dyn.step(x, y, b), "dynamic sampler, eager        ")
 bs = BlockSampler(ei, [25, 10], num_nodes=n, eng=eng)
 print("block capacities (dst, src, edges), innermost first:", bs.capacities(B))
-blk = SAGEBlockTrainer(bs, f, 256, c, device=dev)
+caps = bs.calibrate(B, trials=8, slack=1.25)
+print("calibrated capacities (src, edges), innermost first:", caps, flush=True)
+blk = SAGEBlockTrainer(bs, f, 256, c, device=dev, caps=caps)
 wall(lambda b: blk.step(x, y, b), "static-shape sampler, eager   ")
 seeds = batches[0].clone()
 blk.capture(x, y, seeds)
@@ -54,8 +56,9 @@ def rep(b):
 
 
 wall(rep, "static-shape sampler, hipGraph")
-n_id, blocks, counts = bs.sample(batches[0])
+print("hops that overflowed their capacity so far:", bs.overflow_count())
+n_id, blocks, counts = bs.sample(batches[0], caps=caps)
 print("valid / capacity:", [(int(b.counts[0]), b.n_src_cap, int(b.counts[1]), b.e_cap) for b in blocks])
 # sampler alone
-for lbl, fn in (("dynamic sample()", lambda b: dyn.sampler.sample(b)), ("static  sample()", lambda b: bs.sample(b))):
+for lbl, fn in (("dynamic sample()", lambda b: dyn.sampler.sample(b)), ("static  sample()", lambda b: bs.sample(b, caps=caps))):
     wall(fn, lbl + "               ")
