@@ -131,12 +131,11 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        // masked: 1 = y > 0 (ReLU, and dropout when no rng state is given), 2 = y != 0 (dropout without ReLU
-        // and without an rng state), 3 = redrawn dropout mask only, 4 = redrawn mask and y > 0
+        // masked: 1 = y > 0 (ReLU, with or without dropout: exact), 2 = y != 0 (dropout without ReLU and
+        // without an rng state), 3 = redrawn dropout mask (dropout without ReLU)
         if (masked == 1) gv[i] = (yv[i] > 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
         else if (masked == 2) gv[i] = (yv[i] != 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
         else if (masked == 3) gv[i] = (rw[i] >= drop_thresh) ? __fmul_rn(gv[i], scale) : 0.0f;
-        else if (masked == 4) gv[i] = (rw[i] >= drop_thresh && yv[i] > 0.0f) ? __fmul_rn(gv[i], scale) : 0.0f;
         acc[i] = __fadd_rn(acc[i], gv[i]);  // rows in ascending order, unrolled or not
       }
       stv<VEC>(ga + r * K + c * VEC, gv);
@@ -241,8 +240,11 @@ extern "C" int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64
   // rng_used = the {seed, offset} the forward read (a copy taken before it advanced): the dropout mask is
   // redrawn exactly.  Without it the mask is rebuilt from y (y > 0 with ReLU; y != 0 without — exact except
   // for kept activations that are exactly 0).
-  const bool redraw = p_drop > 0.0f && rng_used != nullptr;
-  const int masked = redraw ? (relu ? 4 : 3) : (relu ? 1 : (p_drop > 0.0f ? 2 : 0));
+  // With ReLU the mask read off y is already exact (y > 0 <=> kept and positive; a kept activation that is
+  // exactly 0 has zero ReLU gradient anyway), so the redraw — 10 Philox rounds per 4 elements, measured
+  // 1.10 -> 1.87 ms on [2.45 M, 256] — is only paid where it is needed: dropout without ReLU.
+  const bool redraw = p_drop > 0.0f && rng_used != nullptr && !relu;
+  const int masked = relu ? 1 : (redraw ? 3 : (p_drop > 0.0f ? 2 : 0));
   const uint32_t thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
   GGL_REQUIRE(!masked || masked == 3 || y || N == 0, GGL_EINVAL, "y is needed to rebuild the ReLU/dropout mask");
   GGL_REQUIRE(!gbias || (workspace && workspace_bytes >= ggl_bias_act_bwd_workspace_bytes(N, K)),

@@ -33,6 +33,8 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_p
     col = col.contiguous().to(torch.int64)
     idx = idx.contiguous().to(torch.int64).reshape(-1)
     B = int(idx.shape[0])
+    if B > 0:  # an out-of-range seed would be an out-of-bounds read of rowptr: device-side assert, no host sync
+        torch._assert_async(((idx >= 0) & (idx < rowptr.shape[0] - 1)).all())
     st = eng._stream(dev)
     deg = torch.empty(B, dtype=torch.int64, device=dev)
     eng._check(eng.lib.ggl_sample_count(_ptr(rowptr), _ptr(idx), B, int(num_neighbors), int(bool(replace)),
@@ -46,26 +48,27 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_p
                                        int(bool(replace)), _ptr(out_rowptr), _ptr(eng._rng_state(dev)),
                                        _ptr(e_pos), _ptr(nbr), st))
     e_pos, nbr = e_pos[:E], nbr[:E]
-    # relabel: seeds keep 0..B-1 (sample.cpp:24-29), new nodes follow in first-seen order (:48-51)
+    # relabel: the seeds keep 0..B-1 VERBATIM — a seed listed twice stays twice in n_id, and a neighbour equal to
+    # it maps to its LAST position (operator[] overwrite, sample.cpp:24-29) — new nodes follow in first-seen
+    # order (:48-51).  Keys: seed i -> -(i + 1), sampled neighbour q -> B + q; the minimum key per node is the
+    # last seed position if the node is a seed, else its first sampled occurrence.
     cat = torch.cat([idx, nbr])
+    key = torch.cat([-(torch.arange(B, device=dev) + 1), B + torch.arange(E, device=dev)])
     if first_pos is not None:
-        ar = torch.arange(cat.shape[0], device=dev)
-        first_pos.scatter_reduce_(0, cat, ar, "amin", include_self=True)   # first position of every node met
+        first_pos.scatter_reduce_(0, cat, key, "amin", include_self=True)
         fp = first_pos[cat]
-        is_first = fp == ar
-        new_id = torch.cumsum(is_first, 0) - 1                              # ids in first-seen order
-        out_n_id = cat[is_first]
-        local = new_id[fp[B:]]
         first_pos[cat] = _BIG                                               # hand the scratch back clean
     else:
         uniq, inv = torch.unique(cat, return_inverse=True)
-        first = torch.full((uniq.shape[0],), cat.shape[0], dtype=torch.int64, device=dev)
-        first.scatter_reduce_(0, inv, torch.arange(cat.shape[0], device=dev), "amin", include_self=True)
-        order = torch.argsort(first)                      # unique ids by first appearance
-        rank = torch.empty_like(order)
-        rank[order] = torch.arange(order.shape[0], device=dev)
-        out_n_id = uniq[order]
-        local = rank[inv[B:]]
+        first = torch.full((uniq.shape[0],), _BIG, dtype=torch.int64, device=dev)
+        first.scatter_reduce_(0, inv, key, "amin", include_self=True)
+        fp = first[inv]
+    is_first = fp == key
+    is_first[:B] = True
+    new_id = torch.cumsum(is_first, 0) - 1                                  # ids in first-seen order
+    out_n_id = cat[is_first]
+    fpn = fp[B:]
+    local = torch.where(fpn < 0, -fpn - 1, new_id[fpn.clamp(min=0)])
     # every row's columns ascending by local id (sample.cpp:112-118)
     if E > 0:
         row = torch.repeat_interleave(torch.arange(B, device=dev), deg, output_size=E)  # size known: no sync
@@ -236,6 +239,7 @@ class BlockSampler:
         eng = self.eng
         dev = self.rowptr.device
         seeds = seeds.to(device=dev, dtype=torch.int64).contiguous().reshape(-1)
+        torch._assert_async(((seeds >= 0) & (seeds < self.num_nodes)).all())
         if n_seeds is None:
             n_seeds = torch.full((1,), seeds.shape[0], dtype=torch.int64, device=dev)
         st = eng._stream(dev)

@@ -169,11 +169,14 @@ def rmat_pairs_ctr(scale, idx, seed, a=0.57, b=0.19, c=0.19):
 class _Comm:
     """The few collectives the builder needs; world == 1 needs no process group."""
 
-    def __init__(self, rank, world, group):
+    def __init__(self, rank, world, group, always=False):
+        """`always` (tests): go through torch.distributed even with one rank, so that the collectives' dtype /
+        split handling is exercised on the real backend (RCCL) by a single-GPU box."""
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.always = bool(always)
 
     def all_reduce(self, t, op="sum"):
-        if self.world > 1:
+        if self.world > 1 or self.always:
             import torch.distributed as dist
 
             dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
@@ -181,7 +184,7 @@ class _Comm:
 
     def route(self, payload, owner):
         """Send row i of `payload` ([m] or [m, c] int64) to rank owner[i]; returns what this rank receives."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return payload
         import torch.distributed as dist
 
@@ -196,7 +199,7 @@ class _Comm:
 
     def all_gather_var(self, t):
         """Concatenation over ranks of 1-D tensors of different lengths (small ones only)."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return t
         import torch.distributed as dist
 
@@ -224,7 +227,8 @@ def bounds_from_degree(deg, world):
 
 
 def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, group=None, device="cpu",
-                     relabel="random", order="src", parts=None, stats=None, buckets=None, slab=1 << 27):
+                     relabel="random", order="src", parts=None, stats=None, buckets=None, slab=1 << 27,
+                     _always_comm=False):
     """This rank's share of the R-MAT graph with `num_nodes` nodes and exactly `num_directed_edges`
     directed edges (symmetrised, de-duplicated) + one self-loop per node, for a 1-D partition into `parts`
     (default: `world`) contiguous node ranges balanced by in-edge count.
@@ -242,7 +246,7 @@ def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, gro
     dev = torch.device(device)
     N, P = int(num_nodes), int(world)
     parts = int(parts or world)
-    comm = _Comm(rank if P > 1 else 0, P, group)   # (world == 1, parts > 1: `rank` only picks the share played)
+    comm = _Comm(rank if P > 1 else 0, P, group, _always_comm)   # (world == 1, parts > 1: `rank` only picks the share played)
     T = int(num_directed_edges) // 2
     if buckets is None:
         buckets = 1 if P > 1 else max(1, -(-int(2.6 * T) // (1 << 29)))
@@ -276,7 +280,7 @@ def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, gro
                 u, v = pi[u], pi[v]
             dkey = torch.cat([v * N + u, u * N + v])         # both directions of every pair
             del u, v, ok
-            if P > 1:
+            if P > 1 or _always_comm:
                 recv = comm.route(dkey, bucket_id(dkey) // nb)
                 peak = max(peak, int(dkey.numel()) + int(recv.numel()))
                 dkey = recv
@@ -354,7 +358,7 @@ def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, gro
         del k
         if rk is not None:
             sr, ds = rk[sr], rk[ds]
-        if P > 1:
+        if P > 1 or (_always_comm and parts == 1):
             own = torch.searchsorted(bt, ds, right=True)
             got = comm.route(torch.stack([sr, ds], 1), own)
             peak = max(peak, int(sr.numel()) + int(got.shape[0]))

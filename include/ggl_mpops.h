@@ -238,10 +238,10 @@ int ggl_colsum_f32(const float *g, int64_t N, int64_t K, float *out, void *works
  *        on rng_state = {seed, offset} (device int64[2]; offset is advanced on the stream after the
  *        launch, so a captured graph draws a new mask per replay).  bias [K] or NULL; p_drop = 0: no RNG.
  *        The word of element (r, k): Philox(counter = r * (K / v) + k / v)[k % v], v = 4 if K % 4 == 0 else 1.
- *   bwd: ga = keep * [relu ? y > 0 : 1] * g / (1 - p_drop); `rng_used` = a copy of the {seed, offset} the
- *        forward READ (taken before it advanced): the dropout mask is redrawn exactly.  rng_used == NULL:
- *        the mask is rebuilt from y (y > 0 with ReLU, y != 0 without).  gbias[K] = column sums of ga
- *        (same pass; NULL to skip).
+ *   bwd: ga = keep * [relu ? y > 0 : 1] * g / (1 - p_drop).  With ReLU the mask is read off y (y > 0: exact).
+ *        Without ReLU `rng_used` = a copy of the {seed, offset} the forward READ (taken before it advanced)
+ *        lets the dropout mask be redrawn exactly; rng_used == NULL: y != 0 stands in for it (exact except
+ *        for kept activations that are exactly 0).  gbias[K] = column sums of ga (same pass; NULL to skip).
  * ---------------------------------------------------------------------------------------------- */
 int ggl_bias_act_fwd(const float *a, const float *bias, int64_t N, int64_t K, int relu, float p_drop,
                      int64_t *rng_state, float *y, void *stream);

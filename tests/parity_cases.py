@@ -600,6 +600,16 @@ def check_sampler(eng, dev, oracle):
     ref = oracle.sample_adj_full(rowptr, col, seeds)
     for a, b, nm in zip(got, ref, ("rowptr", "col", "n_id", "e_id")):
         assert_same(to_np(a), b, "sample_adj full " + nm)
+    # duplicate seeds stay verbatim in n_id and neighbours map to the LAST copy (sample.cpp:24-29), both with the
+    # relabel scratch and without it
+    dup = np.array([7, 3, 9, 3, 100, 7], np.int64)
+    refd = oracle.sample_adj_full(rowptr, col, dup)
+    for fpos in (None, torch.full((N,), sampler._BIG, dtype=torch.int64, device=dev)):
+        gotd = sampler.sample_adj(rp, cl, to_t(dup, dev), -1, eng=eng, first_pos=fpos)
+        for a, b, nm in zip(gotd, refd, ("rowptr", "col", "n_id", "e_id")):
+            assert_same(to_np(a), b, "sample_adj duplicate seeds " + nm)
+        if fpos is not None:
+            assert bool((fpos == sampler._BIG).all())
     deg = rowptr[seeds + 1] - rowptr[seeds]
     for fanout, replace in ((5, False), (25, False), (10, True)):
         orp, ocol, n_id, e_pos = (to_np(t) for t in sampler.sample_adj(rp, cl, idx, fanout, replace, eng=eng))

@@ -414,6 +414,22 @@ def test_rccl_self_halo_exchange(eng, dev):
             bound = eng.c_spmm_sum(ei, w, h.abs())
             assert bool(((ya - yb).abs() <= 1e-5 * bound + 1e-6).all())
             torch.testing.assert_close(ha.grad, hb.grad, rtol=1e-4, atol=1e-4)
+        # the per-rank graph builder's collectives (all-to-all-v of int64 edge keys, variable all-gather,
+        # histogram all-reduce) through RCCL: same graph as the build that never touches the backend
+        from gammagl_amd.synth import rmat_partitioned
+        ga = rmat_partitioned(30000, 500000, seed=2, device=dev, _always_comm=True)
+        gb = rmat_partitioned(30000, 500000, seed=2, device=dev)
+        assert ga["e_global"] == gb["e_global"] == 530000
+        assert torch.equal(ga["src"], gb["src"]) and torch.equal(ga["dst"], gb["dst"]) and torch.equal(ga["w"], gb["w"])
+        # fused epilogue behind the exchange == aggregate -> bias_act, on the real backend
+        hb = torch.randn(N, 64, generator=g, device=dev)
+        bias = torch.randn(1, 64, generator=g, device=dev)
+        eng.reseed(5)
+        st0 = eng._rng_state(dev).clone()
+        y1 = pg.aggregate(hb, bias, relu=True, p_drop=0.3)
+        eng._rng_state(dev).copy_(st0)
+        y2 = eng.bias_act(pg.aggregate(hb), bias, relu=True, p_drop=0.3)
+        assert torch.equal(y1, y2)
         tr = DistGCNTrainer(pg, 32, 64, 5, num_layers=3, drop_rate=0.0, seed=3, device=dev)
         x = torch.randn(N, 32, generator=g, device=dev)
         y = torch.randint(0, 5, (N,), generator=g, device=dev)

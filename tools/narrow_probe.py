@@ -44,7 +44,7 @@ for K in (1, 4, 8, 16, 32, 64, 256):
         eng.spmm(gp, w, x)
         t = timed(lambda: eng.spmm(gp, w, x))
     alg = E * (4 * K + 8) + n * (4 * K + 8)
-    line = f"K={K:4d} spmm_sum {t:7.3f} ms {E / t / 1e6:7.2f} Gedges/s {alg / t / 1e6:7.0f} GB/s ({alg / t / 8e6:4.0f}% of HBM peak)"
+    line = f"K={K:4d} spmm_sum {t:7.3f} ms {E / t / 1e6:7.2f} Gedges/s {alg / t / 1e6:7.0f} GB/s ({alg / t / 8e7:4.0f}% of HBM peak)"
     if E * K * 4 < 60e9:
         msg = torch.randn(E, K, generator=g, device=dev)
         with torch.no_grad():
@@ -52,6 +52,6 @@ for K in (1, 4, 8, 16, 32, 64, 256):
                 fn = (lambda: eng.c_segment_sum(msg, dst, n)) if op == "sum" else (lambda: eng.c_segment_max(msg, dst, n))
                 ts = timed(fn)
                 algs = E * (4 * K + 8) + n * 4 * K + (n * 8 * K if op == "max" else 0)
-                line += f" | segment_{op} [E,K] {ts:7.3f} ms {algs / ts / 1e6:6.0f} GB/s ({algs / ts / 8e6:3.0f}%)"
+                line += f" | segment_{op} [E,K] {ts:7.3f} ms {algs / ts / 1e6:6.0f} GB/s ({algs / ts / 8e7:3.0f}%)"
         del msg
     print(line, flush=True)
