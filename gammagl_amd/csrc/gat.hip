@@ -979,6 +979,352 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src2_kernel(
 }
 #endif  // !GGL_EMULATE
 
+
+// =====================================================================================================
+// Head-mean GAT layer with a SHARED input row (GPU build only): the output layer of a GAT
+// (models/gat.py: concat=False, gat_conv.py:114-122 averages its heads) aggregated BEFORE it is transformed.
+//
+// The layer computes y_i = 1/H sum_h sum_j alpha_ijh (x_j W_h).  Aggregation is linear, so
+//     y_i = 1/H sum_h (sum_j alpha_ijh x_j) W_h = 1/H A_i[H*F] @ Wst[H*F, C],   A_ih = sum_j alpha_ijh x_j,
+// and the logits need no transformed rows either: el = x @ U, U[f,h] = sum_c W[f,h,c] a_src[h,c].  For the Reddit
+// GAT (F = 64 hidden, H = 8, C = 41) the per-edge gather shrinks from the 8 x 44-float transformed row (1408 B,
+// three walks at the roofline of those rows: 20 + 22 + 21 ms) to the 64-float input row (256 B); the backward
+// exploits the head mean the same way — dL/dA_ih = (g_i / H) W_h^T has rank-1 structure per row, so the source
+// walk gathers g_i (C floats) and takes its dots against the row's OWN transformed features:
+//     <dA_ih, x_j> = <g_i / H, x_j W_h>.
+// Every gather of the three walks is <= 256 B + 128 B of row constants per edge.
+//
+// Lane layout (all kernels): 16 lanes (one DPP row) per work item (row or hub chunk), H = 8 heads.
+//   * as a CHANNEL lane, lane l owns floats [4l, 4l+4) of the gathered row and of all 8 per-head accumulators;
+//   * as a WEIGHT lane, lane l = 8e + h computes the scalar softmax terms of head h for the e-th edge of a pair;
+//     weights reach the channel lanes by `row_newbcast` (one DPP move per head and edge), per-head dot products
+//     reach the weight lanes by a 16-value reduce-scatter over the row (row_ror:8, xor 4, quad_perm xor 2 / 1).
+//   * the row maximum of the logits is found by a first pass over (col, el) alone — 36 B per edge from a
+//     cache-resident panel — so the main walk needs no online rescaling.
+// =====================================================================================================
+#ifndef GGL_EMULATE
+constexpr int kShH = 8;  // heads (fixed: 16 lanes = 2 edges x 8 heads)
+
+template <int N> __device__ __forceinline__ float row_bcast(float v) {  // value of lane N of this 16-lane row
+  return dpp_mov<0x150 + N>(v);
+}
+__device__ __forceinline__ float row_ror8(float v) { return dpp_mov<0x128>(v); }  // lane ^ 8 of the row
+
+// v[k] (k = 0..15) summed over the 16 lanes of the row; lane l returns the total of v[l]
+__device__ __forceinline__ float reduce_scatter16(const float (&v)[16], int li) {
+  const bool b3 = li & 8, b2 = li & 4, b1 = li & 2, b0 = li & 1;
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (b3 ? v[8 + k] : v[k]) + row_ror8(b3 ? v[k] : v[8 + k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = (b2 ? a[4 + k] : a[k]) + __shfl_xor(b2 ? a[k] : a[4 + k], 4, 64);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) c[k] = (b1 ? b[2 + k] : b[k]) + dpp_mov<0x4E>(b1 ? b[k] : b[2 + k]);
+  return (b0 ? c[1] : c[0]) + dpp_mov<0xB1>(b0 ? c[0] : c[1]);
+}
+
+// broadcast the 8 per-head weights of edge slot E (weight lanes 8E .. 8E+7) and accumulate w_h * x into acc[h]
+template <int E> __device__ __forceinline__ void sh_accumulate(float wk, const float4 &x, float4 (&acc)[kShH]) {
+#define GGL_SH_ACC(HH)                                                                 \
+  {                                                                                    \
+    const float w = row_bcast<8 * E + HH>(wk);                                         \
+    acc[HH].x = __builtin_fmaf(x.x, w, acc[HH].x); acc[HH].y = __builtin_fmaf(x.y, w, acc[HH].y); \
+    acc[HH].z = __builtin_fmaf(x.z, w, acc[HH].z); acc[HH].w = __builtin_fmaf(x.w, w, acc[HH].w); \
+  }
+  GGL_SH_ACC(0) GGL_SH_ACC(1) GGL_SH_ACC(2) GGL_SH_ACC(3) GGL_SH_ACC(4) GGL_SH_ACC(5) GGL_SH_ACC(6) GGL_SH_ACC(7)
+#undef GGL_SH_ACC
+}
+
+struct ShDims {
+  float slope;
+  int64_t N, F, E;        // rows of this walk, floats per gathered row (<= 64, multiple of 4)
+  int64_t chunk, n_long, n_chunks;
+  uint32_t drop_thresh;
+  float drop_scale;
+};
+
+#define GGL_SH_PROLOGUE()                                                                        \
+  const int64_t item = thread_id() >> 4;                                                         \
+  const int li = (int)threadIdx.x & 15;                                                          \
+  if (item >= d.n_chunks + d.N) return;                                                          \
+  GatDims gd{};                                                                                  \
+  gd.N = d.N; gd.chunk = d.chunk; gd.n_long = d.n_long; gd.n_chunks = d.n_chunks;                \
+  GatItem it;                                                                                    \
+  if (!gat_item(gd, rowptr, row_order, long_rows, chunk_ptr, item, it)) return;                  \
+  const int e = li >> 3, h = li & 7;                                                             \
+  const bool act = 4 * li < (int)d.F; /* channel lanes past the row width idle along */          \
+  const int kk = act ? 4 * li : 0
+
+// pass 0: m[i,h] = max_p LeakyReLU(el[col[p],h] + er[i,h])   (-FLT_MAX for an empty row: unsorted_segment_max)
+__global__ __launch_bounds__(kBlock) void gat_sh_rowmax_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ row_order,
+    const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el,
+    const float *__restrict__ er, float *__restrict__ rowmax, float *__restrict__ pmax, const ShDims d) {
+  GGL_SH_PROLOGUE();
+  (void)kk;
+  const float er_i = er[it.row * kShH + h];
+  float m = -FLT_MAX;
+  int64_t p = it.beg + e;
+  for (; p + 6 < it.end; p += 8) {  // 4 of this lane's edges in flight
+    const int32_t c0 = col[p], c1 = col[p + 2], c2 = col[p + 4], c3 = col[p + 6];
+    const float s0 = el[(int64_t)c0 * kShH + h], s1 = el[(int64_t)c1 * kShH + h], s2 = el[(int64_t)c2 * kShH + h],
+                s3 = el[(int64_t)c3 * kShH + h];
+    m = fmaxf(fmaxf(m, lrelu(s0 + er_i, d.slope)), lrelu(s1 + er_i, d.slope));
+    m = fmaxf(fmaxf(m, lrelu(s2 + er_i, d.slope)), lrelu(s3 + er_i, d.slope));
+  }
+  for (; p < it.end; p += 2) m = fmaxf(m, lrelu(el[(int64_t)col[p] * kShH + h] + er_i, d.slope));
+  m = fmaxf(m, row_ror8(m));
+  if (e == 0) {
+    if (it.is_chunk) pmax[it.cid * kShH + h] = m;
+    else rowmax[it.row * kShH + h] = m;
+  }
+}
+__global__ __launch_bounds__(kBlock) void gat_sh_rowmax_final_kernel(const int32_t *__restrict__ long_rows,
+                                                                     const int64_t *__restrict__ chunk_ptr,
+                                                                     const float *__restrict__ pmax,
+                                                                     float *__restrict__ rowmax, int64_t n_long) {
+  const int64_t stride = grid_threads();
+  for (int64_t t = thread_id(); t < n_long * kShH; t += stride) {
+    const int64_t j = t / kShH, h = t - j * kShH;
+    float m = -FLT_MAX;
+    for (int64_t c = chunk_ptr[j]; c < chunk_ptr[j + 1]; ++c) m = fmaxf(m, pmax[c * kShH + h]);
+    rowmax[(int64_t)long_rows[j] * kShH + h] = m;
+  }
+}
+
+// gather of 4 consecutive positions with validity (blocks at the ends of a row are partly outside it)
+struct ShBlock {
+  int32_t c[4];
+  bool ok[4];
+};
+__device__ __forceinline__ void sh_block(const int32_t *__restrict__ col, int64_t p0, int64_t lo, int64_t hi, ShBlock &b) {
+  if (p0 >= lo && p0 + 4 <= hi) {
+    const int4 t = *reinterpret_cast<const int4 *>(col + p0);
+    b.c[0] = t.x; b.c[1] = t.y; b.c[2] = t.z; b.c[3] = t.w;
+    b.ok[0] = b.ok[1] = b.ok[2] = b.ok[3] = true;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      b.ok[u] = p0 + u >= lo && p0 + u < hi;
+      b.c[u] = b.ok[u] ? col[p0 + u] : 0;
+    }
+  }
+}
+
+// forward: A[i,h,:] = sum_p keep_p/(1-pd) exp(s_p - m) x[col[p],:] / (den + 1e-16), den[i,h] = sum_p exp(s_p - m)
+template <bool DROP>
+__global__ __launch_bounds__(kBlock) void gat_sh_fwd_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ row_order,
+    const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el,
+    const float *__restrict__ er, const float *__restrict__ rowmax, const float *__restrict__ x,
+    float *__restrict__ A, float *__restrict__ den_out, float *__restrict__ pacc, float *__restrict__ pden,
+    const int64_t *__restrict__ rng, const ShDims d) {
+  GGL_SH_PROLOGUE();
+  const int64_t F = d.F;
+  const float er_i = er[it.row * kShH + h], m = rowmax[it.row * kShH + h];
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  float4 acc[kShH];
+#pragma unroll
+  for (int q = 0; q < kShH; ++q) acc[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float den = 0.0f;
+  for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
+    ShBlock b;
+    sh_block(col, p0, it.beg, it.end, b);
+    float4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = act ? *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // this weight lane's two edges of the block: u = e and u = e + 2
+    const int32_t cA = e ? b.c[1] : b.c[0], cB = e ? b.c[3] : b.c[2];
+    const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
+    const float s0 = el[(int64_t)cA * kShH + h], s1 = el[(int64_t)cB * kShH + h];
+    float w0 = okA ? fexp(lrelu(s0 + er_i, d.slope) - m) : 0.0f;
+    float w1 = okB ? fexp(lrelu(s1 + er_i, d.slope) - m) : 0.0f;
+    den += w0 + w1;
+    if (DROP) {
+      const U4 rw = philox4x32_10((uint64_t)((p0 >> 2) * kShH + h), offset, seed);
+      w0 = (pick_word(rw, e) >= d.drop_thresh) ? w0 * d.drop_scale : 0.0f;
+      w1 = (pick_word(rw, e + 2) >= d.drop_thresh) ? w1 * d.drop_scale : 0.0f;
+    }
+    sh_accumulate<0>(w0, xv[0], acc);
+    sh_accumulate<1>(w0, xv[1], acc);
+    sh_accumulate<0>(w1, xv[2], acc);
+    sh_accumulate<1>(w1, xv[3], acc);
+  }
+  den += row_ror8(den);  // both edge parities of head h
+  if (it.is_chunk) {
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(pacc + (it.cid * kShH + q) * F + kk) = acc[q];
+    }
+    if (e == 0) pden[it.cid * kShH + h] = den;
+    return;
+  }
+  const float rinv = 1.0f / (den + 1e-16f);
+#define GGL_SH_NORM(HH)                                                                          \
+  {                                                                                              \
+    const float r = row_bcast<HH>(rinv);                                                         \
+    acc[HH].x *= r; acc[HH].y *= r; acc[HH].z *= r; acc[HH].w *= r;                              \
+  }
+  GGL_SH_NORM(0) GGL_SH_NORM(1) GGL_SH_NORM(2) GGL_SH_NORM(3) GGL_SH_NORM(4) GGL_SH_NORM(5) GGL_SH_NORM(6) GGL_SH_NORM(7)
+#undef GGL_SH_NORM
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(A + (it.row * kShH + q) * F + kk) = acc[q];
+  }
+  if (e == 0) den_out[it.row * kShH + h] = den;
+}
+
+// long rows of the forward: A = sum_c pacc_c / (sum_c pden_c + 1e-16) (the maximum is global: partials just add)
+__global__ __launch_bounds__(kBlock) void gat_sh_fwd_final_kernel(const int32_t *__restrict__ long_rows,
+                                                                  const int64_t *__restrict__ chunk_ptr,
+                                                                  const float *__restrict__ pacc,
+                                                                  const float *__restrict__ pden,
+                                                                  float *__restrict__ A, float *__restrict__ den_out,
+                                                                  int64_t n_long, int64_t F) {
+  const int64_t j = block_id();
+  if (j >= n_long) return;
+  const int64_t row = long_rows[j], c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1], K = kShH * F;
+  for (int64_t k = threadIdx.x; k < K; k += kBlock) {
+    const int64_t hh = k / F;
+    float a = 0.0f, dn = 0.0f;
+    for (int64_t c = c0; c < c1; ++c) {
+      a += pacc[c * K + k];
+      dn += pden[c * kShH + hh];
+    }
+    A[row * K + k] = a / (dn + 1e-16f);
+    if (k == hh * F) den_out[row * kShH + hh] = dn;
+  }
+}
+
+// destination walk of the backward: ger[i,h] = sum_p de_p with <G_i[h,:], x_j> from the row's G in registers
+template <bool DROP>
+__global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ row_order,
+    const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el,
+    const float *__restrict__ x, const float *__restrict__ G, const float *__restrict__ stats,
+    float *__restrict__ ger, float *__restrict__ pger, const int64_t *__restrict__ rng, const ShDims d) {
+  GGL_SH_PROLOGUE();
+  const int64_t F = d.F;
+  float4 g[kShH];
+#pragma unroll
+  for (int q = 0; q < kShH; ++q)
+    g[q] = act ? *reinterpret_cast<const float4 *>(G + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 st = *reinterpret_cast<const float4 *>(stats + (it.row * kShH + h) * 4);  // {er, m, rinv, dot}
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  float gs = 0.0f;
+  for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
+    ShBlock b;
+    sh_block(col, p0, it.beg, it.end, b);
+    float4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = act ? *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t cA = e ? b.c[1] : b.c[0], cB = e ? b.c[3] : b.c[2];
+    const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
+    const float s0 = el[(int64_t)cA * kShH + h], s1 = el[(int64_t)cB * kShH + h];
+    U4 rw{0u, 0u, 0u, 0u};
+    if (DROP) rw = philox4x32_10((uint64_t)((p0 >> 2) * kShH + h), offset, seed);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {  // pair of edges (2 pr, 2 pr + 1): 16 dots -> one per weight lane
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < kShH; ++q) {
+        v[q] = dot4(g[q], xv[2 * pr]);
+        v[8 + q] = dot4(g[q], xv[2 * pr + 1]);
+      }
+      float da = reduce_scatter16(v, li);
+      const float raw = (pr ? s1 : s0) + st.x;
+      const float al = fexp(lrelu(raw, d.slope) - st.y) * st.z;
+      if (DROP) da = (pick_word(rw, e + 2 * pr) >= d.drop_thresh) ? da * d.drop_scale : 0.0f;
+      const float ds = al * (da - st.w);
+      const float dv = raw > 0.0f ? ds : ds * d.slope;
+      gs += (pr ? okB : okA) ? dv : 0.0f;
+    }
+  }
+  gs += row_ror8(gs);
+  if (e == 0) {
+    if (it.is_chunk) pger[it.cid * kShH + h] = gs;
+    else ger[it.row * kShH + h] = gs;
+  }
+}
+
+// source walk of the backward (transposed plan): T[j,h,:] = sum_q alpha_q keep_q/(1-pd) gy[i_q,:] and
+// gel[j,h] = sum_q de_q, with <dA_ih, x_j> = <gy_i, z_jh>, z_j = the row's own transformed features (registers)
+template <bool DROP>
+__global__ __launch_bounds__(kBlock) void gat_sh_bwd_src_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col /* colT */, const int32_t *__restrict__ posT,
+    const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ z,
+    const float *__restrict__ gy, const float *__restrict__ stats, float *__restrict__ T, float *__restrict__ gel,
+    float *__restrict__ pacc, float *__restrict__ pgel, const int64_t *__restrict__ rng, const ShDims d) {
+  GGL_SH_PROLOGUE();
+  const int64_t F = d.F;  // here: padded class width of gy / z rows
+  float4 zr[kShH], acc[kShH];
+#pragma unroll
+  for (int q = 0; q < kShH; ++q) {
+    zr[q] = act ? *reinterpret_cast<const float4 *>(z + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  const float el_j = el[it.row * kShH + h];
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  float gl = 0.0f;
+  for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
+    ShBlock b;
+    sh_block(col, p0, it.beg, it.end, b);
+    float4 gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gv[u] = act ? *reinterpret_cast<const float4 *>(gy + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t cA = e ? b.c[1] : b.c[0], cB = e ? b.c[3] : b.c[2];
+    const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
+    const float4 st0 = *reinterpret_cast<const float4 *>(stats + ((int64_t)cA * kShH + h) * 4);
+    const float4 st1 = *reinterpret_cast<const float4 *>(stats + ((int64_t)cB * kShH + h) * 4);
+    float wk[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < kShH; ++q) {
+        v[q] = dot4(zr[q], gv[2 * pr]);
+        v[8 + q] = dot4(zr[q], gv[2 * pr + 1]);
+      }
+      float da = reduce_scatter16(v, li);
+      const float4 st = pr ? st1 : st0;
+      const bool ok = pr ? okB : okA;
+      const float raw = el_j + st.x;
+      const float al = fexp(lrelu(raw, d.slope) - st.y) * st.z;
+      float alk = al;
+      if (DROP) {  // the keep bit lives at the FORWARD position of the edge
+        const int64_t q = p0 + e + 2 * pr;
+        const bool keep = ok && drop_word((int64_t)posT[ok ? q : it.beg], kShH, h, offset, seed) >= d.drop_thresh;
+        alk = keep ? al * d.drop_scale : 0.0f;
+        da = keep ? da * d.drop_scale : 0.0f;
+      }
+      const float ds = al * (da - st.w);
+      const float dv = raw > 0.0f ? ds : ds * d.slope;
+      gl += ok ? dv : 0.0f;
+      wk[pr] = ok ? alk : 0.0f;
+    }
+    sh_accumulate<0>(wk[0], gv[0], acc);
+    sh_accumulate<1>(wk[0], gv[1], acc);
+    sh_accumulate<0>(wk[1], gv[2], acc);
+    sh_accumulate<1>(wk[1], gv[3], acc);
+  }
+  gl += row_ror8(gl);
+  if (it.is_chunk) {
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(pacc + (it.cid * kShH + q) * F + kk) = acc[q];
+    }
+    if (e == 0) pgel[it.cid * kShH + h] = gl;
+    return;
+  }
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(T + (it.row * kShH + q) * F + kk) = acc[q];
+  }
+  if (e == 0) gel[it.row * kShH + h] = gl;
+}
+#endif  // !GGL_EMULATE
+
 static inline int pow2_log2(int64_t v) {
   int l = 0;
   while (l < 6 && ((int64_t)1 << l) < v) ++l;
@@ -1364,6 +1710,167 @@ extern "C" int ggl_gat_fast_bwd(const ggl_segplan_t *plan, const int32_t *col, c
     if (planT->n_long > 0) {
       GGL_LAUNCH((gat_bwd_src_final_kernel), planT->n_long, kBlock, s, planT->long_rows, planT->chunk_ptr,
                  (const float *)pacc, (const float *)pgel, gx, gel, d);
+      GGL_LAUNCH_CHECK();
+    }
+  }
+  return GGL_OK;
+#endif
+}
+
+// ---- head-mean GAT with a shared input row: entry points (see the block comment above gat_sh_rowmax_kernel) ----
+extern "C" int ggl_gat_sh_supported(int64_t H, int64_t F, int64_t C) {
+#ifdef GGL_EMULATE
+  (void)H; (void)F; (void)C;
+  return 0;
+#else
+  return (H == 8 && F > 0 && F <= 64 && F % 4 == 0 && C > 0 && C <= 64) ? 1 : 0;
+#endif
+}
+
+// floats of plan->partial the forward needs for a plan with n_chunks hub chunks (the backward needs 8 per chunk
+// on the forward plan and 8 * Cp + 8 per chunk of the transposed plan)
+extern "C" size_t ggl_gat_sh_partial_bytes(int64_t n_chunks, int64_t F) {
+  if (n_chunks <= 0) return 0;
+  return (size_t)n_chunks * (size_t)(8 * F + 16) * sizeof(float) + 64;
+}
+
+#ifndef GGL_EMULATE
+static int sh_dims(ShDims &d, const ggl_segplan_t *plan, int64_t F, float slope, float p_drop, const int64_t *rng) {
+  GGL_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, GGL_EINVAL, "p_drop must be in [0, 1)");
+  GGL_REQUIRE(p_drop == 0.0f || rng, GGL_EINVAL, "attention dropout needs an rng_state");
+  d.slope = slope; d.N = plan->N; d.F = F; d.E = plan->E;
+  d.chunk = plan->chunk; d.n_long = plan->n_long; d.n_chunks = plan->n_long > 0 ? plan->n_chunks : 0;
+  d.drop_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
+  d.drop_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  if (plan->n_long > 0)
+    GGL_REQUIRE(plan->long_rows && plan->chunk_ptr && plan->partial, GGL_EWORKSPACE,
+                "plan has long rows but long_rows/chunk_ptr/partial is NULL");
+  return GGL_OK;
+}
+#endif
+
+// A[N,8,F] = sum_j alpha_ijh x[j,:] (normalised), den[N,8], rowmax[N,8]; x[N_src,F], el[N_src,8], er[N,8]
+extern "C" int ggl_gat_sh_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el, const float *er,
+                              const float *x, int64_t F, float slope, float p_drop, int64_t *rng_state,
+                              float *rowmax, float *A, float *den, void *stream) {
+#ifdef GGL_EMULATE
+  (void)plan; (void)col; (void)el; (void)er; (void)x; (void)F; (void)slope; (void)p_drop; (void)rng_state;
+  (void)rowmax; (void)A; (void)den; (void)stream;
+  set_error("the shared-row GAT path needs the GPU build");
+  return GGL_EINVAL;
+#else
+  GGL_REQUIRE(plan && plan->rowptr && plan->chunk > 0, GGL_EINVAL, "plan is NULL");
+  GGL_REQUIRE(ggl_gat_sh_supported(8, F, 1), GGL_EINVAL, "row width not supported by the shared-row GAT path");
+  if (plan->N == 0) return GGL_OK;
+  GGL_REQUIRE(er && rowmax && A && den, GGL_EINVAL, "NULL pointer");
+  GGL_REQUIRE((col && el && x) || plan->E == 0, GGL_EINVAL, "NULL pointer");
+  ShDims d{};
+  int rc = sh_dims(d, plan, F, slope, p_drop, rng_state);
+  if (rc) return rc;
+  float *pacc = nullptr, *pden = nullptr, *pmax = nullptr;
+  if (plan->n_long > 0) {
+    pacc = static_cast<float *>(plan->partial);
+    pden = pacc + plan->n_chunks * 8 * F;
+    pmax = pden + plan->n_chunks * 8;
+  }
+  GGL_REQUIRE(al16(x) && al16(A) && al16(pacc) && al16(col), GGL_EINVAL, "shared-row GAT path needs 16-byte aligned buffers");
+  hipStream_t s = as_stream(stream);
+  const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
+  GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+  const int32_t *order = options().row_order ? plan->row_order : nullptr;
+  GGL_LAUNCH((gat_sh_rowmax_kernel), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows, plan->chunk_ptr, el,
+             er, rowmax, pmax, d);
+  GGL_LAUNCH_CHECK();
+  if (plan->n_long > 0) {
+    GGL_LAUNCH((gat_sh_rowmax_final_kernel), grid_for(plan->n_long * 8), kBlock, s, plan->long_rows, plan->chunk_ptr,
+               (const float *)pmax, rowmax, plan->n_long);
+    GGL_LAUNCH_CHECK();
+  }
+  if (d.drop_thresh)
+    GGL_LAUNCH((gat_sh_fwd_kernel<true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows, plan->chunk_ptr,
+               el, er, (const float *)rowmax, x, A, den, pacc, pden, (const int64_t *)rng_state, d);
+  else
+    GGL_LAUNCH((gat_sh_fwd_kernel<false>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows, plan->chunk_ptr,
+               el, er, (const float *)rowmax, x, A, den, pacc, pden, (const int64_t *)rng_state, d);
+  GGL_LAUNCH_CHECK();
+  if (plan->n_long > 0) {
+    GGL_LAUNCH((gat_sh_fwd_final_kernel), plan->n_long, kBlock, s, plan->long_rows, plan->chunk_ptr, (const float *)pacc,
+               (const float *)pden, A, den, plan->n_long, F);
+    GGL_LAUNCH_CHECK();
+  }
+  if (d.drop_thresh) return rng_advance(rng_state, stream);
+  return GGL_OK;
+#endif
+}
+
+// destination walk (ger) then source walk (T, gel).  G[N,8,F] = dL/dA, stats[N,8,4] = {er, m, 1/(den+1e-16),
+// <G_ih, A_ih>}, z[N_src,8,Cp] = the rows' own transformed features, gy[N,Cp] = the per-row output gradient the
+// head mean spreads over the heads (dL/dA_ih = gy_i W_h^T), Cp <= 64 a multiple of 4.
+extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, const ggl_segplan_t *planT,
+                              const int32_t *colT, const int32_t *posT, const float *el, const float *x, int64_t F,
+                              const float *G, const float *stats, const float *z, const float *gy, int64_t Cp,
+                              float slope, float p_drop, const int64_t *rng_used, float *ger, float *T, float *gel,
+                              void *stream) {
+#ifdef GGL_EMULATE
+  (void)plan; (void)col; (void)planT; (void)colT; (void)posT; (void)el; (void)x; (void)F; (void)G; (void)stats; (void)z;
+  (void)gy; (void)Cp; (void)slope; (void)p_drop; (void)rng_used; (void)ger; (void)T; (void)gel; (void)stream;
+  set_error("the shared-row GAT path needs the GPU build");
+  return GGL_EINVAL;
+#else
+  GGL_REQUIRE(plan && plan->rowptr && planT && planT->rowptr && plan->chunk > 0 && planT->chunk > 0, GGL_EINVAL, "plan is NULL");
+  GGL_REQUIRE(ggl_gat_sh_supported(8, F, Cp) && Cp % 4 == 0, GGL_EINVAL, "shape not supported by the shared-row GAT path");
+  GGL_REQUIRE(planT->E == plan->E, GGL_EINVAL, "forward and transposed plans disagree");
+  GGL_REQUIRE(p_drop == 0.0f || posT || plan->E == 0, GGL_EINVAL, "attention dropout needs posT");
+  hipStream_t s = as_stream(stream);
+  if (plan->N > 0) {
+    GGL_REQUIRE(ger && G && stats && el && x, GGL_EINVAL, "NULL pointer");
+    ShDims d{};
+    int rc = sh_dims(d, plan, F, slope, p_drop, rng_used);
+    if (rc) return rc;
+    float *pger = plan->n_long > 0 ? static_cast<float *>(plan->partial) : nullptr;
+    GGL_REQUIRE(al16(x) && al16(G) && al16(stats) && al16(col), GGL_EINVAL, "shared-row GAT path needs 16-byte aligned buffers");
+    const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
+    GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+    const int32_t *order = options().row_order ? plan->row_order : nullptr;
+    if (d.drop_thresh)
+      GGL_LAUNCH((gat_sh_bwd_dst_kernel<true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                 plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+    else
+      GGL_LAUNCH((gat_sh_bwd_dst_kernel<false>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                 plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+    GGL_LAUNCH_CHECK();
+    if (plan->n_long > 0) {
+      GGL_LAUNCH((gat_bwd_dst_final_kernel), grid_for(plan->n_long * 8), kBlock, s, plan->long_rows, plan->chunk_ptr,
+                 (const float *)pger, ger, plan->n_long, (int64_t)8);
+      GGL_LAUNCH_CHECK();
+    }
+  }
+  if (planT->N > 0) {
+    GGL_REQUIRE(T && gel && z && gy && stats && el, GGL_EINVAL, "NULL pointer");
+    ShDims d{};
+    int rc = sh_dims(d, planT, Cp, slope, p_drop, rng_used);
+    if (rc) return rc;
+    float *pacc = nullptr, *pgel = nullptr;
+    if (planT->n_long > 0) {
+      pacc = static_cast<float *>(planT->partial);
+      pgel = pacc + planT->n_chunks * 8 * Cp;
+    }
+    GGL_REQUIRE(al16(z) && al16(gy) && al16(T) && al16(pacc) && al16(colT), GGL_EINVAL, "shared-row GAT path needs 16-byte aligned buffers");
+    const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
+    GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
+    const int32_t *order = options().row_order ? planT->row_order : nullptr;
+    if (d.drop_thresh)
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    else
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<false>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    GGL_LAUNCH_CHECK();
+    if (planT->n_long > 0) {
+      GatDims gd{};
+      gd.H = 8; gd.K = 8 * Cp; gd.n_long = planT->n_long;
+      GGL_LAUNCH((gat_bwd_src_final_kernel), planT->n_long, kBlock, s, planT->long_rows, planT->chunk_ptr,
+                 (const float *)pacc, (const float *)pgel, T, gel, gd);
       GGL_LAUNCH_CHECK();
     }
   }

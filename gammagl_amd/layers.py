@@ -321,6 +321,14 @@ class FusedGATConv(GATConv):
 
     def forward(self, x, edge_index, num_nodes=None, **kwargs):
         H, C = self.heads, self.out_channels
+        eng = _engine()
+        if (not self.concat and x.dim() == 2 and x.dtype == torch.float32 and (num_nodes is None or num_nodes == x.shape[0])
+                and eng.gat_headmean_supported(H, x.shape[1], C)):
+            # a head-averaging layer whose input row (F floats) is narrower than its H x C transformed row: aggregate
+            # the input per head, transform afterwards (same math, 1408 B -> 256 B gathered per edge on the Reddit GAT)
+            y = eng.gat_headmean(edge_index, x, self.w, self.att, self.negative_slope, num_nodes=x.shape[0],
+                                 dropout_rate=self.dropout_rate, training=self.training)
+            return y + self.bias if self.bias is not None else y
         w = self.w
         pad = (-C) % 4 if C >= 8 else 0
         if pad:  # e.g. 41 classes per head: 44 channels inside the GEMM keep the kernels on 16-byte slices

@@ -962,6 +962,84 @@ class Engine:
                                                                eng._stream(ga.device)))
                 return gx, None, None, None, (ga if ctx.has_add else None), gb, None
 
+        class GATHeadMean(torch.autograd.Function):
+            """y_i = 1/H sum_h sum_j alpha_ijh (x_j W_h) for a head-averaging GAT layer (gat_conv.py:98-122 with
+            concat=False), aggregated BEFORE it is transformed: y_i = 1/H (sum_j alpha_ijh x_j) W_h, logits from
+            el = x (W a_src), er = x (W a_dst).  The three walks gather the F-float input row / the C-float output
+            gradient instead of the H x C transformed row (gat.hip, ggl_gat_sh_*); everything dense runs as GEMMs."""
+
+            @staticmethod
+            def forward(ctx, gp, x, W, att, slope, p_drop):
+                dev = x.device
+                N, F = int(x.shape[0]), int(x.shape[1])
+                H = 8
+                C = int(W.shape[1]) // H
+                Wr = W.view(F, H, C)
+                a_src, a_dst = att[0, :, :C], att[0, :, C:]
+                U, V = (Wr * a_src).sum(-1), (Wr * a_dst).sum(-1)           # [F, H]
+                el, er = (x @ U).contiguous(), (x @ V).contiguous()         # [N, H]
+                rowmax = torch.empty((N, H), dtype=torch.float32, device=dev)
+                den = torch.empty((N, H), dtype=torch.float32, device=dev)
+                A = torch.empty((N, H, F), dtype=torch.float32, device=dev)
+                part = None
+                if gp.fwd.n_long > 0:
+                    part = torch.empty(eng.lib.ggl_gat_sh_partial_bytes(gp.fwd.n_chunks, F) + 16, dtype=torch.uint8,
+                                       device=dev)
+                cs = gp.fwd.c_struct(part)
+                rng = rng_used = None
+                if p_drop > 0:
+                    rng = eng._rng_state(dev)
+                    rng_used = rng.clone()
+                eng._check(eng.lib.ggl_gat_sh_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er), _ptr(x), F,
+                                                  float(slope), float(p_drop), _ptr(rng), _ptr(rowmax), _ptr(A),
+                                                  _ptr(den), eng._stream(dev)))
+                Wst = Wr.permute(1, 0, 2).reshape(H * F, C)
+                y = (A.view(N, H * F) @ Wst) / H
+                ctx.gp, ctx.slope, ctx.p_drop, ctx.rng_used = gp, float(slope), float(p_drop), rng_used
+                ctx.save_for_backward(x, W, att, el, er, rowmax, den, A)
+                return y
+
+            @staticmethod
+            def backward(ctx, gy):
+                gp = ctx.gp
+                x, W, att, el, er, rowmax, den, A = ctx.saved_tensors
+                dev = gy.device
+                N, F = int(x.shape[0]), int(x.shape[1])
+                H = 8
+                C = int(W.shape[1]) // H
+                Cp = C + (-C) % 4
+                Wr = W.view(F, H, C)
+                a_src, a_dst = att[0, :, :C], att[0, :, C:]
+                U, V = (Wr * a_src).sum(-1), (Wr * a_dst).sum(-1)
+                Wst = Wr.permute(1, 0, 2).reshape(H * F, C)
+                gyh = gy.contiguous() / H
+                gyp = torch.nn.functional.pad(gyh, (0, Cp - C)).contiguous()
+                G = (gyh @ Wst.t()).view(N, H, F).contiguous()               # dL/dA
+                stats = torch.stack([er, rowmax, 1.0 / (den + 1e-16), (G * A).sum(-1)], dim=-1).contiguous()
+                z = torch.nn.functional.pad((x @ W).view(N, H, C), (0, Cp - C)).contiguous()
+                ger = torch.empty((N, H), dtype=torch.float32, device=dev)
+                gel = torch.empty((N, H), dtype=torch.float32, device=dev)
+                T = torch.empty((N, H, Cp), dtype=torch.float32, device=dev)
+                bwd = gp.bwd
+                part_f = eng._partial(gp.fwd, torch.float32, H, False, dev)
+                part_t = None
+                if bwd.n_long > 0:
+                    part_t = torch.empty(eng.lib.ggl_gat_sh_partial_bytes(bwd.n_chunks, Cp) + 16, dtype=torch.uint8,
+                                         device=dev)
+                cs, csT = gp.fwd.c_struct(part_f), bwd.c_struct(part_t)
+                posT = gp.posT if ctx.p_drop > 0 else None
+                eng._check(eng.lib.ggl_gat_sh_bwd(ctypes.byref(cs), _ptr(gp.col), ctypes.byref(csT), _ptr(gp.colT),
+                                                  _ptr(posT), _ptr(el), _ptr(x), F, _ptr(G), _ptr(stats), _ptr(z),
+                                                  _ptr(gyp), Cp, ctx.slope, ctx.p_drop, _ptr(ctx.rng_used), _ptr(ger),
+                                                  _ptr(T), _ptr(gel), eng._stream(dev)))
+                gx = torch.einsum("nhc,fhc->nf", T[:, :, :C], Wr) + gel @ U.t() + ger @ V.t()
+                gU, gV = x.t() @ gel, x.t() @ ger                           # [F, H]
+                gW = (A.view(N, H * F).t() @ gyh).view(H, F, C).permute(1, 0, 2) \
+                    + gU.unsqueeze(-1) * a_src + gV.unsqueeze(-1) * a_dst
+                gatt = torch.cat([torch.einsum("fh,fhc->hc", gU, Wr), torch.einsum("fh,fhc->hc", gV, Wr)], dim=-1)
+                return None, gx, gW.reshape(F, H * C), gatt.unsqueeze(0), None, None
+
+        self.GATHeadMean = GATHeadMean
         class BlockMeanEpi(torch.autograd.Function):
             """relu(mean_{j in block row i} x[j] + add_i + bias) over a sampler Block (static capacities,
             device-side sizes): forward = the rectangular SpMM-mean with the epilogue in its store; backward
@@ -1182,6 +1260,22 @@ class Engine:
         if add is not None and tuple(add.shape) != (N, msg.shape[1]):
             raise RuntimeError("add must be [num_segments, feature width]")
         return self.SegmentEpi.apply(msg, ids, N, reduce == "mean", add, bias, bool(relu))
+
+    def gat_headmean_supported(self, heads, in_channels, out_channels):
+        return bool(self.gat_fast and self.lib.ggl_gat_sh_supported(int(heads), int(in_channels), int(out_channels)))
+
+    def gat_headmean(self, index, x, W, att, negative_slope=0.2, num_nodes=None, dropout_rate=0.0, training=True):
+        """mean over the 8 heads of a GAT layer's output (before the bias): [N, C] from x [N, F], W [F, 8 C],
+        att [1, 8, 2 C] — the layer aggregated before it is transformed (see GATHeadMean)."""
+        self._dev(index, x, W, att)
+        for n, t in (("x", x), ("W", W), ("att", att)):
+            self._check_f32(n, t)
+        n = x.shape[0] if num_nodes is None else int(num_nodes)
+        if n != x.shape[0]:
+            raise RuntimeError("gat_headmean runs on square graphs (every destination is also a source row)")
+        gp = index if isinstance(index, GraphPlan) else self.graph_plan(index, n, n)
+        p = float(dropout_rate) if training else 0.0
+        return self.GATHeadMean.apply(gp, x.contiguous(), W.contiguous(), att.contiguous(), negative_slope, p)
 
     def block_mean_epi(self, x, blk, add=None, bias=None, relu=False):
         """SAGEConv(mean) over a sampler Block: relu(mean of the sampled neighbours + add + bias), one kernel."""

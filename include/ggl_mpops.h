@@ -337,6 +337,27 @@ int ggl_gat_fast_bwd(const ggl_segplan_t *plan, const int32_t *col, const ggl_se
                      const float *x, const float *g, const float *out, const float *rowmax,
                      const float *rowden, float slope, int64_t H, int64_t C, float p_drop,
                      const int64_t *rng_used, float *stats, float *gx, float *gel, float *ger, void *stream);
+/* Head-mean GAT layer aggregated BEFORE it is transformed (the output layer of models/gat.py: concat=False,
+ * gat_conv.py:114-122): y_i = 1/H sum_h (sum_j alpha_ijh x_j) W_h, so the per-edge gather is the F-float INPUT row
+ * shared by all heads instead of the H x C transformed row (Reddit GAT: 256 B instead of 1408 B), and in the
+ * backward the source walk gathers the C-float output gradient g_i (dL/dA_ih = g_i W_h^T / H).  H = 8, F and the
+ * padded class width Cp <= 64 (multiples of 4): ggl_gat_sh_supported.  GPU build only (DPP row broadcasts and a
+ * 16-lane reduce-scatter); parity bar as for the fused GAT op (1e-5 / 1e-4 relative).
+ *   ggl_gat_sh_fwd : rowmax[N,8], A[N,8,F] = sum_j alpha_ijh x_j, den[N,8]; plan->partial =
+ *                    ggl_gat_sh_partial_bytes(n_chunks, F) when the plan has long rows
+ *   ggl_gat_sh_bwd : ger[N,8] (destination walk: G[N,8,F] = dL/dA and stats[N,8,4] = {er, m, 1/(den+1e-16),
+ *                    <G_ih, A_ih>} per row, x gathered) and T[N_src,8,Cp] = sum_i alpha_ijh gy_i, gel[N_src,8]
+ *                    (source walk: z[N_src,8,Cp] = the rows' own x_j W_h, gy[N,Cp] gathered); partial buffers:
+ *                    plan->partial >= n_chunks * 8 floats, planT->partial = ggl_gat_sh_partial_bytes(n_chunksT, Cp) */
+int ggl_gat_sh_supported(int64_t H, int64_t F, int64_t C);
+size_t ggl_gat_sh_partial_bytes(int64_t n_chunks, int64_t F);
+int ggl_gat_sh_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el, const float *er, const float *x,
+                   int64_t F, float slope, float p_drop, int64_t *rng_state, float *rowmax, float *A, float *den,
+                   void *stream);
+int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, const ggl_segplan_t *planT, const int32_t *colT,
+                   const int32_t *posT, const float *el, const float *x, int64_t F, const float *G,
+                   const float *stats, const float *z, const float *gy, int64_t Cp, float slope, float p_drop,
+                   const int64_t *rng_used, float *ger, float *T, float *gel, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Uniform neighbour sampling — supersedes ops/sparse sample_adj

@@ -99,6 +99,38 @@ def test_reddit_size_fused_gat(eng, dev, reddit, H, C):
         assert C == 41
 
 
+def test_reddit_size_gat_output_layer_headmean(eng, dev, reddit):
+    """Config 3's OUTPUT layer at full size (64 hidden -> 8 heads x 41 classes, heads averaged): the
+    aggregate-then-transform path == the transform-then-aggregate kernels, output and every gradient."""
+    if not _big(dev):
+        pytest.skip("needs > 100 GB of HBM")
+    from gammagl_amd import layers
+
+    ei, N = reddit
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(N, 64, generator=g, device=dev)
+    go = torch.randn(N, 41, generator=g, device=dev)
+    torch.manual_seed(0)
+    fg = layers.FusedGATConv(64, 41, heads=8, concat=False).to(dev)
+    assert eng.gat_headmean_supported(8, 64, 41)
+    res = []
+    try:
+        for fast in (True, False):
+            eng.gat_fast = fast
+            for p_ in fg.parameters():
+                p_.grad = None
+            xa = x.clone().requires_grad_(True)
+            y = fg(xa, ei, N)
+            y.backward(go)
+            res.append([y.detach(), xa.grad, fg.w.grad.clone(), fg.att.grad.clone()])
+    finally:
+        eng.gat_fast = True
+    for a, b, nm in zip(res[0], res[1], ("y", "gx", "gW", "gatt")):
+        tol = 3e-4 * float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= tol, (nm, float((a - b).abs().max()), tol)
+    assert bool(torch.isfinite(res[0][0]).all())
+
+
 def test_products_size_sampler_and_sage_blocks(eng, dev):
     """Config 4 at full size: NeighborSampler([25, 10]) over the products-sized CSR, 2048 seeds — block structure
     invariants, every block edge is a real edge between the right nodes, the block aggregate straight from the

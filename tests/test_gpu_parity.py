@@ -663,3 +663,67 @@ def test_minibatch_step_captures_into_one_hipgraph(eng, dev):
     assert bool((bs._first_pos == (1 << 62)).all()) and bs.overflow_count() == 0
     # eager step on the same trainer still works after capture (same code path, no graph)
     assert bool(torch.isfinite(tr.step(x, y, seeds)))
+
+
+def test_gat_headmean_layer_aggregate_then_transform(eng, dev):
+    """The head-averaging GAT layer aggregated before it is transformed (ggl_gat_sh_*: shared input row, DPP row
+    broadcasts, 16-lane reduce-scatter) == the same layer on the transform-then-aggregate kernels == the unfused
+    GATConv class: output and the gradients of x, W, att — short rows, hub rows on the chunk path, attention dropout
+    (both paths index the keep bit by (sorted position, head): same mask for the same rng state)."""
+    from gammagl_amd import layers
+
+    g = torch.Generator().manual_seed(11)
+    old = eng.chunk
+    try:
+        for chunk in (0, 16):
+            eng.chunk = chunk
+            eng.clear_caches()
+            for (N, E, F, C) in ((50, 600, 16, 5), (120, 2500, 64, 41), (33, 0, 8, 3), (64, 900, 60, 64)):
+                ei = torch.randint(0, N, (2, E), generator=g)
+                if E:
+                    ei[1, : E // 3] = 3                                   # a hub row (chunked when chunk = 16)
+                ei = layers.add_self_loops(ei.to(dev), N) if E else ei.to(dev)
+                x = torch.randn(N, F, generator=g).to(dev)
+                go = torch.randn(N, C, generator=g).to(dev)
+                fg = layers.FusedGATConv(F, C, heads=8, concat=False).to(dev)
+                ug = layers.GATConv(F, C, heads=8, concat=False).to(dev)
+                ug.load_state_dict(fg.state_dict())
+                assert eng.gat_headmean_supported(8, F, C)
+                res = []
+                for mode in ("headmean", "transform-first", "unfused"):
+                    eng.gat_fast = mode == "headmean"
+                    layer = ug if mode == "unfused" else fg
+                    for p_ in layer.parameters():
+                        p_.grad = None
+                    xa = x.clone().requires_grad_(True)
+                    y = layer(xa, ei, N)
+                    y.backward(go)
+                    res.append([y.detach(), xa.grad, layer.w.grad.clone(), layer.att.grad.clone(), layer.bias.grad.clone()])
+                eng.gat_fast = True
+                for other in res[1:]:
+                    for a, b, nm in zip(res[0], other, ("y", "gx", "gW", "gatt", "gbias")):
+                        tol = 2e-4 * float(b.abs().max()) + 1e-6
+                        assert float((a - b).abs().max()) <= tol, (chunk, N, E, F, C, nm, float((a - b).abs().max()), tol)
+                if E:                                                     # attention dropout: same mask in both fused paths
+                    fg.dropout_rate = 0.5
+                    fg.train()
+                    outs = []
+                    for fast in (True, False):
+                        eng.gat_fast = fast
+                        eng.reseed(123)
+                        eng._rng_state(dev)
+                        for p_ in fg.parameters():
+                            p_.grad = None
+                        xa = x.clone().requires_grad_(True)
+                        y = fg(xa, ei, N)
+                        y.backward(go)
+                        outs.append([y.detach(), xa.grad, fg.w.grad.clone(), fg.att.grad.clone()])
+                    eng.gat_fast = True
+                    for a, b, nm in zip(outs[0], outs[1], ("y", "gx", "gW", "gatt")):
+                        tol = 2e-4 * float(b.abs().max()) + 1e-6
+                        assert float((a - b).abs().max()) <= tol, ("dropout", chunk, N, F, C, nm, float((a - b).abs().max()), tol)
+                    assert not torch.equal(outs[0][0], res[0][0])         # dropout really dropped something
+    finally:
+        eng.chunk = old
+        eng.gat_fast = True
+        eng.clear_caches()
