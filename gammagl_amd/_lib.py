@@ -88,11 +88,11 @@ SIGNATURES = {
     "ggl_gat_sh_fwd": (c_int, [_P, _V, _V, _V, _V, c_int64, c_float, c_float, _V, _V, _V, _V, _V]),
     "ggl_gat_sh_bwd": (c_int, [_P, _V, _P, _V, _V, _V, _V, c_int64, _V, _V, _V, _V, c_int64, c_float, c_float, _V,
                                _V, _V, _V, _V]),
-    "ggl_sample_count": (c_int, [_V, _V, c_int64, c_int64, c_int, _V, _V]),
+    "ggl_sample_count": (c_int, [_V, _V, c_int64, c_int64, c_int64, c_int, _V, _V]),
     "ggl_sample_pick": (c_int, [_V, _V, _V, c_int64, c_int64, c_int, _V, _V, _V, _V, _V]),
     "ggl_sample_hop_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "ggl_sample_hop": (c_int, [_V, _V, _V, _V, c_int64, c_int64, c_int64, c_int64, _V, _V, _V, _V, _V, _V, _V, _V,
-                               c_size_t, _V]),
+    "ggl_sample_hop": (c_int, [_V, _V, _V, _V, c_int64, c_int64, c_int64, c_int64, c_int64, _V, _V, _V, _V, _V, _V, _V,
+                               _V, c_size_t, _V]),
     "ggl_block_transpose_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_block_transpose": (c_int, [_V, _V, c_int64, c_int64, c_int64, _V, _V, _V, c_size_t, _V]),
     "ggl_set_option": (c_int, [c_char_p, c_int64]),

@@ -50,14 +50,16 @@ __device__ __forceinline__ int64_t bounded(uint32_t r, int64_t n) {
   return (int64_t)(((uint64_t)r * (uint64_t)n) >> 32);
 }
 
+// A seed outside [0, N) is treated as a node without neighbours (no out-of-bounds read of rowptr); its id
+// stays in n_id, so the caller's feature gather x[n_id] reports it.
 __global__ __launch_bounds__(kBlock) void sample_count_kernel(const int64_t *__restrict__ rowptr,
                                                               const int64_t *__restrict__ seeds, int64_t B,
-                                                              int64_t fanout, int replace,
+                                                              int64_t N, int64_t fanout, int replace,
                                                               int64_t *__restrict__ out_deg) {
   const int64_t stride = grid_threads();
   for (int64_t i = thread_id(); i < B; i += stride) {
     const int64_t n = seeds[i];
-    const int64_t deg = rowptr[n + 1] - rowptr[n];
+    const int64_t deg = (n >= 0 && n < N) ? rowptr[n + 1] - rowptr[n] : 0;
     int64_t k;
     if (fanout < 0) k = deg;
     else if (replace) k = deg > 0 ? fanout : 0;
@@ -80,9 +82,10 @@ __global__ __launch_bounds__(kBlock) void sample_pick_kernel(const int64_t *__re
   const uint64_t seed = (uint64_t)rng[0], offset = (uint64_t)rng[1];
   const int64_t stride = grid_threads();
   for (int64_t i = thread_id(); i < B; i += stride) {
+    const int64_t o = out_rowptr[i], k = out_rowptr[i + 1] - o;
+    if (k == 0) continue;  // (also every out-of-range seed: the count kernel gave it no neighbours)
     const int64_t n = seeds[i];
     const int64_t beg = rowptr[n], deg = rowptr[n + 1] - beg;
-    const int64_t o = out_rowptr[i], k = out_rowptr[i + 1] - o;
     if (fanout < 0 || (!replace && deg <= fanout)) {
       continue;  // the whole neighbourhood, in CSR order: sample_emit_kernel
     } else if (replace) {
@@ -153,14 +156,14 @@ constexpr long long kBigPos = (long long)1 << 62;
 __global__ __launch_bounds__(kBlock) void hop_count_kernel(const int64_t *__restrict__ rowptr,
                                                            const int64_t *__restrict__ seeds,
                                                            const int64_t *__restrict__ n_seeds, int64_t B_cap,
-                                                           int64_t fanout, int64_t *__restrict__ cnt) {
+                                                           int64_t N, int64_t fanout, int64_t *__restrict__ cnt) {
   const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
   const int64_t stride = grid_threads();
   for (int64_t i = thread_id(); i <= B_cap; i += stride) {
     int64_t k = 0;
     if (i < nb) {
       const int64_t s = seeds[i];
-      const int64_t deg = rowptr[s + 1] - rowptr[s];
+      const int64_t deg = (s >= 0 && s < N) ? rowptr[s + 1] - rowptr[s] : 0;  // out-of-range seed: no neighbours
       k = deg < fanout ? deg : fanout;
     }
     cnt[i] = k;  // cnt[B_cap] = 0: the exclusive scan leaves the total there
@@ -179,9 +182,10 @@ __global__ __launch_bounds__(kBlock) void hop_pick_kernel(const int64_t *__restr
   const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
   const int64_t stride = grid_threads();
   for (int64_t i = thread_id(); i < nb; i += stride) {
+    const int64_t o = out_rowptr[i], k = out_rowptr[i + 1] - o;
+    if (k == 0) continue;
     const int64_t n = seeds[i];
     const int64_t beg = rowptr[n], deg = rowptr[n + 1] - beg;
-    const int64_t o = out_rowptr[i], k = out_rowptr[i + 1] - o;
     if (deg <= fanout) {
       for (int64_t j = 0; j < k; ++j) e_pos[o + j] = beg + j;
     } else {
@@ -202,14 +206,18 @@ __global__ __launch_bounds__(kBlock) void hop_pick_kernel(const int64_t *__restr
 __global__ __launch_bounds__(kBlock) void hop_mark_kernel(const int64_t *__restrict__ seeds,
                                                           const int64_t *__restrict__ n_seeds, int64_t B_cap,
                                                           const int64_t *__restrict__ nbr,
-                                                          const int64_t *__restrict__ out_rowptr,
+                                                          const int64_t *__restrict__ out_rowptr, int64_t N,
                                                           long long *__restrict__ first_pos) {
   const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
   const int64_t ne = out_rowptr[B_cap];
   const int64_t stride = grid_threads();
   for (int64_t t = thread_id(); t < nb + ne; t += stride) {
-    if (t < nb) atomicMin(&first_pos[seeds[t]], -(long long)(t + 1));
-    else atomicMin(&first_pos[nbr[t - nb]], (long long)(B_cap + (t - nb)));
+    if (t < nb) {
+      const int64_t sd = seeds[t];
+      if (sd >= 0 && sd < N) atomicMin(&first_pos[sd], -(long long)(t + 1));
+    } else {
+      atomicMin(&first_pos[nbr[t - nb]], (long long)(B_cap + (t - nb)));
+    }
   }
 }
 
@@ -293,12 +301,15 @@ __global__ void hop_clamp_last_kernel(int64_t *__restrict__ out_rowptr, int64_t 
 __global__ __launch_bounds__(kBlock) void hop_reset_kernel(const int64_t *__restrict__ seeds,
                                                            const int64_t *__restrict__ n_seeds, int64_t B_cap,
                                                            const int64_t *__restrict__ nbr,
-                                                           const int64_t *__restrict__ out_rowptr,
+                                                           const int64_t *__restrict__ out_rowptr, int64_t N,
                                                            long long *__restrict__ first_pos) {
   const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
   const int64_t ne = out_rowptr[B_cap];
   const int64_t stride = grid_threads();
-  for (int64_t t = thread_id(); t < nb + ne; t += stride) first_pos[t < nb ? seeds[t] : nbr[t - nb]] = kBigPos;
+  for (int64_t t = thread_id(); t < nb + ne; t += stride) {
+    const int64_t node = t < nb ? seeds[t] : nbr[t - nb];
+    if (node >= 0 && node < N) first_pos[node] = kBigPos;
+  }
 }
 
 // thread per row: columns ascending by local id (sample.cpp:112-118), e_pos carried along; rows hold <= fanout
@@ -407,12 +418,12 @@ static int scan_i64(void *tmp, size_t tmp_bytes, const int64_t *in, int64_t *out
 
 using namespace ggl;
 
-extern "C" int ggl_sample_count(const int64_t *rowptr, const int64_t *seeds, int64_t B, int64_t fanout,
-                                int replace, int64_t *out_deg, void *stream) {
-  GGL_REQUIRE(B >= 0, GGL_EINVAL, "negative batch");
+extern "C" int ggl_sample_count(const int64_t *rowptr, const int64_t *seeds, int64_t B, int64_t num_nodes,
+                                int64_t fanout, int replace, int64_t *out_deg, void *stream) {
+  GGL_REQUIRE(B >= 0 && num_nodes >= 0, GGL_EINVAL, "negative size");
   if (B == 0) return GGL_OK;
   GGL_REQUIRE(rowptr && seeds && out_deg, GGL_EINVAL, "NULL pointer");
-  GGL_LAUNCH((sample_count_kernel), grid_for(B), kBlock, as_stream(stream), rowptr, seeds, B, fanout,
+  GGL_LAUNCH((sample_count_kernel), grid_for(B), kBlock, as_stream(stream), rowptr, seeds, B, num_nodes, fanout,
              replace, out_deg);
   GGL_LAUNCH_CHECK();
   return GGL_OK;
@@ -457,8 +468,8 @@ extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t E_cap) {
 }
 
 extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds,
-                              const int64_t *n_seeds_dev, int64_t B_cap, int64_t fanout, int64_t E_cap,
-                              int64_t S_cap, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
+                              const int64_t *n_seeds_dev, int64_t B_cap, int64_t num_nodes, int64_t fanout,
+                              int64_t E_cap, int64_t S_cap, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
                               int32_t *out_col, int64_t *out_eid, int64_t *out_nid, int64_t *out_counts,
                               void *workspace, size_t workspace_bytes, void *stream) {
   GGL_REQUIRE(B_cap >= 0 && fanout > 0, GGL_EINVAL, "the static-shape hop needs a positive fan-out");
@@ -483,7 +494,8 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   void *tmp = ws + off;
   const size_t tmp_bytes = workspace_bytes - off;
   long long *fp = reinterpret_cast<long long *>(first_pos);
-  GGL_LAUNCH((hop_count_kernel), grid_for(B_cap + 1), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap, fanout, cnt);
+  GGL_LAUNCH((hop_count_kernel), grid_for(B_cap + 1), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap, num_nodes, fanout,
+             cnt);
   GGL_LAUNCH_CHECK();
   int rc = scan_i64(tmp, tmp_bytes, cnt, out_rowptr, B_cap + 1, s);
   if (rc) return rc;
@@ -495,7 +507,7 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
              (const int64_t *)out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_mark_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
-             (const int64_t *)out_rowptr, fp);
+             (const int64_t *)out_rowptr, num_nodes, fp);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_flag_kernel), grid_for(T), kBlock, s, n_seeds_dev, B_cap, E_cap, (const int64_t *)nbr,
              (const int64_t *)out_rowptr, (const long long *)fp, flag);
@@ -507,7 +519,7 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
              (const int64_t *)new_id, S_cap, out_nid, local, out_counts);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_reset_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
-             (const int64_t *)out_rowptr, fp);
+             (const int64_t *)out_rowptr, num_nodes, fp);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_rowsort_kernel), grid_for(B_cap), kBlock, s, (const int64_t *)out_rowptr, B_cap, E_cap, local, e_pos,
              out_col, out_eid);

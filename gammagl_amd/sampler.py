@@ -33,12 +33,12 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_p
     col = col.contiguous().to(torch.int64)
     idx = idx.contiguous().to(torch.int64).reshape(-1)
     B = int(idx.shape[0])
-    if B > 0:  # an out-of-range seed would be an out-of-bounds read of rowptr: device-side assert, no host sync
-        torch._assert_async(((idx >= 0) & (idx < rowptr.shape[0] - 1)).all())
     st = eng._stream(dev)
     deg = torch.empty(B, dtype=torch.int64, device=dev)
-    eng._check(eng.lib.ggl_sample_count(_ptr(rowptr), _ptr(idx), B, int(num_neighbors), int(bool(replace)),
-                                        _ptr(deg), st))
+    # (a seed outside [0, N) gets no neighbours inside the kernels — no out-of-bounds read — and stays in n_id,
+    #  where the caller's feature gather x[n_id] reports it)
+    eng._check(eng.lib.ggl_sample_count(_ptr(rowptr), _ptr(idx), B, int(rowptr.shape[0]) - 1, int(num_neighbors),
+                                        int(bool(replace)), _ptr(deg), st))
     out_rowptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
     torch.cumsum(deg, 0, out=out_rowptr[1:])
     E = int(out_rowptr[-1]) if B > 0 else 0  # the one host read of this hop
@@ -53,7 +53,7 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_p
     # order (:48-51).  Keys: seed i -> -(i + 1), sampled neighbour q -> B + q; the minimum key per node is the
     # last seed position if the node is a seed, else its first sampled occurrence.
     cat = torch.cat([idx, nbr])
-    key = torch.cat([-(torch.arange(B, device=dev) + 1), B + torch.arange(E, device=dev)])
+    key = torch.cat([torch.arange(-1, -B - 1, -1, device=dev), torch.arange(B, B + E, device=dev)])
     if first_pos is not None:
         first_pos.scatter_reduce_(0, cat, key, "amin", include_self=True)
         fp = first_pos[cat]
@@ -67,8 +67,8 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_p
     is_first[:B] = True
     new_id = torch.cumsum(is_first, 0) - 1                                  # ids in first-seen order
     out_n_id = cat[is_first]
-    fpn = fp[B:]
-    local = torch.where(fpn < 0, -fpn - 1, new_id[fpn.clamp(min=0)])
+    # key -> local id in one gather: keys >= 0 index new_id, a seed key -(i + 1) wraps to the tail, which holds i
+    local = torch.cat([new_id, torch.arange(B - 1, -1, -1, device=dev)])[fp[B:]]
     # every row's columns ascending by local id (sample.cpp:112-118)
     if E > 0:
         row = torch.repeat_interleave(torch.arange(B, device=dev), deg, output_size=E)  # size known: no sync
@@ -239,7 +239,6 @@ class BlockSampler:
         eng = self.eng
         dev = self.rowptr.device
         seeds = seeds.to(device=dev, dtype=torch.int64).contiguous().reshape(-1)
-        torch._assert_async(((seeds >= 0) & (seeds < self.num_nodes)).all())
         if n_seeds is None:
             n_seeds = torch.full((1,), seeds.shape[0], dtype=torch.int64, device=dev)
         st = eng._stream(dev)
@@ -256,8 +255,8 @@ class BlockSampler:
             counts = torch.zeros(3, dtype=torch.int64, device=dev)
             wsb = eng.lib.ggl_sample_hop_workspace_bytes(b_cap, e_cap)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            eng._check(eng.lib.ggl_sample_hop(_ptr(self.rowptr), _ptr(self.col), _ptr(cur), _ptr(n_cur), b_cap, f,
-                                              e_cap, s_cap, _ptr(eng._rng_state(dev)), _ptr(self._first_pos),
+            eng._check(eng.lib.ggl_sample_hop(_ptr(self.rowptr), _ptr(self.col), _ptr(cur), _ptr(n_cur), b_cap,
+                                              self.num_nodes, f, e_cap, s_cap, _ptr(eng._rng_state(dev)), _ptr(self._first_pos),
                                               _ptr(rowptr), _ptr(col), _ptr(e_pos), _ptr(nid), _ptr(counts), _ptr(ws),
                                               wsb, st))
             self._overflow += counts[2]

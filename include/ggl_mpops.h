@@ -368,7 +368,7 @@ int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, const ggl_segp
  *                     positions by Floyd's algorithm when !replace (sample.cpp:75-83); Philox4x32-10 on
  *                     rng_state = {seed, offset} (device int64[2], offset advanced after the launch).
  * ---------------------------------------------------------------------------------------------- */
-int ggl_sample_count(const int64_t *rowptr, const int64_t *seeds, int64_t B, int64_t fanout, int replace,
+int ggl_sample_count(const int64_t *rowptr, const int64_t *seeds, int64_t B, int64_t num_nodes, int64_t fanout, int replace,
                      int64_t *out_deg, void *stream);
 int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const int64_t *seeds, int64_t B,
                     int64_t fanout, int replace, const int64_t *out_rowptr, int64_t *rng_state,
@@ -387,7 +387,7 @@ int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const int64_t *se
  *   hit (rows cut at E_cap / nodes past S_cap dropped — memory-safe, but the block is incomplete). */
 size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t E_cap);
 int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds, const int64_t *n_seeds_dev,
-                   int64_t B_cap, int64_t fanout, int64_t E_cap, int64_t S_cap, int64_t *rng_state,
+                   int64_t B_cap, int64_t num_nodes, int64_t fanout, int64_t E_cap, int64_t S_cap, int64_t *rng_state,
                    int64_t *first_pos, int64_t *out_rowptr, int32_t *out_col, int64_t *out_eid, int64_t *out_nid,
                    int64_t *out_counts, void *workspace, size_t workspace_bytes, void *stream);
 /* CSC of such a block without a host read: rowptrT[N_src_cap + 1], dstT[E_cap] = destination rows of each source

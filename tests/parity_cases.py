@@ -1148,6 +1148,16 @@ def check_block_sampler(eng, dev, oracle):
         assert nn <= blk.n_src_cap and ne <= blk.e_cap and rp[-1] == ne and (np.diff(rp) >= 0).all()
         assert (to_np(blk.col) >= 0).all() and (to_np(blk.col) < blk.n_src_cap).all()
     assert any(int(to_np(b.counts)[2]) == 1 for b in blocks) and bool((bs._first_pos == sampler._BIG).all())
+    # (4c) a seed outside [0, N) is memory-safe: it gets no neighbours (no out-of-bounds read of rowptr or of the
+    # relabel scratch) and stays in n_id, where the caller's feature gather reports it
+    bad = to_t(np.array([7, N + 5, -1, 9], np.int64), dev)
+    n_idb, blocks_b, cb = bs.sample(bad)
+    bb = blocks_b[-1]                                             # the seeds' own block
+    rpb = to_np(bb.rowptr)
+    assert rpb[2] == rpb[1] and rpb[3] == rpb[2] and (to_np(bb.n_id)[:4] == to_np(bad)).all()
+    assert bool((bs._first_pos == sampler._BIG).all())
+    gotb = sampler.sample_adj(to_t(rowptr, dev), to_t(col, dev), bad, 3, eng=eng)
+    assert to_np(gotb[0])[2] == to_np(gotb[0])[1] and (to_np(gotb[2])[:4] == to_np(bad)).all()
     # (5) the model runs on blocks end to end (shapes by capacity, loss on the seed rows)
     bs = sampler.BlockSampler(eit, [5, 3], num_nodes=N, eng=eng)
     n_id, blocks, _ = bs.sample(to_t(sd, dev))
