@@ -99,13 +99,13 @@ __global__ void rng_advance_kernel(int64_t *rng, int64_t inc) {
 // backward + first stage of the bias gradient.  Same thread geometry as the forward; every lane keeps a
 // running column sum of the ga values it produces and writes it to partial[(block * groups + j), :];
 // ggl_colsum_f32 (backward.hip) then reduces the [P, K] partial matrix.
-template <int VEC>
+template <int VEC, int MASKED>
 __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__restrict__ g,
                                                               const float *__restrict__ y,
                                                               float *__restrict__ ga, int64_t N,
                                                               int64_t K, int64_t nblocks,
                                                               int64_t rows_per_block, int kp,
-                                                              int groups, int masked, float scale,
+                                                              int groups, float scale,
                                                               const int64_t *__restrict__ rng,
                                                               uint32_t drop_thresh,
                                                               float *__restrict__ partial) {
@@ -123,8 +123,9 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
     auto finish = [&](int64_t r, float (&gv)[VEC], const float (&yv)[VEC]) {
+      constexpr int masked = MASKED;  // compile-time: the common ReLU case carries no Philox code at all
       uint32_t rw[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-      if (rng) {  // the mask the forward drew: same word for vector (r, c)
+      if (MASKED == 3) {  // the mask the forward drew: same word for vector (r, c)
         const U4 u = philox4x32_10((uint64_t)(r * KVm + (c * VEC) / ev), (uint64_t)rng[1], (uint64_t)rng[0]);
         rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
         if (VEC == 1) rw[0] = rw[(c * VEC) % ev];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
 #pragma unroll
       for (int u = 0; u < kRowUnroll; ++u) {
         ldv<VEC>(g + (r + (int64_t)u * groups) * K + c * VEC, gv[u]);
-        if (masked && masked != 3) ldv<VEC>(y + (r + (int64_t)u * groups) * K + c * VEC, yv[u]);
+        if (MASKED == 1 || MASKED == 2) ldv<VEC>(y + (r + (int64_t)u * groups) * K + c * VEC, yv[u]);
         else yv[u][0] = 0.0f;
       }
 #pragma unroll
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_kernel(const float *__res
     for (; r < r1; r += groups) {
       float gv[VEC], yv[VEC];
       ldv<VEC>(g + r * K + c * VEC, gv);
-      if (masked && masked != 3) ldv<VEC>(y + r * K + c * VEC, yv);
+      if (MASKED == 1 || MASKED == 2) ldv<VEC>(y + r * K + c * VEC, yv);
       else yv[0] = 0.0f;
       finish(r, gv, yv);
     }
@@ -258,12 +259,15 @@ extern "C" int ggl_bias_act_bwd(const float *g, const float *y, int64_t N, int64
   const float scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
   hipStream_t s = as_stream(stream);
   float *partial = gbias ? static_cast<float *>(workspace) : nullptr;
-  if (vec4)
-    GGL_LAUNCH((bias_act_bwd_kernel<4>), blocks, kBlock, s, g, y, ga, N, K, blocks, rpb, kp, groups, masked, scale,
-               redraw ? rng_used : nullptr, thresh, partial);
-  else
-    GGL_LAUNCH((bias_act_bwd_kernel<1>), blocks, kBlock, s, g, y, ga, N, K, blocks, rpb, kp, groups, masked, scale,
-               redraw ? rng_used : nullptr, thresh, partial);
+#define GGL_BAB(V, M)                                                                                    \
+  GGL_LAUNCH((bias_act_bwd_kernel<V, M>), blocks, kBlock, s, g, y, ga, N, K, blocks, rpb, kp, groups, scale, \
+             redraw ? rng_used : nullptr, thresh, partial)
+  if (vec4) {
+    if (masked == 0) GGL_BAB(4, 0); else if (masked == 1) GGL_BAB(4, 1); else if (masked == 2) GGL_BAB(4, 2); else GGL_BAB(4, 3);
+  } else {
+    if (masked == 0) GGL_BAB(1, 0); else if (masked == 1) GGL_BAB(1, 1); else if (masked == 2) GGL_BAB(1, 2); else GGL_BAB(1, 3);
+  }
+#undef GGL_BAB
   GGL_LAUNCH_CHECK();
   if (gbias) {  // second stage: column sums of the [P, K] partial matrix
     const size_t part = bwd_partial_bytes(N, K);

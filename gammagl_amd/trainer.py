@@ -104,10 +104,13 @@ class SAGEBlockTrainer:
     whole step into one hipGraph that is replayed per batch with the seeds updated in place."""
 
     def __init__(self, sampler, in_feat, hid_feat, num_class, num_layers=2, drop_rate=0.0, lr=0.005, seed=0,
-                 device="cuda", capturable=None, caps=None):
+                 device="cuda", capturable=None, caps=None, group=None, world=1):
         """`caps`: block capacities from `sampler.calibrate(batch_size)` (default: the worst case, on which
-        every dense layer runs several times more padding than data); check `sampler.overflow_count()`."""
-        self.sampler, self.caps = sampler, caps
+        every dense layer runs several times more padding than data); check `sampler.overflow_count()`.
+        `world` > 1: replicas (BASELINE config 4's multi-GPU mode) — every rank samples its own seeds and the
+        weight gradients are averaged by one flat all-reduce per step; that step runs eagerly (the collective is
+        not recorded into the graph), `capture()` is for world == 1."""
+        self.sampler, self.caps, self.group, self.world = sampler, caps, group, int(world)
         torch.manual_seed(seed)
         self.net = GraphSAGESampleModel(in_feat, hid_feat, num_class, drop_rate, num_layers).to(device)
         cap = torch.device(device).type == "cuda" if capturable is None else capturable
@@ -121,11 +124,25 @@ class SAGEBlockTrainer:
         logits = self.net(x.index_select(0, n_id), blocks)
         loss = F.cross_entropy(logits[: seeds.shape[0]], y.index_select(0, seeds))
         loss.backward()
+        if self.world > 1:
+            import torch.distributed as dist
+
+            params = [p for p in self.net.parameters() if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat, group=self.group)
+            flat.div_(self.world)
+            o = 0
+            for p in params:
+                n = p.grad.numel()
+                p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                o += n
         self.opt.step()
         return loss.detach()
 
     def capture(self, x, y, seeds, warmup=3):
         """Record step(x, y, seeds) into a hipGraph.  Afterwards: seeds.copy_(new_batch); trainer.replay()."""
+        if self.world > 1:
+            raise RuntimeError("capture() records a single-replica step; with world > 1 call step() per batch")
         for p in self.net.parameters():
             p.grad = torch.zeros_like(p)
         self.graph = GraphedStep(lambda: self.step(x, y, seeds), warmup=warmup)
