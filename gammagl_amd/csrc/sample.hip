@@ -345,6 +345,112 @@ __global__ __launch_bounds__(kBlock) void hop_rowsort_kernel(const int64_t *__re
   }
 }
 
+
+// ---- register-resident variants for fan-outs <= 32 (the reference's [25, 10]) ---------------------------------
+// hop_pick_kernel walks Floyd's algorithm with its picks in global memory (an O(k^2) chain of dependent global
+// reads per thread: 46 us per hop on the products-sized graph) and hop_rowsort_kernel insertion-sorts rows in
+// global memory (61 us); with the row in registers both are a few microseconds: the random draws of Floyd's steps do
+// not depend on earlier picks (only the membership test does), and a 32-element bitonic network sorts a row.
+constexpr int kRegF = 32;
+
+__global__ __launch_bounds__(kBlock) void hop_pick_reg_kernel(const int64_t *__restrict__ rowptr,
+                                                              const int64_t *__restrict__ col,
+                                                              const int64_t *__restrict__ seeds,
+                                                              const int64_t *__restrict__ n_seeds, int64_t B_cap,
+                                                              int64_t fanout, const int64_t *__restrict__ out_rowptr,
+                                                              const int64_t *__restrict__ rng, int64_t *__restrict__ e_pos,
+                                                              int64_t *__restrict__ nbr) {
+  const uint64_t seed = (uint64_t)rng[0], offset = (uint64_t)rng[1];
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < nb; i += stride) {
+    const int64_t o = out_rowptr[i];
+    const int k = (int)(out_rowptr[i + 1] - o);
+    if (k == 0) continue;
+    const int64_t n = seeds[i];
+    const int64_t beg = rowptr[n], deg = rowptr[n + 1] - beg;
+    int64_t pk[kRegF];
+    if (deg <= fanout) {
+#pragma unroll
+      for (int s = 0; s < kRegF; ++s) pk[s] = s;
+    } else {
+      const int64_t j0 = deg - k;
+#pragma unroll
+      for (int s = 0; s < kRegF; ++s)  // the draws are independent of the earlier picks
+        pk[s] = s < k ? bounded(philox_u32((uint64_t)i, (uint64_t)s, seed, offset), j0 + s + 1) : -1 - s;
+#pragma unroll
+      for (int s = 1; s < kRegF; ++s) {  // resolve in order: a draw already taken is replaced by j (Floyd)
+        bool taken = false;
+#pragma unroll
+        for (int q = 0; q < s; ++q) taken |= (pk[q] == pk[s]);
+        if (s < k && taken) pk[s] = j0 + s;
+      }
+    }
+    int64_t nv[kRegF];
+#pragma unroll
+    for (int s = 0; s < kRegF; ++s) nv[s] = s < k ? col[beg + pk[s]] : 0;  // k independent gathers
+#pragma unroll
+    for (int s = 0; s < kRegF; ++s) {
+      if (s < k) {
+        e_pos[o + s] = beg + pk[s];
+        nbr[o + s] = nv[s];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hop_rowsort_reg_kernel(const int64_t *__restrict__ out_rowptr, int64_t B_cap,
+                                                                 int64_t E_cap, const int64_t *__restrict__ local,
+                                                                 const int64_t *__restrict__ e_pos,
+                                                                 int32_t *__restrict__ out_col,
+                                                                 int64_t *__restrict__ out_eid) {
+  const int64_t ne = out_rowptr[B_cap];
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < B_cap; i += stride) {
+    const int64_t b = out_rowptr[i];
+    const int k = (int)(out_rowptr[i + 1] - b);
+    if (k == 0) continue;
+    int32_t key[kRegF];
+    int64_t val[kRegF];
+#pragma unroll
+    for (int s = 0; s < kRegF; ++s) {
+      key[s] = s < k ? (int32_t)local[b + s] : INT32_MAX;  // padding sorts to the end
+      val[s] = s < k ? e_pos[b + s] : 0;
+    }
+    // bitonic network on 32 (key, val) pairs; keys within a row are distinct (distinct neighbours), so the
+    // order is total and equals the insertion sort's
+#pragma unroll
+    for (int size = 2; size <= kRegF; size <<= 1) {
+#pragma unroll
+      for (int st = size >> 1; st > 0; st >>= 1) {
+#pragma unroll
+        for (int a = 0; a < kRegF; ++a) {
+          const int c = a ^ st;
+          if (c > a) {
+            const bool up = (a & size) == 0;
+            const bool sw = up ? key[a] > key[c] : key[a] < key[c];
+            const int32_t ka = key[a], kc = key[c];
+            const int64_t va = val[a], vc = val[c];
+            key[a] = sw ? kc : ka; key[c] = sw ? ka : kc;
+            val[a] = sw ? vc : va; val[c] = sw ? va : vc;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kRegF; ++s) {
+      if (s < k) {
+        out_col[b + s] = key[s];
+        if (out_eid) out_eid[b + s] = val[s];
+      }
+    }
+  }
+  for (int64_t q = ne + thread_id(); q < E_cap; q += stride) {  // padding past the sampled edges
+    out_col[q] = 0;
+    if (out_eid) out_eid[q] = 0;
+  }
+}
+
 // ---- transposed structure of a block, asynchronously (for the backward of its aggregate) --------------
 // key[q] = source column of edge q (N_src_cap for the padding past n_edges: sorts to the end),
 // val[q] = destination row of q (binary search in rowptr)
@@ -503,8 +609,13 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_clamp_last_kernel), 1, 64, s, out_rowptr, B_cap, E_cap);
   GGL_LAUNCH_CHECK();
-  GGL_LAUNCH((hop_pick_kernel), grid_for(B_cap), kBlock, s, rowptr, col, seeds, n_seeds_dev, B_cap, fanout,
-             (const int64_t *)out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
+  const bool in_regs = fanout <= kRegF;
+  if (in_regs)
+    GGL_LAUNCH((hop_pick_reg_kernel), grid_for(B_cap), kBlock, s, rowptr, col, seeds, n_seeds_dev, B_cap, fanout,
+               (const int64_t *)out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
+  else
+    GGL_LAUNCH((hop_pick_kernel), grid_for(B_cap), kBlock, s, rowptr, col, seeds, n_seeds_dev, B_cap, fanout,
+               (const int64_t *)out_rowptr, (const int64_t *)rng_state, e_pos, nbr);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_mark_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
              (const int64_t *)out_rowptr, num_nodes, fp);
@@ -521,8 +632,12 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   GGL_LAUNCH((hop_reset_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
              (const int64_t *)out_rowptr, num_nodes, fp);
   GGL_LAUNCH_CHECK();
-  GGL_LAUNCH((hop_rowsort_kernel), grid_for(B_cap), kBlock, s, (const int64_t *)out_rowptr, B_cap, E_cap, local, e_pos,
-             out_col, out_eid);
+  if (in_regs)
+    GGL_LAUNCH((hop_rowsort_reg_kernel), grid_for(B_cap), kBlock, s, (const int64_t *)out_rowptr, B_cap, E_cap,
+               (const int64_t *)local, (const int64_t *)e_pos, out_col, out_eid);
+  else
+    GGL_LAUNCH((hop_rowsort_kernel), grid_for(B_cap), kBlock, s, (const int64_t *)out_rowptr, B_cap, E_cap, local, e_pos,
+               out_col, out_eid);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((sample_rng_advance_kernel), 1, 64, s, rng_state);
   GGL_LAUNCH_CHECK();
