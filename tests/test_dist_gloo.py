@@ -382,6 +382,12 @@ def test_bench_launches_its_own_ranks(tmp_path):
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True,
                          timeout=120)
     assert bad.returncode != 0 and "{" not in bad.stdout
+    # more ranks requested than this node has GPUs (none here): refuses instead of reporting an N-GPU line
+    env2 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GGL_BENCH_EMUL")}
+    few = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--workload", "tiny"], env=env2,
+                         capture_output=True, text=True, timeout=120)
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 8:
+        assert few.returncode != 0 and "{" not in few.stdout and "GPU" in (few.stderr + few.stdout)
 
 
 if __name__ == "__main__":
