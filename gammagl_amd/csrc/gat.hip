@@ -53,8 +53,26 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ?
 __device__ __forceinline__ uint32_t pick_word(const U4 &u, int c) {
   return c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
 }
+// Attention-dropout word of (sorted position p, head h): a counter-based 32-bit mix of (seed, offset, p * H + h)
+// with xxHash32's avalanche as the finaliser (~15 VALU instructions).  Round 1 drew these from Philox4x32-10
+// (one 4-word block per four positions); the backward's source walks meet forward positions in scattered order
+// and had to run the full ten rounds per edge for one word — 2.6-3.2 ms of a 5-9 ms walk on the Reddit-sized
+// graph.  Dropout masks need decorrelation, not cryptographic strength; the layer epilogue's dropout
+// (epilogue.hip, reduce.hip) stays on Philox.  The host restatement lives in tests/parity_cases.py.
 __device__ __forceinline__ uint32_t drop_word(int64_t p, int64_t H, int64_t h, uint64_t offset, uint64_t seed) {
-  return pick_word(philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed), (int)(p & 3));
+  const uint64_t idx = (uint64_t)(p * H + h);
+  uint32_t x = ((uint32_t)idx * 0x9E3779B1u) ^ (uint32_t)seed;
+  x ^= ((uint32_t)(idx >> 32) + (uint32_t)offset) * 0x85EBCA77u;
+  x ^= ((uint32_t)(offset >> 32) ^ (uint32_t)(seed >> 32)) * 0xC2B2AE3Du;
+  x ^= x >> 15; x *= 0x85EBCA77u;
+  x ^= x >> 13; x *= 0xC2B2AE3Du;
+  x ^= x >> 16;
+  return x;
+}
+// the words of positions 4b .. 4b+3 (the unrolled walks consume them four at a time)
+__device__ __forceinline__ U4 drop_words4(int64_t b, int64_t H, int64_t h, uint64_t offset, uint64_t seed) {
+  return U4{drop_word(4 * b, H, h, offset, seed), drop_word(4 * b + 1, H, h, offset, seed),
+            drop_word(4 * b + 2, H, h, offset, seed), drop_word(4 * b + 3, H, h, offset, seed)};
 }
 
 template <int VEC> struct F32V {
@@ -90,9 +108,9 @@ template <> struct F32V<4> {
 // 1e-5 relative and is tested against the oracle's three-pass restatement).  Four feature rows in flight.
 // DROP: attention dropout — the softmax statistics (m, den) see every edge, the weighted sum only the
 // kept ones, scaled by 1/(1-p): out = sum_p keep_p alpha_p x_p / (1-p), alpha = softmax over ALL edges.
-// Random word of (position p, head h): component p & 3 of Philox4x32-10((p >> 2) * H + h) — one draw
-// serves four consecutive positions of a head, and the walks below are aligned to multiples of 4 so the
-// unrolled body makes one draw per four edges (a draw per edge doubled the forward: 4.1 -> 9.4 ms).
+// Random word of (position p, head h): drop_word(p, h) above — a 15-instruction counter-based mix, so a draw per
+// edge is affordable in every walk (with Philox4x32-10 a draw per edge doubled the forward: 4.1 -> 9.4 ms, and the
+// walks were aligned to multiples of 4 to share one 4-word block; the alignment is kept for the 16-byte index loads).
 template <int VEC, bool DROP>
 __device__ __forceinline__ void gat_online(const int32_t *__restrict__ col, const float *__restrict__ el,
                                            const float *__restrict__ x, float er_i, float slope, int64_t H,
@@ -133,7 +151,7 @@ __device__ __forceinline__ void gat_online(const int32_t *__restrict__ col, cons
     int64_t c[4];
     float v[4][VEC], s[4];
     U4 rw{0u, 0u, 0u, 0u};
-    if (DROP) rw = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+    if (DROP) rw = drop_words4(p >> 2, H, h, offset, seed);
 #pragma unroll
     for (int u = 0; u < 4; ++u) c[u] = col[p + u];
 #pragma unroll
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst_kernel(
       int64_t sj[4];
       float ev[4];
       U4 rw{0u, 0u, 0u, 0u};
-      if (d.drop_thresh) rw = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+      if (d.drop_thresh) rw = drop_words4(p >> 2, H, h, offset, seed);
 #pragma unroll
       for (int u = 0; u < 4; ++u) sj[u] = col[p + u];
 #pragma unroll
@@ -785,8 +803,8 @@ __global__ __launch_bounds__(kBlock) void gat_fwd2_kernel(
     rescale(mx);
     U4 r0{0u, 0u, 0u, 0u}, r1{0u, 0u, 0u, 0u};
     if (DROP) {
-      r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
-      r1 = philox4x32_10((uint64_t)(((p >> 2) + 1) * H + h), offset, seed);
+      r0 = drop_words4(p >> 2, H, h, offset, seed);
+      r1 = drop_words4((p >> 2) + 1, H, h, offset, seed);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) add(s[u], v[u], pick_word(r0, u));
@@ -807,7 +825,7 @@ __global__ __launch_bounds__(kBlock) void gat_fwd2_kernel(
     for (int u = 0; u < 4; ++u) { s[u] = lrelu(s[u] + er_i, slope); mx = fmaxf(mx, s[u]); }
     rescale(mx);
     U4 r0{0u, 0u, 0u, 0u};
-    if (DROP) r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+    if (DROP) r0 = drop_words4(p >> 2, H, h, offset, seed);
 #pragma unroll
     for (int u = 0; u < 4; ++u) add(s[u], v[u], pick_word(r0, u));
   }
@@ -883,8 +901,8 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst2_kernel(
     for (int u = 0; u < 8; ++u) e[u] = *reinterpret_cast<const float *>(ea.at(c[u]));
     U4 r0{0u, 0u, 0u, 0u}, r1{0u, 0u, 0u, 0u};
     if (DROP) {
-      r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
-      r1 = philox4x32_10((uint64_t)(((p >> 2) + 1) * H + h), offset, seed);
+      r0 = drop_words4(p >> 2, H, h, offset, seed);
+      r1 = drop_words4((p >> 2) + 1, H, h, offset, seed);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) edge(e[u], v[u], pick_word(r0, u));
@@ -901,7 +919,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst2_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) e[u] = *reinterpret_cast<const float *>(ea.at(c[u]));
     U4 r0{0u, 0u, 0u, 0u};
-    if (DROP) r0 = philox4x32_10((uint64_t)((p >> 2) * H + h), offset, seed);
+    if (DROP) r0 = drop_words4(p >> 2, H, h, offset, seed);
 #pragma unroll
     for (int u = 0; u < 4; ++u) edge(e[u], v[u], pick_word(r0, u));
   }
@@ -1141,7 +1159,7 @@ __global__ __launch_bounds__(kBlock) void gat_sh_fwd_kernel(
     float w1 = okB ? fexp(lrelu(s1 + er_i, d.slope) - m) : 0.0f;
     den += w0 + w1;
     if (DROP) {
-      const U4 rw = philox4x32_10((uint64_t)((p0 >> 2) * kShH + h), offset, seed);
+      const U4 rw = drop_words4(p0 >> 2, kShH, h, offset, seed);
       w0 = (pick_word(rw, e) >= d.drop_thresh) ? w0 * d.drop_scale : 0.0f;
       w1 = (pick_word(rw, e + 2) >= d.drop_thresh) ? w1 * d.drop_scale : 0.0f;
     }
@@ -1222,7 +1240,7 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
     const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
     const float s0 = el[(int64_t)cA * kShH + h], s1 = el[(int64_t)cB * kShH + h];
     U4 rw{0u, 0u, 0u, 0u};
-    if (DROP) rw = philox4x32_10((uint64_t)((p0 >> 2) * kShH + h), offset, seed);
+    if (DROP) rw = drop_words4(p0 >> 2, kShH, h, offset, seed);
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {  // pair of edges (2 pr, 2 pr + 1): 16 dots -> one per weight lane
       float v[16];

@@ -295,9 +295,10 @@ int ggl_segment_epi(const float *x, const ggl_segplan_t *plan, int64_t K, int me
  *       planT->partial = ggl_partial_bytes(GGL_F32, n_chunks, H*C + H, 0) bytes when it has long rows
  * ---------------------------------------------------------------------------------------------- */
 /* p_drop > 0: attention dropout (gat_conv.py:104 `dropout(segment_softmax(.))`, GATConvFuse's last
- * argument): edge (p, h) is kept when word p & 3 of Philox4x32-10(rng_state; (p >> 2) * H + h) >= p_drop * 2^32
- * and then weighs
- * alpha / (1 - p_drop); the softmax itself runs over all edges.  rng_state = device int64 {seed, offset},
+ * argument): edge (sorted position p, head h) is kept when the 32-bit word mix(seed, offset, p * H + h)
+ * (a counter-based multiply-xor mix with xxHash32's avalanche, gat.hip drop_word; ABI 4 — ABI 3 drew it from
+ * Philox4x32-10, whose ten rounds per scattered position dominated the backward's source walks) is
+ * >= p_drop * 2^32, and then weighs alpha / (1 - p_drop); the softmax itself runs over all edges.  rng_state = device int64 {seed, offset},
  * offset advanced after the launch; the backward needs the values the forward READ (rng_used). */
 int ggl_gat_fused_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el,
                       const float *er, const float *x, float slope, int64_t H, int64_t C,

@@ -403,6 +403,24 @@ def philox4x32_10(index, offset, seed):
     return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
 
 
+def gat_drop_word(index, offset, seed):
+    """numpy restatement of gat.hip drop_word: the attention-dropout word of counter index = p * H + h."""
+    idx = np.asarray(index, dtype=np.uint64)
+    m32 = np.uint64(0xFFFFFFFF)
+    lo, hi = (idx & m32).astype(np.uint64), (idx >> np.uint64(32)).astype(np.uint64)
+    off_lo, off_hi = np.uint64(offset) & m32, (np.uint64(offset) >> np.uint64(32)) & m32
+    sd_lo, sd_hi = np.uint64(seed) & m32, (np.uint64(seed) >> np.uint64(32)) & m32
+    x = ((lo * np.uint64(0x9E3779B1)) & m32) ^ sd_lo
+    x ^= (((hi + off_lo) & m32) * np.uint64(0x85EBCA77)) & m32
+    x ^= ((off_hi ^ sd_hi) * np.uint64(0xC2B2AE3D)) & m32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x85EBCA77)) & m32
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE3D)) & m32
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
 def check_gat_dropout(eng, dev, oracle):
     """Attention dropout inside the fused op (gat_conv.py:104; GATConvFuse's dropout_rate): the mask is
     rebuilt on the host from the RNG state the launch read, and forward + gradients are compared with the
@@ -426,9 +444,8 @@ def check_gat_dropout(eng, dev, oracle):
             # host mask per (sorted position, head) -> per original edge through the plan's permutation
             gp = eng.graph_plan(it, N)
             pos = np.arange(E, dtype=np.int64)
-            # word p & 3 of the draw for counter (p >> 2) * H + h  (gat.hip: drop_word)
-            words = philox4x32_10(((pos[:, None] >> 2) * H + np.arange(H)[None, :]).reshape(-1), offset, seed)
-            draw = words.reshape(E, H, 4)[pos, :, pos & 3]
+            # the word of counter p * H + h  (gat.hip: drop_word)
+            draw = gat_drop_word((pos[:, None] * H + np.arange(H)[None, :]).reshape(-1), offset, seed).reshape(E, H)
             keep_pos = draw >= np.uint32(int(pd * 4294967296.0))
             perm = gp.fwd.perm.cpu().numpy().astype(np.int64) if gp.fwd.perm is not None else pos
             keep = np.empty_like(keep_pos)
