@@ -53,3 +53,65 @@ def test_sample_adj_fuzz_gpu(target, prob):
 @given(F.fused_problems())
 def test_fused_epilogue_and_strided_fuzz_gpu(target, prob):
     F.run_fused_case(target[0], target[1], prob)
+
+
+@st.composite
+def _headmean_problems(draw):
+    N = draw(st.integers(1, 40))
+    E = draw(st.integers(0, 300))
+    F_in = 4 * draw(st.integers(1, 16))
+    C = draw(st.integers(1, 64))
+    chunk = draw(st.sampled_from([1, 3, 16, 4096]))
+    kind = draw(st.sampled_from(["uniform", "sorted", "hub", "single"]))
+    scale = draw(st.sampled_from([0.05, 1.0, 8.0]))
+    p_drop = draw(st.sampled_from([0.0, 0.0, 0.5]))
+    seed = draw(st.integers(0, 2**31 - 1))
+    return N, E, F_in, C, chunk, kind, scale, p_drop, seed
+
+
+@settings(**_cfg)
+@given(_headmean_problems())
+def test_gat_headmean_fuzz_gpu(target, prob):
+    """The aggregate-then-transform output layer (shared-row kernels: row broadcasts, 16-lane reduce-scatter, hub
+    chunks, partial blocks at row ends) == the same layer on the transform-then-aggregate kernels, forward and the
+    gradients of x / W / att, with the same dropout mask for the same rng state."""
+    import numpy as np
+
+    from gammagl_amd import layers
+
+    eng, dev = target
+    N, E, F_in, C, chunk, kind, scale, p_drop, seed = prob
+    rng = np.random.default_rng(seed)
+    index = np.stack([F.make_ids(rng, N, E, "hub" if kind == "single" else "uniform"),
+                      F.make_ids(rng, N, E, kind)]).astype(np.int64)
+    ei = torch.as_tensor(index, device=dev)
+    x = torch.as_tensor(rng.standard_normal((N, F_in)).astype(np.float32), device=dev)
+    go = torch.as_tensor(rng.standard_normal((N, C)).astype(np.float32), device=dev)
+    torch.manual_seed(seed % 1000)
+    conv = layers.FusedGATConv(F_in, C, heads=8, concat=False, dropout_rate=p_drop).to(dev)
+    with torch.no_grad():
+        conv.w.mul_(scale / 0.05)
+        conv.att.mul_(scale / 0.05)
+    conv.train()
+    old = eng.chunk
+    eng.chunk = chunk
+    eng.clear_caches()
+    try:
+        outs = []
+        for fast in (True, False):
+            eng.gat_fast = fast
+            eng.reseed(seed % 997)
+            eng._rng_state(dev)
+            for p_ in conv.parameters():
+                p_.grad = None
+            xa = x.clone().requires_grad_(True)
+            y = conv(xa, ei, N)
+            y.backward(go)
+            outs.append([y.detach(), xa.grad, conv.w.grad.clone(), conv.att.grad.clone()])
+        for a, b, nm in zip(outs[0], outs[1], ("y", "gx", "gW", "gatt")):
+            tol = 3e-4 * float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= tol, (prob, nm, float((a - b).abs().max()), tol)
+    finally:
+        eng.gat_fast = True
+        eng.chunk = old
+        eng.clear_caches()
