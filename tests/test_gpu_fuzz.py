@@ -108,8 +108,12 @@ def test_gat_headmean_fuzz_gpu(target, prob):
             y = conv(xa, ei, N)
             y.backward(go)
             outs.append([y.detach(), xa.grad, conv.w.grad.clone(), conv.att.grad.clone()])
+        # absolute floor: gradients that cancel to ~0 (a single edge has no logit gradient) carry rounding noise of
+        # the size of the terms that cancel
+        terms = (1.0 + float(conv.w.abs().max()) * float(conv.att.abs().max())) * (1.0 + float(x.abs().max())) \
+            * (1.0 + float(go.abs().max())) * (1.0 + float(conv.w.abs().max()))
         for a, b, nm in zip(outs[0], outs[1], ("y", "gx", "gW", "gatt")):
-            tol = 3e-4 * float(b.abs().max()) + 1e-6
+            tol = 3e-4 * float(b.abs().max()) + 1e-6 * terms
             assert float((a - b).abs().max()) <= tol, (prob, nm, float((a - b).abs().max()), tol)
     finally:
         eng.gat_fast = True
