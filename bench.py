@@ -51,6 +51,10 @@ def parse():
                    help="edge order of the synthetic edge_index (src = coalesced COO as in GammaGL/PyG)")
     p.add_argument("--relabel", default="random", choices=["random", "degree", "none"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
+                   help="auto: after the timed region (N = 1, products), collect the dominant kernel's HBM-side traffic "
+                        "with two rocprofv3 --pmc passes of tools/pmc_probe.py on the same graph (skipped when rocprofv3 "
+                        "is not on PATH; falls back to the committed profile)")
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
 
@@ -133,6 +137,48 @@ def cpu_baseline(hidden, classes, seed, full_graph=None):
     return out
 
 
+def measure_traffic(args, hidden):
+    """HBM-side bytes per launch of the dominant kernel, measured NOW on this box: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 --pmc passes (MI355X_MICROARCH.md, HBM section: KiB units, x2 on the read side for gfx950) of
+    tools/pmc_probe.py, which rebuilds this run's graph and launches the K=hidden SpMM-sum a few times.  Returns
+    (bytes, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ggl_pmc_")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(REPO, "tools", "pmc_probe.py"), args.workload, str(hidden), str(args.seed), args.relabel,
+                   args.order]
+            r = subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR=d), capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            xs = []
+            with open(files[0], newline="") as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == counter and "row_reduce_kernel<float, 4, 0, 1, 1, true" in row["Kernel_Name"]:
+                        xs.append(float(row["Counter_Value"]))
+            if not xs:
+                return None, "kernel not found in the counter file"
+            vals[counter] = sum(xs) / len(xs)
+        except Exception as ex:  # noqa: BLE001
+            return None, f"{type(ex).__name__}: {ex}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py on the same graph " \
+        "((2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 read-side correction)"
+
+
 def _free_port():
     import socket
 
@@ -208,6 +254,12 @@ def main():
 
         assert dist.get_world_size() == args.gpus
     if rank == 0:
+        if world == 1 and not emul and args.pmc_traffic == "auto" and args.workload == "products":
+            t, src = measure_traffic(args, args.hidden)
+            if t is not None:
+                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t, src
+            elif out["roofline"].get("traffic") is not None:
+                out["roofline"]["traffic_source"] += f" [in-run collection unavailable: {src}]"
         if world == 1 and not args.no_cpu_baseline and not emul:
             # the benchmark graph itself on the host (rank 0 holds all of it at N = 1)
             ei = torch.cat([torch.stack([pg.ei_loc[0] + pg.lo, pg.ei_loc[1] + pg.lo]).cpu()], dim=1)

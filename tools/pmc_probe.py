@@ -12,10 +12,13 @@ from gammagl_amd.synth import DATASETS, rmat_partitioned  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "products"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+relabel = sys.argv[4] if len(sys.argv) > 4 else "random"
+order = sys.argv[5] if len(sys.argv) > 5 else "src"
 dev = torch.device("cuda", 0)
 eng = engine()
 n, e, _, _ = DATASETS[wl]
-g = rmat_partitioned(n, e, seed=0, device=dev)          # the bench's own graph (bench.py defaults)
+g = rmat_partitioned(n, e, seed=seed, device=dev, relabel=relabel, order=order)   # the bench's own graph
 ei = torch.stack([g["src"], g["dst"]])
 w = g["w"]
 gp = eng.graph_plan(ei, n)
