@@ -10,11 +10,15 @@ its own share of the graph (gammagl_amd.synth.rmat_partitioned): no rank holds t
 
 * a "step" = one full training step of GCNModel(100 -> 256 -> 256 -> 47, norm='none') on
   precomputed symmetric-normalised edge weights (edge_weight = calc_gcn_norm(edge_index), the
-  configuration examples/gcn/gcn_trainer.py:59 sketches) over the whole graph: forward (Linear ->
-  aggregate -> +bias -> ReLU -> dropout per layer), softmax cross-entropy on the train nodes,
-  backward, Adam with weight decay.  Every step aggregates 6 x E edges: 3 forward CSR SpMMs + 3
-  transposed SpMMs in backward.  Same code path for every N (N = 1: no halo exchange);
-* value = 6 * E * steps / time over the whole job (max over ranks), inputs resident in HBM;
+  configuration examples/gcn/gcn_trainer.py:59 sketches) over the whole graph: forward (Linear,
+  aggregate, +bias, ReLU, dropout per layer), softmax cross-entropy on the train nodes, backward, Adam
+  with weight decay.  GammaGL's GCNConv always computes A (X W) (gcn_conv.py:79): 3 forward CSR SpMMs + 3
+  transposed ones per step (--transform-first).  By default a layer whose input is narrower than its output
+  computes the same product as (A X) W: the first layer then aggregates 100-wide rows, and its backward needs
+  no aggregation (the input features carry no gradient, dW = (A X)^T dH): 5 aggregations per step.
+  Same code path for every N (N = 1: no halo exchange);
+* value = (aggregations actually executed per step) * E * steps / time over the whole job (max over ranks),
+  inputs resident in HBM; "aggregations_per_step" is in the line;
   scaling = "strong": the graph is fixed and node-partitioned over the N GPUs;
 * roofline = the dominant kernel (CSR SpMM-sum, feature width 256, forward, rank 0's rows) timed
   with hipEvents on its launch stream: algorithmic bytes E*(4*256+8) + N*(4*256+8) per launch
@@ -50,6 +54,9 @@ def parse():
     p.add_argument("--order", default="src", choices=["src", "dst"],
                    help="edge order of the synthetic edge_index (src = coalesced COO as in GammaGL/PyG)")
     p.add_argument("--relabel", default="random", choices=["random", "degree", "none"])
+    p.add_argument("--transform-first", action="store_true",
+                   help="A (X W) in every layer, as GammaGL's GCNConv writes it (default: a layer whose input is narrower "
+                        "than its output computes (A X) W — same product, fewer bytes, no aggregation in layer 1's backward)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                    help="auto: after the timed region (N = 1, products), collect the dominant kernel's HBM-side traffic "

@@ -307,9 +307,16 @@ class DistGCN(torch.nn.Module):
     """GCNModel(norm='none') on precomputed symmetric-normalised edge weights (models/gcn.py:30-64,
     gcn_conv.py:78-108 with norm='none'), each GCNConv's propagate replaced by the halo aggregate."""
 
-    def __init__(self, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, overlap_wgrad=True):
+    def __init__(self, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, overlap_wgrad=True,
+                 aggregate_first=True):
+        """`aggregate_first`: a layer whose input is NARROWER than its output computes (A X) W instead of
+        A (X W) — the same product, associated the cheap way round (the rule DGL's GraphConv applies; GammaGL's
+        GCNConv always transforms first, gcn_conv.py:79).  For the first layer of the products model (100 -> 256)
+        the aggregate then moves 400-byte rows instead of 1 KiB ones, and its BACKWARD needs no aggregation at all:
+        the input features carry no gradient, and dW = (A X)^T dH is a GEMM on the saved aggregate."""
         super().__init__()
-        self.overlap_wgrad = overlap_wgrad
+        self.overlap_wgrad, self.aggregate_first = overlap_wgrad, aggregate_first
+        self.agg_per_step = 2 * num_layers   # aggregations one training step executes (set by forward)
         dims = [feature_dim] + [hidden_dim] * (num_layers - 1) + [num_class]
         self.lin = torch.nn.ModuleList([torch.nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
         self.bias = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, b)) for b in dims[1:]])
@@ -335,27 +342,38 @@ class DistGCN(torch.nn.Module):
         n = len(self.lin)
         if x.is_cuda and self.side is None and self.overlap_wgrad:
             self.side = torch.cuda.Stream(device=x.device)
+        n_agg = 0
         for i in range(n):
             hidden = i < n - 1
             n_out = self.lin[i].weight.shape[0]
             pad = (-n_out) % 4 if n_out >= 8 else 0   # e.g. 47 classes -> 48 columns, dropped at the end
-            h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink, pad)
             bias = self.bias[i] if not pad else F.pad(self.bias[i], (0, pad))
             p = self.dropout.p if hidden else 0.0
-            # + bias, ReLU and dropout ride on the store of the last edge block added to a row: the local SpMM
-            # on one GPU, the halo-source SpMM behind the exchange otherwise (reduce.hip MODE_SPMM_EPI)
-            x = pg.aggregate(h, bias, relu=hidden, p_drop=p, training=self.training)
+            if self.aggregate_first and x.shape[1] < n_out and x.shape[1] % 4 == 0:
+                # (A X) W: aggregate the narrower side; the epilogue follows the GEMM as its own pass
+                n_agg += 2 if x.requires_grad else 1
+                z = pg.aggregate(x)
+                h = _LinearSideWgrad.apply(z, self.lin[i].weight, self.side, self._sink, pad)
+                x = pg.eng.bias_act(h, bias, relu=hidden, p_drop=p, training=self.training)
+            else:
+                n_agg += 2
+                h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink, pad)
+                # + bias, ReLU and dropout ride on the store of the last edge block added to a row: the local SpMM
+                # on one GPU, the halo-source SpMM behind the exchange otherwise (reduce.hip MODE_SPMM_EPI)
+                x = pg.aggregate(h, bias, relu=hidden, p_drop=p, training=self.training)
             if pad:
                 x = x[:, :n_out]
+        self.agg_per_step = n_agg
         return x
 
 
 class DistGCNTrainer:
     def __init__(self, pg, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, lr=0.01,
-                 l2_coef=5e-4, seed=0, device="cuda"):
+                 l2_coef=5e-4, seed=0, device="cuda", aggregate_first=True):
         self.pg = pg
         torch.manual_seed(seed)  # identical initial weights on every rank
-        self.net = DistGCN(feature_dim, hidden_dim, num_class, num_layers, drop_rate).to(device)
+        self.net = DistGCN(feature_dim, hidden_dim, num_class, num_layers, drop_rate,
+                           aggregate_first=aggregate_first).to(device)
         self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef)
         torch.manual_seed(seed + 1000 * (pg.rank + 1))  # independent dropout masks per rank
 
@@ -418,7 +436,8 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
     if world > 1:
         dist.all_reduce(nt)  # the global train-set size every rank normalises its loss by
     n_train = max(int(nt), 1)
-    tr = DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev)
+    tr = DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev,
+                        aggregate_first=not getattr(args, "transform_first", False))
 
     def sync():
         if world > 1:
@@ -426,20 +445,33 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
         if dev.type == "cuda":
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step(x, y, train_local, n_train)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = tr.step(x, y, train_local, n_train)
-    sync()
-    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    lsum = loss.detach().double().reshape(1).clone()
-    if world > 1:
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lsum)
-    dt = float(dt)
-    n_agg = 2 * args.layers
+    def timed(trainer):
+        for _ in range(args.warmup):
+            trainer.step(x, y, train_local, n_train)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = trainer.step(x, y, train_local, n_train)
+        sync()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        lsum = loss.detach().double().reshape(1).clone()
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lsum)
+        return float(dt), float(lsum)
+
+    dt, lsum = timed(tr)
+    like = None
+    if tr.net.agg_per_step < 2 * args.layers:
+        # the like-for-like figure beside it: A (X W) in every layer, exactly as GammaGL's GCNConv associates it
+        tr2 = DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev,
+                             aggregate_first=False)
+        dt2, _ = timed(tr2)
+        like = {"ms_per_step": dt2 / args.steps * 1e3, "aggregations_per_step": tr2.net.agg_per_step,
+                "value": tr2.net.agg_per_step * E * args.steps / dt2, "unit": "edges/s",
+                "note": "same model and step with every layer computing A (X W) as gcn_conv.py:79 writes it (--transform-first)"}
+        del tr2
+    n_agg = tr.net.agg_per_step     # aggregations the step actually executed (counted by the model's forward)
     value = n_agg * E * args.steps / dt
 
     # dominant kernel on this rank's local CSR (K = hidden), hipEvents on the launch stream
@@ -471,6 +503,8 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
         except Exception:  # noqa: BLE001
             traffic = None
     widths = [args.hidden] * (args.layers - 1) + [n_cls + (-n_cls) % 4]
+    if n_agg < 2 * args.layers:     # layer 1 exchanges its input rows (forward only) instead of its output rows
+        widths = [f_in / 2.0] + widths[1:]
     out = {
         "metric": "edges aggregated/sec, 3-layer GCN hidden=256 training step, ogbn-products-sized graph",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -480,15 +514,18 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
         "config": {
             "workload": f"{args.workload}-sized R-MAT: N={n_nodes}, E={E} directed incl. self-loops, features "
                         f"{f_in}->{args.hidden}x{args.layers - 1}->{n_cls}, edge order={args.order}, relabel={args.relabel}, "
-                        f"full-graph GCN train step (fwd+bwd+Adam), {n_agg} aggregations/step, symmetric-norm edge "
-                        f"weights precomputed (GCNConv norm='none' + calc_gcn_norm edge_weight)",
+                        f"full-graph GCN train step (fwd+bwd+Adam), {n_agg} aggregations/step"
+                        + (f" (layer 1 computes (A X) W on its {f_in}-wide input: one aggregate forward, none backward — "
+                           f"the input features carry no gradient)" if n_agg < 2 * args.layers else "")
+                        + ", symmetric-norm edge weights precomputed (GCNConv norm='none' + calc_gcn_norm edge_weight)",
+            "aggregations_per_step": n_agg, "transform_first": like,
             "parallelism": f"node-partition x{world}, 1-hop halo all-to-all-v, per-rank graph construction" if world > 1 else "1 GPU",
             "rank0_local_edges": pg.e_local, "rank0_halo_rows": pg.n_halo, "rank0_send_rows": pg.n_send,
             "rank0_peak_edges_during_build": stats.get("peak_edges"),
             # rows received + sent by rank 0 per step: each aggregate moves the halo rows in (forward) or their
             # gradients out (backward) and the mirror image for the rows other ranks need, at the layer's width
             "rank0_halo_GB_per_step": round(2 * (pg.n_halo + pg.n_send) * 4 * sum(widths) / 1e9, 3),
-            "setup_s": round(t_gen, 2), "loss": float(lsum)},
+            "setup_s": round(t_gen, 2), "loss": lsum},
         "roofline": {"bound": "hbm", "kernel": f"row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, K={K}, rank 0 local rows"
                                f"{', halo-source edges' if use_halo else ''})",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
