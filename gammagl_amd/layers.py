@@ -237,6 +237,17 @@ class SAGEConv(MessagePassing):
             if self.aggr != 'mean':
                 raise NotImplementedError("sampler Blocks carry the mean aggregator")
             fused_act = self.act is None or self.act is torch.relu or self.act is torch.nn.functional.relu
+            w_n, w_s = self.fc_neigh.weight, self.fc_self.weight
+            if w_n.shape[1] < w_n.shape[0] and src_feat.shape[1] % 4 == 0:
+                # input narrower than output: aggregate first (the rule DGL's SAGEConv applies; sage_conv.py:100 always
+                # transforms first).  In a sampled block this also shrinks the GEMM from the block's SOURCE rows to its
+                # destination rows (100 608 -> 18 432 on the products-sized graph) and, for the first layer, whose
+                # input rows carry no gradient, removes the backward aggregate together with the block's CSC build.
+                agg = edge.eng.block_mean_epi(src_feat, edge)
+                out = torch.nn.functional.linear(torch.cat([agg, dst_feat], dim=1), torch.cat([w_n, w_s], dim=1))
+                if self.bias is not None or self.act is not None:
+                    out = edge.eng.bias_act(out, self.bias, relu=fused_act and self.act is not None)
+                return out if fused_act else self.act(out)
             out = edge.eng.block_mean_epi(self.fc_neigh(src_feat), edge, add=self.fc_self(dst_feat), bias=self.bias,
                                            relu=fused_act and self.act is not None)
             return out if fused_act else self.act(out)
