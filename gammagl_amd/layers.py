@@ -252,8 +252,23 @@ class SAGEConv(MessagePassing):
                                            relu=fused_act and self.act is not None)
             return out if fused_act else self.act(out)
         if self.aggr == 'mean':
-            src_feat = self.fc_neigh(src_feat)
             fused_act = self.act is None or self.act is torch.relu or self.act is torch.nn.functional.relu
+            w_n = self.fc_neigh.weight
+            if (SAGE_FUSE_EPILOGUE and w_n.shape[1] < w_n.shape[0] and src_feat.dim() == 2 and src_feat.shape[1] % 4 == 0
+                    and src_feat.dtype == torch.float32 and fused_act):
+                # input narrower than output: aggregate first, transform the (fewer, in a sampled block) destination
+                # rows afterwards — see the Block branch above
+                eng = _engine()
+                if edge.shape[1] >= FUSED_MIN_EDGES:
+                    gp = eng.graph_plan(edge, num_nodes, int(src_feat.shape[0]))
+                    agg = eng.spmm(gp, None, src_feat, "mean")
+                else:
+                    agg = unsorted_segment_mean(src_feat.index_select(0, edge[0]), edge[1], num_nodes)
+                out = torch.nn.functional.linear(torch.cat([agg, dst_feat], dim=1), torch.cat([w_n, self.fc_self.weight], dim=1))
+                if self.bias is not None or self.act is not None:
+                    out = eng.bias_act(out, self.bias, relu=self.act is not None)
+                return out
+            src_feat = self.fc_neigh(src_feat)
             if SAGE_FUSE_EPILOGUE and src_feat.dim() == 2 and src_feat.dtype == torch.float32 and fused_act:
                 # "mean + fc_self(x_dst) + bias -> act" (sage_conv.py:100-108) rides on the aggregate's store:
                 # the fused rectangular SpMM-mean for big edge lists, the segment route for sampled blocks

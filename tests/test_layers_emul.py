@@ -95,6 +95,23 @@ def _body():
                 torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
             assert torch.equal(outs[0][0], outs[1][0])
     layers.SAGE_FUSE_EPILOGUE = True
+    # input narrower than output (10 -> 16): the layer aggregates first, on both routes == the formula
+    for thr in (10**12, 0):
+        layers.FUSED_MIN_EDGES = thr
+        sage = layers.SAGEConv(10, 16, activation=torch.relu, aggr="mean")
+        torch.nn.init.normal_(sage.bias)
+        xa = x.clone().requires_grad_(True)
+        y = sage((xa, xa[:nd]), blk)
+        ref = torch.relu((torch.zeros(nd, 10).index_add_(0, blk[1], x[blk[0]]) / cnt) @ sage.fc_neigh.weight.t()
+                         + x[:nd] @ sage.fc_self.weight.t() + sage.bias)
+        torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+        gr = torch.autograd.grad(y.square().sum(), [xa] + list(sage.parameters()))
+        xr = x.clone().requires_grad_(True)
+        ref2 = torch.relu((torch.zeros(nd, 10).index_add_(0, blk[1], xr[blk[0]]) / cnt) @ sage.fc_neigh.weight.t()
+                          + xr[:nd] @ sage.fc_self.weight.t() + sage.bias)
+        gref = torch.autograd.grad(ref2.square().sum(), [xr] + list(sage.parameters()))
+        for a, b in zip(gr, gref):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
     layers.FUSED_MIN_EDGES = 2_000_000
     # a float64 edge_weight promotes the messages exactly as the reference's message() route does
     conv = layers.GCNConv(10, 8, norm="none")
