@@ -114,12 +114,17 @@ class SAGEBlockTrainer:
         torch.manual_seed(seed)
         self.net = GraphSAGESampleModel(in_feat, hid_feat, num_class, drop_rate, num_layers).to(device)
         cap = torch.device(device).type == "cuda" if capturable is None else capturable
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, capturable=cap)
+        # one fused optimizer kernel and gradients assigned (not zero-filled and accumulated) per step: in a replayed
+        # graph the step is bound by the NUMBER of small kernels (~5 us + gap each), not by their work
+        try:
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, capturable=cap, fused=cap)
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, capturable=cap)
         self.graph = None
 
     def step(self, x, y, seeds):
         self.net.train()
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)
         n_id, blocks, _ = self.sampler.sample(seeds, caps=self.caps)
         logits = self.net(x.index_select(0, n_id), blocks)
         loss = F.cross_entropy(logits[: seeds.shape[0]], y.index_select(0, seeds))
@@ -143,8 +148,6 @@ class SAGEBlockTrainer:
         """Record step(x, y, seeds) into a hipGraph.  Afterwards: seeds.copy_(new_batch); trainer.replay()."""
         if self.world > 1:
             raise RuntimeError("capture() records a single-replica step; with world > 1 call step() per batch")
-        for p in self.net.parameters():
-            p.grad = torch.zeros_like(p)
         self.graph = GraphedStep(lambda: self.step(x, y, seeds), warmup=warmup)
         return self.graph
 
