@@ -374,7 +374,11 @@ class DistGCNTrainer:
         torch.manual_seed(seed)  # identical initial weights on every rank
         self.net = DistGCN(feature_dim, hidden_dim, num_class, num_layers, drop_rate,
                            aggregate_first=aggregate_first).to(device)
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef)
+        try:    # one fused optimizer kernel for all parameters on the GPU
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef,
+                                        fused=torch.device(device).type == "cuda")
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef)
         torch.manual_seed(seed + 1000 * (pg.rank + 1))  # independent dropout masks per rank
 
     def step(self, x_local, y_local, train_local, n_train_global):
