@@ -49,7 +49,7 @@ def run(pg, label, steps=8):
         tr.step(x, y, idx, idx.numel())
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    print(f"{label}: {ms:.1f} ms/step ({6 * E / ms / 1e6:.2f} Gedges/s); halo rows {pg.n_halo}, "
+    print(f"{label}: {ms:.1f} ms/step ({tr.net.agg_per_step * E / ms / 1e6:.2f} Gedges/s over {tr.net.agg_per_step} aggregations); halo rows {pg.n_halo}, "
           f"local-source edges {pg.gp_loc.E}, halo-source edges {pg.gp_halo.E if pg.gp_halo else 0}", flush=True)
     return ms
 
