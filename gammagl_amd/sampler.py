@@ -109,13 +109,38 @@ class NeighborSampler:
         self.value = (torch.arange(ei.shape[1], device=ei.device) if plan.perm is None else plan.perm.long())
         self._first_pos = torch.full((self.num_nodes,), _BIG, dtype=torch.int64, device=ei.device)  # relabel scratch
 
+    def _hop_exact(self, seeds, fanout):
+        """One sampled hop with exact output shapes: the static-shape kernels (ggl_sample_hop: ~15 launches, relabelling
+        included) at worst-case capacity, then ONE host read of the counts to cut the buffers to size — instead of the
+        count / pick kernels plus ~80 torch launches of relabelling and sorting of `sample_adj`."""
+        eng, dev = self.eng, self.rowptr.device
+        b = int(seeds.shape[0])
+        e_cap, s_cap = max(b * fanout, 1), b + max(b * fanout, 1)
+        rowptr = torch.empty(b + 1, dtype=torch.int64, device=dev)
+        col = torch.empty(e_cap, dtype=torch.int32, device=dev)
+        e_pos = torch.empty(e_cap, dtype=torch.int64, device=dev)
+        nid = torch.empty(s_cap, dtype=torch.int64, device=dev)
+        counts = torch.zeros(3, dtype=torch.int64, device=dev)
+        n_seeds = torch.full((1,), b, dtype=torch.int64, device=dev)
+        wsb = eng.lib.ggl_sample_hop_workspace_bytes(b, e_cap)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        eng._check(eng.lib.ggl_sample_hop(_ptr(self.rowptr), _ptr(self.col), _ptr(seeds), _ptr(n_seeds), b,
+                                          self.num_nodes, int(fanout), e_cap, s_cap, _ptr(eng._rng_state(dev)),
+                                          _ptr(self._first_pos), _ptr(rowptr), _ptr(col), _ptr(e_pos), _ptr(nid),
+                                          _ptr(counts), _ptr(ws), wsb, eng._stream(dev)))
+        nn, ne, _ = counts.tolist()   # the one host read of this hop
+        return rowptr, col[:ne].long(), nid[:nn], e_pos[:ne]
+
     def sample(self, batch):
         batch = torch.as_tensor(batch, device=self.rowptr.device, dtype=torch.int64).reshape(-1)
         n_id, adjs = batch, []
         for size in self.sizes:
             n_dst = int(n_id.shape[0])
-            rowptr, col, n_id, e_pos = sample_adj(self.rowptr, self.col, n_id, size, replace=False, eng=self.eng,
-                                                  first_pos=self._first_pos)
+            if size > 0 and n_dst > 0 and n_dst * size < (1 << 30):
+                rowptr, col, n_id, e_pos = self._hop_exact(n_id.contiguous(), size)
+            else:
+                rowptr, col, n_id, e_pos = sample_adj(self.rowptr, self.col, n_id, size, replace=False, eng=self.eng,
+                                                      first_pos=self._first_pos)
             row = torch.repeat_interleave(torch.arange(n_dst, device=col.device), rowptr[1:] - rowptr[:-1],
                                           output_size=int(col.shape[0]))
             block = torch.stack([col, row])
