@@ -53,7 +53,6 @@ SIGNATURES = {
     "ggl_segment_sum": (c_int, [c_int, _V, _P, c_int64, _V, _V]),
     "ggl_segment_mean": (c_int, [c_int, _V, _P, c_int64, _V, _V]),
     "ggl_segment_max": (c_int, [c_int, _V, _P, c_int64, _V, _V, c_int64, _V]),
-    "ggl_segment_rows": (c_int, [c_int, c_int, _V, _P, _V, c_int64, c_int64, _V, _V]),
     "ggl_segment_sum_bwd": (c_int, [c_int, _V, _V, c_int64, c_int64, _V, _V]),
     "ggl_segment_mean_bwd": (c_int, [c_int, _V, _V, _V, c_int64, c_int64, _V, _V]),
     "ggl_segment_max_bwd": (c_int, [c_int, _V, _V, c_int64, c_int64, c_int64, _V, _V]),

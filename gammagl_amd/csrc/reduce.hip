@@ -484,7 +484,6 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   const float *epi_add;
   int64_t add_ld;
   int64_t epi_K, epi_col0; // 0 / 0 = the launch covers whole rows
-  int force_order;         // row_order is a ROW LIST (ggl_segment_rows), not a scheduling hint: never dropped
 };
 
 static inline int pow2_ceil_log2(int64_t v) {
@@ -506,8 +505,7 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
   d.chunk_blocks = a.n_long > 0 ? ceil_div(a.n_chunks, kWavesPerBlock) : 0;
   const int64_t grid = d.chunk_blocks + d.nblocks;
   GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "grid too large");
-  const int32_t *order = a.force_order ? a.row_order
-                         : ((options().row_order && (!uniform || options().row_order > 1)) ? a.row_order : nullptr);
+  const int32_t *order = (options().row_order && (!uniform || options().row_order > 1)) ? a.row_order : nullptr;
 #define GGL_RR_ARGS GGL_RPTR_ARGS(S), order, a.long_rows, a.chunk_ptr, static_cast<S *>(a.partial), a.partial_arg, out, a.arg, d
   if (uniform) {
     // the f32 wave-per-row kernels; U = 8 only for the dominant SpMM-sum (A/B knob)
@@ -678,42 +676,6 @@ extern "C" int ggl_segment_sum_ex(int dtype, const void *x, int64_t x_ld, const 
   a.out = out;
   a.x_ld = x_ld; a.out_ld = out_ld; a.accumulate = accumulate ? 1 : 0;
   return launch_seg<OP_SUM>(dtype, a, as_stream(stream));
-}
-
-// The listed rows only, each walked in ONE piece with one feature column per lane (VEC = 1, up to a whole
-// wavefront per row).  For the 16-bit float types: their sums accumulate in the storage type
-// (segment_sum_cpu.cpp:47-56), so a hub row cannot be cut into chunks — but a lane that owns 8 packed columns
-// spends 8 x (add, round, widen) per element of a 109 110-element walk, while 64 lanes with one column each
-// spend 3.  ggl_segment_{sum,mean} with a plan whose long-row table is withheld (n_long = 0, chunk kept) skips
-// those rows; this call fills them in.  op: 0 = sum, 1 = mean.
-extern "C" int ggl_segment_rows(int dtype, int op, const void *x, const ggl_segplan_t *plan, const int32_t *rows,
-                                int64_t n_rows, int64_t K, void *out, void *stream) {
-  GGL_REQUIRE(op == 0 || op == 1, GGL_EINVAL, "op must be 0 (sum) or 1 (mean)");
-  GGL_REQUIRE(n_rows >= 0, GGL_EINVAL, "negative row count");
-  if (n_rows == 0 || K == 0) return GGL_OK;
-  ReduceArgs a{};
-  int rc = fill_plan(a, plan, dtype, K, false);
-  if (rc) return rc;
-  GGL_REQUIRE(x && out && rows, GGL_EINVAL, "NULL pointer");
-  a.x = x;
-  a.out = out;
-  a.N = n_rows;            // slots of this launch = the listed rows
-  a.row_order = rows;
-  a.force_order = 1;
-  a.chunk = (int64_t)1 << 62;
-  a.n_long = a.n_chunks = 0;
-  a.long_rows = nullptr; a.chunk_ptr = nullptr; a.partial = nullptr;
-  hipStream_t s = as_stream(stream);
-#define GGL_ROWS(T)                                                                                   \
-  (op == 0 ? launch_typed<T, 1, OP_SUM, MODE_SEG, false>(a, s) : launch_typed<T, 1, OP_MEAN, MODE_SEG, false>(a, s))
-  switch (dtype) {
-    case GGL_F16: return GGL_ROWS(f16_t);
-    case GGL_BF16: return GGL_ROWS(bf16_t);
-    case GGL_F32: return GGL_ROWS(float);
-    case GGL_F64: return GGL_ROWS(double);
-    default: set_error("ggl_segment_rows: floating dtypes only (got code %d)", dtype); return GGL_EDTYPE;
-  }
-#undef GGL_ROWS
 }
 
 extern "C" int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K,

@@ -47,12 +47,10 @@ class SegPlan:
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
                  "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid")
 
-    def c_struct(self, partial=None, perm_override=None, unsplit=False, skip_long=False):
-        """`unsplit`: present the plan without its long-row table, every row walked in one piece.
-        `skip_long`: withhold the long-row table but keep the threshold: rows longer than `chunk` are left out
-        of the launch (ggl_segment_rows fills them in)."""
+    def c_struct(self, partial=None, perm_override=None, unsplit=False):
+        """`unsplit`: present the plan without its long-row table, every row walked in one piece."""
         perm = self.perm if perm_override is None else perm_override
-        n_long = 0 if (unsplit or skip_long) else self.n_long
+        n_long = 0 if unsplit else self.n_long
         return SegPlanC(
             rowptr=self.rowptr.data_ptr(), perm=(perm.data_ptr() if perm is not None else None),
             long_rows=(self.long_rows.data_ptr() if n_long else None),
@@ -411,17 +409,13 @@ class Engine:
         # the serial order well beyond rounding (a running f16 sum of ones sticks at 2048), so combining
         # chunk partials would not reproduce the reference: those rows are always walked in one piece
         unsplit = op != "max" and x.dtype in (torch.float16, torch.bfloat16)
-        # ... and their hub rows get a launch of their own with one column per lane (ggl_segment_rows): a lane with 8
-        # packed columns pays 8 x (add, round, widen) per element of a 100 000-element serial walk
-        hubs = unsplit and plan.n_long > 0 and K > 1
         part = None if unsplit else self._partial(plan, x.dtype, K, op == "max", dev)
-        cs = plan.c_struct(part, unsplit=unsplit and not hubs, skip_long=hubs)
-        if op in ("sum", "mean"):
-            fn = self.lib.ggl_segment_sum if op == "sum" else self.lib.ggl_segment_mean
-            self._check(fn(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
-            if hubs:
-                self._check(self.lib.ggl_segment_rows(code, 0 if op == "sum" else 1, _ptr(x), ctypes.byref(cs),
-                                                      _ptr(plan.long_rows), plan.n_long, K, _ptr(out), st))
+        cs = plan.c_struct(part, unsplit=unsplit)
+        if op == "sum":
+            self._check(self.lib.ggl_segment_sum(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
+            return out, None
+        if op == "mean":
+            self._check(self.lib.ggl_segment_mean(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
             return out, None
         arg = torch.empty((plan.N,) + tuple(x.shape[1:]), dtype=torch.int64, device=dev)
         self._check(self.lib.ggl_segment_max(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), _ptr(arg),

@@ -154,12 +154,6 @@ int ggl_segment_sum(int dtype, const void *x, const ggl_segplan_t *plan, int64_t
                     void *stream);
 int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,
                      void *stream);
-/* sum (op 0) / mean (op 1) of the LISTED rows only, each walked in one piece with one feature column per lane:
- * the 16-bit float types accumulate in the storage type (segment_sum_cpu.cpp:47-56), so their hub rows cannot
- * be chunked; call ggl_segment_{sum,mean} with the plan's long-row table withheld (n_long = 0, chunk kept: rows
- * longer than chunk are skipped) and fill those rows in with this. */
-int ggl_segment_rows(int dtype, int op, const void *x, const ggl_segplan_t *plan, const int32_t *rows,
-                     int64_t n_rows, int64_t K, void *out, void *stream);
 int ggl_segment_max(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,
                     int64_t *arg, int64_t arg_fill, void *stream);
 
