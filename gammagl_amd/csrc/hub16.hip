@@ -1,0 +1,128 @@
+// gammagl_amd/csrc/hub16.hip — hub rows of the 16-bit float segment sums (GPU build only: LDS + barriers).
+//
+// f16 / bf16 sums accumulate in the storage type (segment_sum_cpu.cpp:47-56: the running sum is rounded to 16 bits
+// after every add, so a sum of ones sticks at 2048): the result depends on the serial order far beyond rounding and a
+// hub row cannot be cut into independently reduced chunks.  The row kernel of reduce.hip therefore walks such a row
+// with ONE lane group, four dependent gathers at a time — 0.2-0.3 us per element, 12-32 ms for a 109 110-element hub
+// where the f32 op (chunked) takes 0.15-0.7 ms.  What is serial is only the ADD chain, not the loads: here a
+// workgroup owns (hub row, 64-column slab); four producer wavefronts gather the next 256 elements of the slab
+// through `perm` into one half of a double-buffered LDS tile (one element per thread, up to eight independent
+// 16-byte loads in flight each, the index fetched a stage earlier) while the consumer wavefront — one column per lane — folds the other half into its running sums in the
+// reference's order: load, add in f32, round to the storage type (3 VALU instructions per element).  Bit-identical to
+// the serial walk; the slabs of a row and the hub rows run in parallel.
+#include "common.hpp"
+
+namespace ggl {
+
+constexpr int kHubStage = 256;              // elements per LDS half = producer threads (one element each)
+constexpr int kHubCols = 64;                // columns per slab = consumer lanes
+constexpr int kHubBlock = kWave + kHubStage;  // wavefront 0 consumes, wavefronts 1-4 produce
+
+template <typename T>
+__global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *__restrict__ x,
+                                                               const int32_t *__restrict__ perm,
+                                                               const int64_t *__restrict__ rowptr,
+                                                               const int32_t *__restrict__ long_rows, int64_t n_long,
+                                                               int64_t K, int64_t slabs, int mean,
+                                                               uint16_t *__restrict__ out) {
+  __shared__ uint16_t buf[2][kHubStage][kHubCols];   // 2 x 32 KiB
+  const int64_t j = block_id() / slabs, slab = block_id() - j * slabs;
+  if (j >= n_long) return;
+  const int64_t row = long_rows[j];
+  const int64_t beg = rowptr[row], end = rowptr[row + 1], len = end - beg;
+  const int64_t c0 = slab * kHubCols;
+  const int ncol = (int)((K - c0) < kHubCols ? (K - c0) : kHubCols);   // multiple of 8 (checked at launch)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t nst = (len + kHubStage - 1) / kHubStage;
+  const int parts = ncol >> 3;                                          // 16-byte pieces per element of this slab
+  if (tid >= kWave) {
+    // ---- producers: thread e owns element e of every stage; its source row index is fetched one stage ahead of
+    // the row itself, so a stage costs one gather latency, not two
+    const int e = tid - kWave;
+    auto src_of = [&](int64_t st) -> int64_t {
+      const int64_t p = beg + st * kHubStage + e;
+      return p < end ? (perm ? (int64_t)perm[p] : p) : -1;
+    };
+    auto fill = [&](int64_t src, int b) {
+      if (src < 0) return;
+      const uint4 *g = reinterpret_cast<const uint4 *>(x + src * K + c0);
+      uint4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q < parts) v[q] = g[q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q < parts) *reinterpret_cast<uint4 *>(&buf[b][e][q * 8]) = v[q];
+    };
+    int64_t src = src_of(0);
+    int64_t nxt = nst > 1 ? src_of(1) : -1;
+    fill(src, 0);
+    __syncthreads();
+    for (int64_t st = 0; st < nst; ++st) {
+      src = nxt;
+      nxt = st + 2 < nst ? src_of(st + 2) : -1;
+      if (st + 1 < nst) fill(src, (int)((st + 1) & 1));
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- consumer: one column per lane, the elements of a stage in order; the LDS reads of 8 elements are issued
+  // together, the adds stay the reference's serial chain
+  typename TT<T>::A acc = TT<T>::zero();
+  __syncthreads();
+  for (int64_t st = 0; st < nst; ++st) {
+    const int b = (int)(st & 1);
+    if (lane < ncol) {
+      const int cnt = (int)((len - st * kHubStage) < kHubStage ? (len - st * kHubStage) : kHubStage);
+      int e = 0;
+      for (; e + 8 <= cnt; e += 8) {
+        uint16_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = buf[b][e + q][lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = TT<T>::add(acc, TT<T>::load(v[q]));
+      }
+      for (; e < cnt; ++e) acc = TT<T>::add(acc, TT<T>::load(buf[b][e][lane]));
+    }
+    __syncthreads();
+  }
+  if (lane < ncol) {
+    if (mean) {  // segment_mean_cpu.cpp:67-76: the count lives in the storage type; divide only where count > 1
+      const typename TT<T>::A c = TT<T>::count(len);
+      if (TT<T>::gt1(c)) acc = TT<T>::div(acc, c);
+    }
+    out[row * K + c0 + lane] = TT<T>::store(acc);
+  }
+}
+
+}  // namespace ggl
+
+using namespace ggl;
+
+extern "C" int ggl_segment_hub16_supported(int dtype, int64_t K, const void *x, const void *out) {
+  return ((dtype == GGL_F16 || dtype == GGL_BF16) && K > 0 && K % 8 == 0 &&
+          (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 1u) == 0) ? 1 : 0;
+}
+
+// sum (mean = 0) / mean (mean = 1) of the plan's LONG rows only (plan->long_rows, n_long), each in the reference's
+// serial order.  Pair it with ggl_segment_{sum,mean} on the same plan with the long-row table withheld (n_long = 0,
+// chunk kept): that launch skips the rows longer than chunk, this one fills them in.
+extern "C" int ggl_segment_hub16(int dtype, int mean, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,
+                                 void *stream) {
+  GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
+  GGL_REQUIRE(ggl_segment_hub16_supported(dtype, K, x, out), GGL_EINVAL,
+              "ggl_segment_hub16: f16 / bf16 rows of a multiple of 8 columns, 16-byte aligned");
+  if (plan->n_long <= 0) return GGL_OK;
+  GGL_REQUIRE(plan->long_rows && x && out, GGL_EINVAL, "NULL pointer");
+  const int64_t slabs = ceil_div(K, (int64_t)kHubCols);
+  const int64_t grid = plan->n_long * slabs;
+  hipStream_t s = as_stream(stream);
+  if (dtype == GGL_F16)
+    GGL_LAUNCH((hub_rows16_kernel<f16_t>), grid, kHubBlock, s, static_cast<const uint16_t *>(x), plan->perm, plan->rowptr,
+               plan->long_rows, plan->n_long, K, slabs, mean ? 1 : 0, static_cast<uint16_t *>(out));
+  else
+    GGL_LAUNCH((hub_rows16_kernel<bf16_t>), grid, kHubBlock, s, static_cast<const uint16_t *>(x), plan->perm, plan->rowptr,
+               plan->long_rows, plan->n_long, K, slabs, mean ? 1 : 0, static_cast<uint16_t *>(out));
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}

@@ -47,10 +47,12 @@ class SegPlan:
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
                  "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid")
 
-    def c_struct(self, partial=None, perm_override=None, unsplit=False):
-        """`unsplit`: present the plan without its long-row table, every row walked in one piece."""
+    def c_struct(self, partial=None, perm_override=None, unsplit=False, skip_long=False):
+        """`unsplit`: present the plan without its long-row table, every row walked in one piece.
+        `skip_long`: withhold the long-row table but keep the threshold — rows longer than `chunk` are left out
+        of the launch (ggl_segment_hub16 fills them in)."""
         perm = self.perm if perm_override is None else perm_override
-        n_long = 0 if unsplit else self.n_long
+        n_long = 0 if (unsplit or skip_long) else self.n_long
         return SegPlanC(
             rowptr=self.rowptr.data_ptr(), perm=(perm.data_ptr() if perm is not None else None),
             long_rows=(self.long_rows.data_ptr() if n_long else None),
@@ -204,6 +206,7 @@ class Engine:
         self.stats = {"plans_built": 0, "plan_hits": 0}
         self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk; 0 = auto_chunk(E)
         self.gat_fast = True        # fused GAT: the low-VALU kernels where the head shape allows (GPU build only)
+        self.hub16 = True           # f16 / bf16 sums: LDS-pipelined hub rows (GPU build only; A/B switch)
         self._make_functions()
 
     def clear_caches(self):
@@ -409,13 +412,19 @@ class Engine:
         # the serial order well beyond rounding (a running f16 sum of ones sticks at 2048), so combining
         # chunk partials would not reproduce the reference: those rows are always walked in one piece
         unsplit = op != "max" and x.dtype in (torch.float16, torch.bfloat16)
+        # ... but only their ADD chain is serial, not the loads: where the library has the LDS-pipelined hub kernel
+        # (GPU build, hub16.hip) the hub rows get a launch of their own, a workgroup per (row, 64-column slab)
+        hubs = bool(unsplit and plan.n_long > 0 and self.hub16 and
+                    self.lib.ggl_segment_hub16_supported(code, K, _ptr(x), _ptr(out)))
         part = None if unsplit else self._partial(plan, x.dtype, K, op == "max", dev)
-        cs = plan.c_struct(part, unsplit=unsplit)
-        if op == "sum":
-            self._check(self.lib.ggl_segment_sum(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
-            return out, None
-        if op == "mean":
-            self._check(self.lib.ggl_segment_mean(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
+        cs = plan.c_struct(part, unsplit=unsplit and not hubs, skip_long=hubs)
+        if op in ("sum", "mean"):
+            fn = self.lib.ggl_segment_sum if op == "sum" else self.lib.ggl_segment_mean
+            self._check(fn(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
+            if hubs:
+                full = plan.c_struct(None)
+                self._check(self.lib.ggl_segment_hub16(code, 0 if op == "sum" else 1, _ptr(x), ctypes.byref(full), K,
+                                                       _ptr(out), st))
             return out, None
         arg = torch.empty((plan.N,) + tuple(x.shape[1:]), dtype=torch.int64, device=dev)
         self._check(self.lib.ggl_segment_max(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), _ptr(arg),

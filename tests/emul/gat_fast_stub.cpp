@@ -37,3 +37,8 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *, const int32_t *, const ggl_
                               float *, void *) {
   return no_gpu();
 }
+
+// gammagl_amd/csrc/hub16.hip (LDS + barriers) has no host-emulated build either: the emulated library reports the
+// path as unsupported and the 16-bit sums keep walking their hub rows with the row kernel of reduce.hip.
+extern "C" int ggl_segment_hub16_supported(int, int64_t, const void *, const void *) { return 0; }
+extern "C" int ggl_segment_hub16(int, int, const void *, const ggl_segplan_t *, int64_t, void *, void *) { return no_gpu(); }

@@ -275,6 +275,26 @@ def check_long_rows(eng, dev, oracle, chunk=8):
             xi = rng.integers(-100, 100, size=(E, K)).astype(np.int32)
             assert_same(to_np(eng.c_segment_sum(to_t(xi, dev), it, N)), oracle.segment_sum(xi, ids, N), "long i32")
             assert_same(to_np(eng.c_segment_mean(to_t(xi, dev), it, N)), oracle.segment_mean(xi, ids, N), "long i32 mean")
+        # f16 / bf16 accumulate in the storage type: their hub rows are never chunked.  With K % 8 == 0 the GPU build
+        # hands them to the LDS-pipelined hub kernel (hub16.hip), otherwise (and in the emulated build) one lane group
+        # walks them: both must be the reference's serial result bit for bit — sums that saturate included.
+        for K in (8, 40, 64, 72, 256, 5):
+            ids = rng.integers(0, N, size=E).astype(np.int64)
+            ids[:700] = 7       # 700 > 2 x 256: several LDS stages + a ragged last one
+            ids[700:1000] = 0
+            ids[1000:1009] = 39
+            xf = (rng.standard_normal((E, K)) * 40 + 3).astype(np.float32)
+            it = to_t(ids, dev)
+            for nm in ("float16", "bfloat16"):
+                xh = oracle.f32_to_bf16_bits(xf) if nm == "bfloat16" else xf.astype(np.float16)
+                xt = to_t(xh, dev, nm)
+                want_s = oracle.segment_sum(xh, ids, N, bf16=nm == "bfloat16")
+                want_m = oracle.segment_mean(xh, ids, N, bf16=nm == "bfloat16")
+                for hub16 in (True, False):
+                    eng.hub16 = hub16
+                    assert_same(to_np(eng.c_segment_sum(xt, it, N)), want_s, f"{nm} hub sum K{K} hub16={hub16}")
+                    assert_same(to_np(eng.c_segment_mean(xt, it, N)), want_m, f"{nm} hub mean K{K} hub16={hub16}")
+                eng.hub16 = True
         for K in (4, 47, 256):
             index = _rand_graph(rng, N, E, hub=3)
             index[0, : E // 2] = 11  # a source hub too: long rows in the transposed plan
