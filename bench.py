@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--transform-first", action="store_true",
                    help="A (X W) in every layer, as GammaGL's GCNConv writes it (default: a layer whose input is narrower "
                         "than its output computes (A X) W — same product, fewer bytes, no aggregation in layer 1's backward)")
+    p.add_argument("--no-comparison", action="store_true",
+                   help="skip the like-for-like transform-first trainer timed beside the default (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                    help="auto: after the timed region (N = 1, products), collect the dominant kernel's HBM-side traffic "

@@ -307,13 +307,13 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src2_kernel(
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
   float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float gl = 0.0f;
-  auto edge = [&](const float4 &gi, const float4 &st, int64_t q) {
+  auto edge = [&](const float4 &gi, const float4 &st, int32_t fq /* forward position of the edge */) {
     float da = head_sum<C4>(dot4(gi, xj));
     const float raw = el_j + st.x;
     const float al = fexp(lrelu(raw, slope) - st.y) * st.z;
     float alk = al;
     if (DROP) {  // the keep bit of the FORWARD position of this edge
-      const bool keep = drop_word((int64_t)posT[q], H, h, offset, seed) >= d.drop_thresh;
+      const bool keep = drop_word((int64_t)fq, H, h, offset, seed) >= d.drop_thresh;
       alk = keep ? al * d.drop_scale : 0.0f;
       da = keep ? da * d.drop_scale : 0.0f;
     }
@@ -326,20 +326,23 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_src2_kernel(
     const int32_t c = col[q];
     const float4 gi = *reinterpret_cast<const float4 *>(ga.at(c));
     const float4 st = *reinterpret_cast<const float4 *>(sa.at(c));
-    edge(gi, st, q);
+    edge(gi, st, DROP ? posT[q] : 0);
   };
   int64_t p = it.beg;
   for (; p < it.end && (p & 3) != 0; ++p) single(p);
   for (; p + 4 <= it.end; p += 4) {  // 4 gradient rows + 4 stats vectors in flight
     const int4 i0 = *reinterpret_cast<const int4 *>(col + p);
     const int32_t c[4] = {i0.x, i0.y, i0.z, i0.w};
+    int4 f0 = make_int4(0, 0, 0, 0);  // the block's forward positions (dropout), fetched beside the ids
+    if (DROP) f0 = *reinterpret_cast<const int4 *>(posT + p);
+    const int32_t fq[4] = {f0.x, f0.y, f0.z, f0.w};
     float4 gi[4], st[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) gi[u] = *reinterpret_cast<const float4 *>(ga.at(c[u]));
 #pragma unroll
     for (int u = 0; u < 4; ++u) st[u] = *reinterpret_cast<const float4 *>(sa.at(c[u]));
 #pragma unroll
-    for (int u = 0; u < 4; ++u) edge(gi[u], st[u], p + u);
+    for (int u = 0; u < 4; ++u) edge(gi[u], st[u], fq[u]);
   }
   for (; p < it.end; ++p) single(p);
   if (!act) return;
@@ -640,8 +643,9 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_src_kernel(
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
   float gl = 0.0f;
   for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
-    ShBlock b;
+    ShBlock b, fp;  // fp: the block's FORWARD positions (dropout), fetched beside the column ids, not behind them
     sh_block(col, p0, it.beg, it.end, b);
+    if (DROP) sh_block(posT, p0, it.beg, it.end, fp);
     float4 gv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) gv[u] = act ? *reinterpret_cast<const float4 *>(gy + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -665,8 +669,8 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_src_kernel(
       const float al = fexp(lrelu(raw, d.slope) - st.y) * st.z;
       float alk = al;
       if (DROP) {  // the keep bit lives at the FORWARD position of the edge
-        const int64_t q = p0 + e + 2 * pr;
-        const bool keep = ok && drop_word((int64_t)posT[ok ? q : it.beg], kShH, h, offset, seed) >= d.drop_thresh;
+        const int32_t fq = pr ? (e ? fp.c[3] : fp.c[2]) : (e ? fp.c[1] : fp.c[0]);
+        const bool keep = ok && drop_word((int64_t)fq, kShH, h, offset, seed) >= d.drop_thresh;
         alk = keep ? al * d.drop_scale : 0.0f;
         da = keep ? da * d.drop_scale : 0.0f;
       }

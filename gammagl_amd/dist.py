@@ -284,6 +284,9 @@ class _LinearSideWgrad(torch.autograd.Function):
         side, n_out = ctx.side, w.shape[0]
         gx = None
         if ctx.needs_input_grad[0]:
+            # first, and the side stream waits for it: issuing the weight-gradient GEMM beside this one (both read g)
+            # was measured — two compute-bound GEMMs sharing the CUs stretch each other (2.6 -> 4.5 ms and
+            # 3.6 -> 7.9 ms) and the step lost 1.3 ms; the side stream earns its keep under the HBM-bound SpMM only
             gx = g @ (w if not ctx.pad_out else F.pad(w, (0, 0, 0, ctx.pad_out)))
         gw = None
         if ctx.needs_input_grad[1]:
@@ -466,7 +469,7 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
 
     dt, lsum = timed(tr)
     like = None
-    if tr.net.agg_per_step < 2 * args.layers:
+    if tr.net.agg_per_step < 2 * args.layers and not getattr(args, "no_comparison", False):
         # the like-for-like figure beside it: A (X W) in every layer, exactly as GammaGL's GCNConv associates it
         tr2 = DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev,
                              aggregate_first=False)
