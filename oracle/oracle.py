@@ -283,7 +283,9 @@ def load_ref_ext():
 def sample_adj_full(rowptr, col, idx):
     """ops/sparse/cpu/sample.cpp:10-135 with num_neighbors < 0 (no sampling, :39-55): n_id = seeds then
     new nodes in first-seen order (:24-29,:48-51); every row's (local col, e_id) pairs sorted by local
-    id (:112-118).  Returns (out_rowptr, out_col, out_n_id, out_e_id) as int64 arrays."""
+    id (:112-118).  Returns (out_rowptr, out_col, out_n_id, out_e_id) as int64 arrays.
+    Pinned: tests/test_oracle_golden.py holds it to tests/golden/sampler.npz, the outputs of the reference's own
+    c_sample_adj (oracle/_ref/_sample.so, compiled from sample.cpp by oracle/Makefile)."""
     rowptr, col, idx = np.asarray(rowptr), np.asarray(col), np.asarray(idx)
     n_ids = [int(i) for i in idx]
     n_id_map = {}

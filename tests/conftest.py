@@ -17,7 +17,7 @@ def golden():
     import numpy as np
 
     d = os.path.join(REPO, "tests", "golden")
-    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("kat", "segment", "spmm", "layers")}
+    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("kat", "segment", "spmm", "layers", "sampler", "convert")}
 
 
 @pytest.fixture(scope="session")

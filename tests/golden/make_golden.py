@@ -337,8 +337,100 @@ def layer_cases():
     print("layers.npz:", len(out), "arrays")
 
 
+# ------------------------------------------------------------------------------------------------
+# 5. neighbour sampler: the reference's own c_sample_adj (oracle/_ref/_sample.so, built from
+#    ops/sparse/cpu/sample.cpp as it lies in the reference tree) on its DETERMINISTIC branches:
+#      * num_neighbors < 0 (sample.cpp:39-55): no sampling;
+#      * replace=False with num_neighbors >= every row's length (:77-80): every neighbour taken — the new
+#        nodes are numbered in the iteration order of a std::unordered_set, so tests compare this one up
+#        to that numbering (same seeds first, same (seed, neighbour, e_id) triples).
+#    The sampled branches draw from srand(time(0)); rand() (sparse_utils.cpp:31-39) and cannot be pinned
+#    by vectors: tests/ hold their invariants instead.
+# ------------------------------------------------------------------------------------------------
+def sampler_cases():
+    sys.path.insert(0, os.path.join(REPO, "oracle", "_ref"))
+    import _sample  # noqa: E402  (PYBIND11_MODULE(_sample) of the reference's sample.cpp)
+
+    rng = np.random.default_rng(2024)
+    out = {}
+    ci = 0
+
+    def csr(N, E, hub=None, dup=0):
+        ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
+        if hub is not None:
+            ei[1, : E // 5] = hub
+        if dup:
+            ei[:, :dup] = ei[:, dup:2 * dup]          # repeated edges (multi-graph rows)
+        order = np.argsort(ei[1], kind="stable")
+        rowptr = np.concatenate(([0], np.cumsum(np.bincount(ei[1], minlength=N)))).astype(np.int64)
+        return rowptr, ei[0][order].copy()
+
+    def emit(rowptr, col, seeds, fanout):
+        nonlocal ci
+        res = _sample.c_sample_adj(rowptr, col, seeds, int(fanout), False)
+        k = f"c{ci}"
+        out[k + "_rowptr"], out[k + "_col"], out[k + "_seeds"] = rowptr, col, seeds
+        out[k + "_fanout"] = np.int64(fanout)
+        for nm, a in zip(("orp", "ocol", "nid", "eid"), res):
+            out[f"{k}_{nm}"] = np.asarray(a, dtype=np.int64)
+        ci += 1
+
+    # the tiny example worked by hand in tests (4 nodes)
+    rp0 = np.array([0, 2, 5, 5, 6], np.int64)
+    c0 = np.array([1, 3, 0, 2, 2, 1], np.int64)
+    emit(rp0, c0, np.array([3, 0], np.int64), -1)
+    emit(rp0, c0, np.array([1, 0, 2], np.int64), -1)
+    emit(rp0, c0, np.array([1, 0], np.int64), 5)
+    emit(rp0, c0, np.array([], np.int64), -1)
+    for (N, E, hub, dup, B) in ((30, 200, 4, 0, 8), (300, 4000, 7, 0, 64), (300, 4000, 7, 150, 64),
+                                (50, 60, None, 0, 50), (1000, 30000, 11, 500, 200)):
+        rowptr, col = csr(N, E, hub, dup)
+        perm = rng.permutation(N)
+        seeds = perm[:B].astype(np.int64)
+        if hub is not None and hub not in seeds:
+            seeds[0] = hub
+        emit(rowptr, col, seeds, -1)
+        emit(rowptr, col, seeds, int(np.diff(rowptr).max()) + 3)   # take-all branch of the sampled code path
+        dups = seeds.copy()
+        dups[1::3] = dups[0]                                        # a seed listed several times (:24-29)
+        emit(rowptr, col, dups, -1)
+    out["ncases"] = np.int64(ci)
+    np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
+    print("sampler.npz:", ci, "cases")
+
+
+# ------------------------------------------------------------------------------------------------
+# 6. COO <-> CSR pointers: the reference's c_ind2ptr / c_ptr2ind (oracle/_ref/_convert.so, built from
+#    ops/sparse/cpu/convert.cpp), the host side of FusedGATConv's preprocessing (fusedgat_conv.py:103-117)
+# ------------------------------------------------------------------------------------------------
+def convert_cases():
+    sys.path.insert(0, os.path.join(REPO, "oracle", "_ref"))
+    import _convert  # noqa: E402
+
+    rng = np.random.default_rng(77)
+    out = {}
+    ci = 0
+    for (M, E, lo, hi) in ((1, 0, 0, 1), (5, 1, 2, 3), (5, 7, 0, 5), (40, 300, 0, 40), (40, 300, 5, 30),
+                           (1000, 20000, 0, 1000), (7, 5000, 0, 7), (64, 64, 63, 64), (64, 64, 0, 1)):
+        ind = np.sort(rng.integers(lo, hi, size=E)).astype(np.int64)
+        for workers in (1, 0):
+            ptr = np.asarray(_convert.c_ind2ptr(ind, M, workers), np.int64)
+            back = np.asarray(_convert.c_ptr2ind(ptr, E, workers), np.int64)
+            assert (back == ind).all()      # the reference's own round trip
+            if workers == 1:
+                out[f"v{ci}_ind"], out[f"v{ci}_M"], out[f"v{ci}_ptr"] = ind, np.int64(M), ptr
+            else:
+                assert (ptr == out[f"v{ci}_ptr"]).all()
+        ci += 1
+    out["ncases"] = np.int64(ci)
+    np.savez_compressed(os.path.join(HERE, "convert.npz"), **out)
+    print("convert.npz:", ci, "cases")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    sampler_cases()
+    convert_cases()
     kat()
     segment_cases()
     spmm_cases()

@@ -566,11 +566,20 @@ def check_edge_cases(eng, dev, oracle):
         eng.c_spmm_sum(torch.tensor([[0, 7], [1, 0]], device=dev), torch.ones(2, device=dev), torch.ones((2, 2), device=dev))
 
 
-def check_convert(eng, dev):
+def check_convert(eng, dev, golden=None):
     """ind2ptr / ptr2ind / sort_edge_index vs the reference's numpy statements
     (ops/sparse/__init__.py:23-41: bincount + cumsum, repeat(arange, diff); sort_edge_index.py:36-39:
-    argsort(row * N + col))."""
+    argsort(row * N + col)) and, with `golden`, vs what the reference's compiled c_ind2ptr / c_ptr2ind returned
+    (tests/golden/convert.npz, ops/sparse/cpu/convert.cpp built by oracle/Makefile)."""
     from gammagl_amd import sparse
+
+    if golden is not None:
+        g = golden["convert"]
+        for ci in range(int(g["ncases"])):
+            ind, M, ptr = g[f"v{ci}_ind"], int(g[f"v{ci}_M"]), g[f"v{ci}_ptr"]
+            got = sparse.ind2ptr(to_t(ind, dev), M, eng=eng)
+            assert_same(to_np(got), ptr, f"ind2ptr vs reference, case {ci}")
+            assert_same(to_np(sparse.ptr2ind(to_t(ptr, dev), len(ind), eng=eng)), ind, f"ptr2ind vs reference, case {ci}")
 
     rng = np.random.default_rng(3)
     for (M, E) in ((1, 0), (5, 1), (40, 300), (1000, 20000), (7, 5000)):
@@ -694,6 +703,57 @@ def check_sampler(eng, dev, oracle):
     # the global edges the block refers to are real edges between the right nodes
     g_src, g_dst = to_t(ei, dev)[0][adj.e_id], to_t(ei, dev)[1][adj.e_id]
     assert torch.equal(n_id[adj.edge_index[0]], g_src)
+
+
+def block_triples(orp, ocol, nid, eid):
+    """(seed row, global neighbour, e_id) of every edge of a sampled block, sorted: what the block MEANS, whatever the
+    numbering of its new nodes and the order of equal columns (std::sort is not stable, sample.cpp:112-118)."""
+    orp, ocol, nid, eid = (np.asarray(a, np.int64) for a in (orp, ocol, nid, eid))
+    rows = np.repeat(np.arange(len(orp) - 1, dtype=np.int64), np.diff(orp))
+    t = np.stack([rows, nid[ocol] if len(ocol) else ocol, eid], 1)
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+def ties_sorted(orp, ocol, eid):
+    """e_id with the pairs of every row ordered by (local column, e_id) — the reference leaves ties in std::sort's order"""
+    orp, ocol, eid = (np.asarray(a, np.int64) for a in (orp, ocol, eid))
+    rows = np.repeat(np.arange(len(orp) - 1, dtype=np.int64), np.diff(orp))
+    return eid[np.lexsort((eid, ocol, rows))]
+
+
+def compare_block_with_reference(got, g, k, what):
+    """`got` = (rowptr, col, n_id, e_id) of a sample_adj implementation, g[k_*] = what the reference's own
+    c_sample_adj returned for the same input (tests/golden/sampler.npz)."""
+    orp, ocol, nid, eid = (np.asarray(a, np.int64) for a in got)
+    seeds, fanout = g[k + "_seeds"], int(g[k + "_fanout"])
+    r_orp, r_col, r_nid, r_eid = g[k + "_orp"], g[k + "_ocol"], g[k + "_nid"], g[k + "_eid"]
+    assert_same(orp, r_orp, what + " rowptr")
+    if fanout < 0:   # no sampling: everything is determined (ties in e_id up to std::sort's order)
+        assert_same(ocol, r_col, what + " col")
+        assert_same(nid, r_nid, what + " n_id")
+        assert_same(ties_sorted(orp, ocol, eid), ties_sorted(r_orp, r_col, r_eid), what + " e_id")
+        return
+    # every neighbour taken through the sampled code path: new nodes numbered in unordered_set order
+    assert_same(nid[: len(seeds)], seeds, what + " seeds first")
+    assert_same(np.sort(nid), np.sort(r_nid), what + " node set")
+    assert_same(block_triples(orp, ocol, nid, eid), block_triples(r_orp, r_col, r_nid, r_eid), what + " edges")
+    rows = np.repeat(np.arange(len(orp) - 1), np.diff(orp))
+    if len(ocol) > 1:
+        inner = rows[1:] == rows[:-1]
+        assert (np.diff(ocol)[inner] >= 0).all(), what + " columns ascending"
+
+
+def check_sampler_golden(eng, dev, golden):
+    """sample_adj against the outputs of the reference's own c_sample_adj (built from ops/sparse/cpu/sample.cpp by
+    oracle/Makefile, run by tests/golden/make_golden.py): the two branches without a random draw."""
+    from gammagl_amd import sampler
+
+    g = golden["sampler"]
+    for ci in range(int(g["ncases"])):
+        k = f"c{ci}"
+        rp, cl, idx = to_t(g[k + "_rowptr"], dev), to_t(g[k + "_col"], dev), to_t(g[k + "_seeds"], dev)
+        got = sampler.sample_adj(rp, cl, idx, int(g[k + "_fanout"]), False, eng=eng)
+        compare_block_with_reference([to_np(t) for t in got], g, k, f"sampler case {ci}")
 
 
 def check_colsum(eng, dev):

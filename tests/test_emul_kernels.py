@@ -107,16 +107,17 @@ def test_colsum_bias_gradient(eng):
     pc.check_colsum(eng, DEV)
 
 
-def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng):
-    pc.check_convert(eng, DEV)
+def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng, golden):
+    pc.check_convert(eng, DEV, golden)
 
 
 def test_fused_bias_relu_dropout(eng):
     pc.check_bias_act(eng, DEV)
 
 
-def test_neighbor_sampler(eng, oracle):
+def test_neighbor_sampler(eng, oracle, golden):
     pc.check_sampler(eng, DEV, oracle)
+    pc.check_sampler_golden(eng, DEV, golden)
 
 
 def test_dropout_without_relu_gradient(eng):

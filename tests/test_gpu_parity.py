@@ -445,8 +445,8 @@ def test_rccl_self_halo_exchange(eng, dev):
         dist.destroy_process_group()
 
 
-def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng, dev):
-    pc.check_convert(eng, dev)
+def test_format_conversion_ind2ptr_ptr2ind_sort_edge_index(eng, dev, golden):
+    pc.check_convert(eng, dev, golden)
 
 
 def test_fused_bias_relu_dropout(eng, dev):
@@ -535,8 +535,9 @@ def test_ops_follow_the_current_stream(eng, dev, oracle):
     np.testing.assert_array_equal(arg.cpu().numpy(), oarg)
 
 
-def test_neighbor_sampler(eng, dev, oracle):
+def test_neighbor_sampler(eng, dev, oracle, golden):
     pc.check_sampler(eng, dev, oracle)
+    pc.check_sampler_golden(eng, dev, golden)
 
 
 def test_training_step_captures_into_a_hipgraph(eng, dev):

@@ -158,6 +158,30 @@ def test_gat_math_fixture(golden, oracle):
     np.testing.assert_allclose(gx_total, g["gat_gx"], rtol=2e-4, atol=2e-5)
 
 
+def test_sampler_restatement_against_reference_sample_adj(golden, oracle):
+    """oracle.sample_adj_full (the Python restatement the sampler tests check against) vs the reference's own
+    c_sample_adj on its deterministic branches (tests/golden/sampler.npz)."""
+    import parity_cases as pc
+
+    g = golden["sampler"]
+    assert int(g["ncases"]) >= 19
+    for ci in range(int(g["ncases"])):
+        k = f"c{ci}"
+        got = oracle.sample_adj_full(g[k + "_rowptr"], g[k + "_col"], g[k + "_seeds"])
+        pc.compare_block_with_reference(got, g, k, f"restated sampler case {ci}")
+
+
+def test_convert_statements_against_reference_ind2ptr(golden):
+    """the numpy statements parity_cases.check_convert holds ind2ptr / ptr2ind to, vs the reference's compiled
+    c_ind2ptr (tests/golden/convert.npz)."""
+    g = golden["convert"]
+    for ci in range(int(g["ncases"])):
+        ind, M, ptr = g[f"v{ci}_ind"], int(g[f"v{ci}_M"]), g[f"v{ci}_ptr"]
+        stated = np.concatenate(([0], np.cumsum(np.bincount(ind, minlength=M), dtype=np.int64)))
+        assert same(stated, ptr), ci
+        assert same(np.repeat(np.arange(M, dtype=np.int64), np.diff(ptr)), ind), ci
+
+
 def test_oracle_rejects_out_of_range_ids(oracle):
     x = np.ones((3, 2), np.float32)
     with pytest.raises(IndexError):
