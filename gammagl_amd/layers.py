@@ -228,6 +228,9 @@ class SAGEConv(MessagePassing):
             self.fc_self = Linear(in_channels, out_channels, bias=False)
         if aggr == 'pool':
             self.pool = Linear(in_channels, in_channels, bias=False)
+        if aggr == 'lstm':   # sage_conv.py:46-47
+            self.in_feat = in_channels
+            self.lstm = nn.LSTM(input_size=in_channels, hidden_size=in_channels, batch_first=True)
         self.bias = nn.Parameter(torch.zeros(1, out_channels)) if add_bias else None
 
     def forward(self, feat, edge):
@@ -295,6 +298,15 @@ class SAGEConv(MessagePassing):
             src_feat = torch.relu(self.pool(src_feat))
             out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='max')
             out = self.fc_neigh(out)
+        elif self.aggr == 'lstm':
+            # sage_conv.py:93-98: no graph op at all — the source rows are taken as [N_dst, fan-out, D] sequences in
+            # the order they arrive (the edge list is not consulted) and the LSTM's last hidden state is the aggregate
+            size = dst_feat.shape[0]
+            seq = src_feat.reshape(size, -1, src_feat.shape[1])
+            h0 = (torch.zeros((1, size, self.in_feat), dtype=seq.dtype, device=seq.device),
+                  torch.zeros((1, size, self.in_feat), dtype=seq.dtype, device=seq.device))
+            _, (rst, _) = self.lstm(seq, h0)
+            out = self.fc_neigh(rst[0])
         else:
             raise NotImplementedError(self.aggr)
         if self.aggr != 'gcn':
@@ -348,6 +360,11 @@ class FusedGATConv(GATConv):
     def forward(self, x, edge_index, num_nodes=None, **kwargs):
         H, C = self.heads, self.out_channels
         eng = _engine()
+        if 'row_ptr' in kwargs:
+            # fusedgat_conv.py:95-100: the caller's own CSR (rows = the aggregating nodes, col_ind = the nodes they
+            # gather from), its transpose and the CSC -> CSR position map: taken as they are, no sort, no host trip
+            edge_index = eng.graph_plan_from_csr(kwargs['row_ptr'], kwargs['col_ind'], kwargs['col_ptr'],
+                                                 kwargs['row_ind'], kwargs['permute'])
         if (not self.concat and x.dim() == 2 and x.dtype == torch.float32 and (num_nodes is None or num_nodes == x.shape[0])
                 and eng.gat_headmean_supported(H, x.shape[1], C)):
             # a head-averaging layer whose input row (F floats) is narrower than its H x C transformed row: aggregate

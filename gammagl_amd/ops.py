@@ -84,6 +84,31 @@ class GraphPlan:
         self._bwd = self._colT = self._posT = None
         self.aux = {}  # graph-constant tensors callers derive from this edge list (e.g. GCN edge norms)
 
+    @classmethod
+    def from_csr(cls, engine, row_ptr, col_ind, col_ptr, row_ind, permute, n_rows, n_cols):
+        """A GraphPlan from structures the caller already holds, no sort: the CSR of the aggregating rows
+        (`row_ptr` [n_rows + 1], `col_ind` [E]: the nodes each row gathers from), its transpose (`col_ptr` [n_cols + 1],
+        `row_ind` [E]) and `permute` [E] = the CSR position of every CSC entry — the five tensors FusedGATConv takes as
+        keyword arguments (fusedgat_conv.py:95-100) and otherwise rebuilds on the host in every forward (:102-117)."""
+        gp = cls.__new__(cls)
+        gp.engine, gp.index = engine, None
+        gp.N_dst, gp.N_src, gp.E = int(n_rows), int(n_cols), int(col_ind.shape[0])
+        for nm, t, n in (("row_ptr", row_ptr, gp.N_dst + 1), ("col_ptr", col_ptr, gp.N_src + 1), ("col_ind", col_ind, gp.E),
+                         ("row_ind", row_ind, gp.E), ("permute", permute, gp.E)):
+            if t.dim() != 1 or int(t.shape[0]) != n or t.dtype not in (torch.int32, torch.int64):
+                raise RuntimeError(f"{nm} must be a 1-D int32 / int64 tensor of {n} elements, got {tuple(t.shape)} {t.dtype}")
+        engine._dev(row_ptr, col_ind, col_ptr, row_ind, permute)
+        engine._check_range(col_ind, gp.N_src)
+        engine._check_range(row_ind, gp.N_dst)
+        engine._check_range(permute, max(gp.E, 1))
+        gp.fwd = engine.plan_from_rowptr(row_ptr, gp.E)
+        gp.col = col_ind.to(torch.int32).contiguous()
+        gp._bwd = engine.plan_from_rowptr(col_ptr, gp.E)
+        gp._colT = row_ind.to(torch.int32).contiguous()
+        gp._posT = permute.to(torch.int32).contiguous()
+        gp.aux = {}
+        return gp
+
     @property
     def bwd(self):
         if self._bwd is None:
@@ -229,7 +254,7 @@ class Engine:
     def _dev(self, *tensors):
         dev = None
         for t in tensors:
-            if t is None:
+            if t is None or isinstance(t, GraphPlan):
                 continue
             if self.require_cuda and not t.is_cuda:
                 raise RuntimeError(
@@ -379,6 +404,19 @@ class Engine:
             idx = index if index.dtype == torch.int64 else index.to(torch.int64)
             gp = GraphPlan(self, idx.contiguous(), n_dst, n_src)
             self.graph_cache.put(index, (int(n_dst), int(n_src), self.chunk), gp)
+        else:
+            self.stats["plan_hits"] += 1
+        return gp
+
+    def graph_plan_from_csr(self, row_ptr, col_ind, col_ptr, row_ind, permute, n_rows=None, n_cols=None):
+        """GraphPlan of prebuilt CSR + CSC + permutation (FusedGATConv's keyword arguments), cached on `row_ptr`."""
+        n_rows = int(row_ptr.shape[0]) - 1 if n_rows is None else int(n_rows)
+        n_cols = int(col_ptr.shape[0]) - 1 if n_cols is None else int(n_cols)
+        extra = ("csr", n_rows, n_cols, self.chunk) + tuple(_PlanCache.key(t, ()) for t in (col_ind, col_ptr, row_ind, permute))
+        gp = self.graph_cache.get(row_ptr, extra)
+        if gp is None:
+            gp = GraphPlan.from_csr(self, row_ptr, col_ind, col_ptr, row_ind, permute, n_rows, n_cols)
+            self.graph_cache.put(row_ptr, extra, gp)
         else:
             self.stats["plan_hits"] += 1
         return gp

@@ -728,3 +728,50 @@ def test_gat_headmean_layer_aggregate_then_transform(eng, dev):
         eng.chunk = old
         eng.gat_fast = True
         eng.clear_caches()
+
+
+def test_fusedgat_prebuilt_csr_keyword_arguments(eng, dev):
+    """FusedGATConv with the caller's own row_ptr / col_ind / col_ptr / row_ind / permute (fusedgat_conv.py:95-100,
+    int32 as :113-117 makes them) == the same layer on the edge list: the fast 8 x 8 kernels and the head-mean
+    output layer take the CSR + CSC as given (hub rows chunked), no sort and no second plan build."""
+    from gammagl_amd import layers, sparse
+
+    g = torch.Generator().manual_seed(21)
+    old = eng.chunk
+    try:
+        eng.chunk = 32
+        eng.clear_caches()
+        N, E = 300, 6000
+        ei = torch.randint(0, N, (2, E), generator=g)
+        ei[1, :500] = 9                                                   # a hub row of aggregating node 9
+        ei[0, 500:900] = 4                                                # and a hub source (long row of the transpose)
+        ei = layers.add_self_loops(ei.to(dev), N)
+        s1 = sparse.sort_edge_index(torch.stack([ei[1], ei[0]]), num_nodes=N, eng=eng)
+        s2, permute = sparse.sort_edge_index(s1, torch.arange(ei.shape[1], device=dev), N, sort_by_row=False, eng=eng)
+        kw = dict(row_ptr=sparse.ind2ptr(s1[0], N, eng=eng).int(), col_ind=s1[1].int(),
+                  col_ptr=sparse.ind2ptr(s2[1], N, eng=eng).int(), row_ind=s2[0].int(), permute=permute.int())
+        for (F, C, concat) in ((32, 8, True), (64, 41, False)):
+            fg = layers.FusedGATConv(F, C, heads=8, concat=concat).to(dev)
+            x = torch.randn(N, F, generator=g).to(dev)
+            go = torch.randn(N, 8 * C if concat else C, generator=g).to(dev)
+            res = []
+            for use_kw in (False, True):
+                for p_ in fg.parameters():
+                    p_.grad = None
+                xa = x.clone().requires_grad_(True)
+                y = fg(xa, None, N, **kw) if use_kw else fg(xa, ei, N)
+                y.backward(go)
+                res.append([y.detach(), xa.grad, fg.w.grad.clone(), fg.att.grad.clone()])
+            for a, b, nm in zip(res[0], res[1], ("y", "gx", "gW", "gatt")):
+                tol = 2e-4 * float(b.abs().max()) + 1e-6
+                assert float((a - b).abs().max()) <= tol, (F, C, nm, float((a - b).abs().max()), tol)
+        built = eng.stats["plans_built"]
+        fg(x, None, N, **kw)
+        assert eng.stats["plans_built"] == built
+        with pytest.raises(IndexError):
+            bad = dict(kw, col_ind=kw["col_ind"].clone())
+            bad["col_ind"][0] = N
+            fg(x, None, N, **bad)
+    finally:
+        eng.chunk = old
+        eng.clear_caches()

@@ -1,7 +1,7 @@
 """gammagl_amd/layers.py without a GPU: in a subprocess the package's engine is replaced by the host-emulation
 build (test-only injection, as in the gloo tests) and the layer classes are checked against the formulas of the
 reference layers written out in plain torch: GCNConv (all norms, cached norm weights, padded class widths, fused
-epilogue through GCNModel, learnable edge weights), SAGEConv (mean / gcn / pool, fused and segment routes),
+epilogue through GCNModel, learnable edge weights), SAGEConv (mean / gcn / pool / lstm, fused and segment routes),
 GATConv == FusedGATConv (incl. 41 channels per head), the GAT / GraphSAGE models."""
 import os
 import subprocess
@@ -126,6 +126,11 @@ def _body():
     mx = torch.full((nd, 10), -3.4028234663852886e38).scatter_reduce(0, blk[1].view(-1, 1).expand(-1, 10), hp[blk[0]], "amax")
     torch.testing.assert_close(pool((x, x[:nd]), blk), pool.fc_neigh(mx) + pool.fc_self(x[:nd]) + pool.bias,
                                rtol=1e-5, atol=1e-5)
+    # aggr='lstm' (sage_conv.py:93-98): the source rows as [N_dst, fan-out, D] sequences, last hidden state
+    lst = layers.SAGEConv(10, 6, aggr="lstm")
+    xs = torch.randn(nd * 3, 10, generator=g)
+    want = lst.fc_neigh(lst.lstm(xs.reshape(nd, 3, 10))[1][0][0]) + lst.fc_self(x[:nd]) + lst.bias
+    torch.testing.assert_close(lst((xs, x[:nd]), blk), want, rtol=1e-6, atol=1e-6)
     # GATConv == FusedGATConv, narrow and 41 channels per head (padded inside the fused layer)
     for (C, concat) in ((8, True), (41, False)):
         gat = layers.GATConv(10, C, heads=4, concat=concat)
@@ -139,6 +144,22 @@ def _body():
         torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-4, atol=2e-5)
         torch.testing.assert_close(gat.w.grad, fgat.w.grad, rtol=2e-4, atol=2e-5)
         torch.testing.assert_close(gat.att.grad, fgat.att.grad, rtol=2e-4, atol=2e-5)
+        # the prebuilt CSR / CSC / permute keyword arguments (fusedgat_conv.py:95-117 builds exactly these), int32
+        from gammagl_amd import sparse
+        s1 = sparse.sort_edge_index(torch.stack([ei[1], ei[0]]), num_nodes=N, eng=eng)       # rows = aggregating nodes
+        s2, permute = sparse.sort_edge_index(s1, torch.arange(ei.shape[1]), N, sort_by_row=False, eng=eng)
+        kw = dict(row_ptr=sparse.ind2ptr(s1[0], N, eng=eng).int(), col_ind=s1[1].int(),
+                  col_ptr=sparse.ind2ptr(s2[1], N, eng=eng).int(), row_ind=s2[0].int(), permute=permute.int())
+        xc = x.clone().requires_grad_(True)
+        built = eng.stats["plans_built"]
+        yc = fgat(xc, None, N, **kw)
+        torch.testing.assert_close(yc, yb, rtol=1e-5, atol=1e-6)
+        fgat.zero_grad()
+        yc.square().sum().backward()
+        torch.testing.assert_close(xc.grad, xb.grad, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(gat.att.grad, fgat.att.grad, rtol=2e-4, atol=2e-5)
+        fgat(x, None, N, **kw)
+        assert eng.stats["plans_built"] == built + 2      # CSR + CSC taken as given, once; the second call hits the cache
     # models: GAT (fused, dropout on) trains a step; GraphSAGE sample model + layer-wise inference; full model
     gm = layers.GATModel(10, 8, 5, heads=4, drop_rate=0.5, num_layers=2, fused=True)
     gm.train()
