@@ -44,6 +44,7 @@ Options &options() {
     t.unroll_narrow = env_i64("GGL_UNROLL_NARROW", t.unroll_narrow);
     t.xcd_swizzle = env_i64("GGL_XCD_SWIZZLE", t.xcd_swizzle);
     t.force_generic = env_i64("GGL_FORCE_GENERIC", t.force_generic);
+    t.ragged4 = env_i64("GGL_RAGGED4", t.ragged4);
     t.row_order = env_i64("GGL_ROW_ORDER", t.row_order);
     t.max_grid_x = env_i64("GGL_MAX_GRID_X", t.max_grid_x);
     return t;
@@ -249,6 +250,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "unroll_narrow")) o.unroll_narrow = value;
   else if (!strcmp(name, "xcd_swizzle")) o.xcd_swizzle = value;
   else if (!strcmp(name, "force_generic")) o.force_generic = value;
+  else if (!strcmp(name, "ragged4")) o.ragged4 = value;
   else if (!strcmp(name, "row_order")) o.row_order = value;
   else if (!strcmp(name, "max_grid_x")) o.max_grid_x = value > 0 ? value : 1;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
@@ -261,6 +263,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "unroll_narrow")) return o.unroll_narrow;
   if (!strcmp(name, "xcd_swizzle")) return o.xcd_swizzle;
   if (!strcmp(name, "force_generic")) return o.force_generic;
+  if (!strcmp(name, "ragged4")) return o.ragged4;
   if (!strcmp(name, "row_order")) return o.row_order;
   if (!strcmp(name, "max_grid_x")) return o.max_grid_x;
   return -1;

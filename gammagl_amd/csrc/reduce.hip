@@ -139,14 +139,51 @@ template <> struct VecIO<double, 2> {
   }
 };
 
+// RAGGED f32 rows (K % 4 != 0, or a base / stride that is not 16-byte aligned): still four floats per lane.  A row of
+// 47 floats used to take the VEC = 1 kernels — one dword per lane, 64 lanes per row, and a wave-wide dword load
+// costs the texture addresser as many cycles as a dwordx4 one — at 3.3 TB/s where K = 48 runs at 5+.  Here lanes
+// 0 .. K/4 - 1 move 16 bytes from a 4-byte aligned address (global_load_dwordx4 needs dword alignment only) and the
+// last lane of the row moves the K % 4 floats that are left: `nv` = this lane's valid components.
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+template <typename S, int VEC, bool RAG> struct RowIO {
+  static __device__ __forceinline__ void load(const S *__restrict__ p, S (&v)[VEC], int) { VecIO<S, VEC>::load(p, v); }
+  static __device__ __forceinline__ void store(S *__restrict__ p, const S (&v)[VEC], int) { VecIO<S, VEC>::store(p, v); }
+};
+template <> struct RowIO<float, 4, true> {
+  static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[4], int nv) {
+    if (nv == 4) {
+      const F4U t = *reinterpret_cast<const F4U *>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = i < nv ? p[i] : 0.0f;
+    }
+  }
+  static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[4], int nv) {
+    if (nv == 4) {
+      F4U t;
+      t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+      *reinterpret_cast<F4U *>(p) = t;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nv) p[i] = v[i];
+    }
+  }
+};
+template <int VEC, bool RAG> __device__ __forceinline__ int valid_lanes(int64_t K, int64_t kk) {
+  return RAG ? (int)((K - kk) < VEC ? (K - kk) : VEC) : VEC;
+}
+
 // ---- reduce sorted positions [beg, end) of `row` for the VEC features starting at kk -------------
-template <typename T, int VEC, int OP, int MODE, int IDX, int U>
+template <typename T, int VEC, int OP, int MODE, int IDX, int U, bool RAG = false>
 __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, const ReduceDims &d,
                                              int64_t row, int64_t beg, int64_t end, int64_t kk,
                                              typename TT<T>::A (&acc)[VEC], int64_t (&arg)[VEC]) {
   using S = typename TT<T>::S;
   using A = typename TT<T>::A;
   const int64_t K = d.K;
+  const int nv = valid_lanes<VEC, RAG>(K, kk);
   const int64_t head = (MODE == MODE_BSPMM) ? kk / d.C : 0;
   // resolve the index mode (compile time unless IDX_RUNTIME)
   const bool seg_perm = seg_like(MODE) && (IDX == IDX_RUNTIME ? q.perm != nullptr : IDX == IDX_PERM);
@@ -204,7 +241,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
 #pragma unroll
     for (int u = 0; u < U; ++u) element(p + u, xrow[u], wv[u], who[u]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) VecIO<S, VEC>::load(q.x + xrow[u] * d.x_ld + kk, raw[u]);
+    for (int u = 0; u < U; ++u) RowIO<S, VEC, RAG>::load(q.x + xrow[u] * d.x_ld + kk, raw[u], nv);
 #pragma unroll
     for (int u = 0; u < U; ++u) accumulate(raw[u], xrow[u], wv[u], who[u]);
   }
@@ -221,7 +258,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
 #pragma unroll
       for (int u = 0; u < TB; ++u) element(p + u, xrow[u], wv[u], who[u]);
 #pragma unroll
-      for (int u = 0; u < TB; ++u) VecIO<S, VEC>::load(q.x + xrow[u] * d.x_ld + kk, raw[u]);
+      for (int u = 0; u < TB; ++u) RowIO<S, VEC, RAG>::load(q.x + xrow[u] * d.x_ld + kk, raw[u], nv);
 #pragma unroll
       for (int u = 0; u < TB; ++u) accumulate(raw[u], xrow[u], wv[u], who[u]);
     }
@@ -236,7 +273,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
       if (u < rem) element(p + u, xrow[u], wv[u], who[u]);
 #pragma unroll
     for (int u = 0; u < TB - 1; ++u)
-      if (u < rem) VecIO<S, VEC>::load(q.x + xrow[u] * d.x_ld + kk, raw[u]);
+      if (u < rem) RowIO<S, VEC, RAG>::load(q.x + xrow[u] * d.x_ld + kk, raw[u], nv);
 #pragma unroll
     for (int u = 0; u < TB - 1; ++u)
       if (u < rem) accumulate(raw[u], xrow[u], wv[u], who[u]);
@@ -254,25 +291,26 @@ __device__ __forceinline__ void init_acc(typename TT<T>::A (&acc)[VEC], int64_t 
 }
 
 // accumulate mode: the row starts from what `out` already holds (sum only)
-template <typename T, int VEC, int OP>
+template <typename T, int VEC, int OP, bool RAG = false>
 __device__ __forceinline__ void seed_acc(const ReduceDims &d, const typename TT<T>::S *__restrict__ out,
                                          int64_t row, int64_t kk, typename TT<T>::A (&acc)[VEC]) {
   if (OP == OP_SUM && d.accumulate) {
     typename TT<T>::S o[VEC];
-    VecIO<typename TT<T>::S, VEC>::load(out + row * d.out_ld + kk, o);
+    RowIO<typename TT<T>::S, VEC, RAG>::load(out + row * d.out_ld + kk, o, valid_lanes<VEC, RAG>(d.K, kk));
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = TT<T>::load(o[i]);
   }
 }
 
 // mean / store epilogue of a finished row
-template <typename T, int VEC, int OP, int MODE>
+template <typename T, int VEC, int OP, int MODE, bool RAG = false>
 __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, const ReduceDims &d,
                                            typename TT<T>::S *__restrict__ out,
                                            int64_t *__restrict__ argout, int64_t K, int64_t row,
                                            int64_t len, int64_t kk, typename TT<T>::A (&acc)[VEC],
                                            const int64_t (&arg)[VEC]) {
   using S = typename TT<T>::S;
+  const int nv = valid_lanes<VEC, RAG>(K, kk);
   if (OP == OP_MEAN) {
     if (seg_like(MODE)) {
       // segment_mean_cpu.cpp:67-76: count lives in x's dtype; divide only where count > 1
@@ -295,28 +333,37 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
     const int64_t kg = d.epi_col0 + kk;  // column of acc[0] in the full epi_K-wide row
     if (d.epi_thresh) {
       const int64_t KV = (d.epi_K + ev - 1) / ev;
-      const U4 u = philox4x32_10((uint64_t)(row * KV + kg / ev), (uint64_t)q.epi_rng[1], (uint64_t)q.epi_rng[0]);
-      rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
+      if (RAG && VEC > 1 && ev == 1) {  // one Philox word per ELEMENT (epi_K % 4 != 0): component x of its own draw
+#pragma unroll
+        for (int i = 0; i < (VEC < 4 ? VEC : 4); ++i)
+          rw[i] = i < nv ? philox4x32_10((uint64_t)(row * KV + kg + i), (uint64_t)q.epi_rng[1], (uint64_t)q.epi_rng[0]).x
+                         : 0xffffffffu;
+      } else {
+        const U4 u = philox4x32_10((uint64_t)(row * KV + kg / ev), (uint64_t)q.epi_rng[1], (uint64_t)q.epi_rng[0]);
+        rw[0] = u.x; rw[1] = u.y; rw[2] = u.z; rw[3] = u.w;
+      }
     }
+    const bool own_words = RAG && VEC > 1 && ev == 1;
     float addv[VEC];
-    if (q.epi_add) VecIO<float, VEC>::load(q.epi_add + row * d.add_ld + kk, addv);
+    if (q.epi_add) RowIO<float, VEC, RAG>::load(q.epi_add + row * d.add_ld + kk, addv, nv);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float v = (float)acc[i];
       if (q.epi_add) v = __fadd_rn(v, addv[i]);
-      if (q.epi_bias) v = __fadd_rn(v, q.epi_bias[kk + i]);
+      if (q.epi_bias && (!RAG || i < nv)) v = __fadd_rn(v, q.epi_bias[kk + i]);
       if (d.epi_relu) v = (v < 0.0f) ? 0.0f : v;
-      if (d.epi_thresh) v = (rw[(kg + i) % ev] >= d.epi_thresh) ? __fmul_rn(v, d.epi_scale) : 0.0f;
+      if (d.epi_thresh) v = (rw[own_words ? i : (kg + i) % ev] >= d.epi_thresh) ? __fmul_rn(v, d.epi_scale) : 0.0f;
       acc[i] = (typename TT<T>::A)v;
     }
   }
   S o[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
-  VecIO<S, VEC>::store(out + row * d.out_ld + kk, o);
+  RowIO<S, VEC, RAG>::store(out + row * d.out_ld + kk, o, nv);
   if (OP == OP_MAX) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) argout[row * K + kk + i] = arg[i];
+    for (int i = 0; i < VEC; ++i)
+      if (!RAG || i < nv) argout[row * K + kk + i] = arg[i];
   }
 }
 
@@ -333,7 +380,7 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
 // partial buffer; they carry the lowest block ids so the hub work is dispatched first and the tail
 // of the launch is made of short rows.  Blocks [chunk_blocks, chunk_blocks + nblocks) own rows.
 // long_final_kernel then combines the partials of each long row in chunk order.
-template <typename T, int VEC, int OP, int MODE, int IDX, bool UNIFORM, int U>
+template <typename T, int VEC, int OP, int MODE, int IDX, bool UNIFORM, int U, bool RAG = false>
 __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(typename TT<T>::S),
                                                             const int32_t *__restrict__ row_order,
                                                             const int32_t *__restrict__ long_rows,
@@ -367,14 +414,16 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
       A acc[VEC];
       int64_t arg[VEC];
       init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
-      reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
+      reduce_range<T, VEC, OP, MODE, IDX, U, RAG>(q, d, row, beg, end, kk, acc, arg);
       S o[VEC];
 #pragma unroll
       for (int i = 0; i < VEC; ++i) o[i] = TT<T>::store(acc[i]);
-      VecIO<S, VEC>::store(partial + cid * d.K + kk, o);
+      const int nv = valid_lanes<VEC, RAG>(d.K, kk);
+      RowIO<S, VEC, RAG>::store(partial + cid * d.K + kk, o, nv);
       if (OP == OP_MAX) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) partial_arg[cid * d.K + kk + i] = arg[i];
+        for (int i = 0; i < VEC; ++i)
+          if (!RAG || i < nv) partial_arg[cid * d.K + kk + i] = arg[i];
       }
     }
     return;
@@ -404,9 +453,9 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
     A acc[VEC];
     int64_t arg[VEC];
     init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
-    seed_acc<T, VEC, OP>(d, out, row, kk, acc);
-    reduce_range<T, VEC, OP, MODE, IDX, U>(q, d, row, beg, end, kk, acc, arg);
-    finish_row<T, VEC, OP, MODE>(q, d, out, argout, d.K, row, len, kk, acc, arg);
+    seed_acc<T, VEC, OP, RAG>(d, out, row, kk, acc);
+    reduce_range<T, VEC, OP, MODE, IDX, U, RAG>(q, d, row, beg, end, kk, acc, arg);
+    finish_row<T, VEC, OP, MODE, RAG>(q, d, out, argout, d.K, row, len, kk, acc, arg);
   }
 }
 
@@ -495,10 +544,10 @@ static inline int pow2_ceil_log2(int64_t v) {
 #define GGL_RPTR_ARGS(S)                                                                           \
   static_cast<const S *>(a.x), a.perm, a.col, a.w, a.rowptr, a.aux_rowptr, a.aux_arg, a.epi_bias, a.epi_rng, a.epi_add
 
-template <typename T, int VEC, int OP, int MODE, int IDX>
+template <typename T, int VEC, int OP, int MODE, int IDX, bool RAG = false>
 static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
   using S = typename TT<T>::S;
-  const bool uniform = (d.logL == 6) && std::is_same<T, float>::value;
+  const bool uniform = !RAG && (d.logL == 6) && std::is_same<T, float>::value;   // (ragged rows: K <= 128 only)
   S *out = static_cast<S *>(a.out);
   if (a.n_long > 0)
     GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
@@ -508,23 +557,25 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
   const int32_t *order = (options().row_order && (!uniform || options().row_order > 1)) ? a.row_order : nullptr;
 #define GGL_RR_ARGS GGL_RPTR_ARGS(S), order, a.long_rows, a.chunk_ptr, static_cast<S *>(a.partial), a.partial_arg, out, a.arg, d
   if (uniform) {
-    // the f32 wave-per-row kernels; U = 8 only for the dominant SpMM-sum (A/B knob)
-    if (std::is_same<T, float>::value && VEC == 4 && OP == OP_SUM && spmm_like(MODE) &&
-        options().unroll >= 8) {
-      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 8>), grid,
-                 kBlock, stream, GGL_RR_ARGS);
-    } else {
-      GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 4>), grid,
-                 kBlock, stream, GGL_RR_ARGS);
+    if constexpr (!RAG) {
+      // the f32 wave-per-row kernels; U = 8 only for the dominant SpMM-sum (A/B knob)
+      if (std::is_same<T, float>::value && VEC == 4 && OP == OP_SUM && spmm_like(MODE) &&
+          options().unroll >= 8) {
+        GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 8>), grid,
+                   kBlock, stream, GGL_RR_ARGS);
+      } else {
+        GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, std::is_same<T, float>::value, 4>), grid,
+                   kBlock, stream, GGL_RR_ARGS);
+      }
     }
-  } else if (OP != OP_MAX && d.logL <= 2 && options().unroll_narrow > 4) {
+  } else if (!RAG && OP != OP_MAX && d.logL <= 2 && options().unroll_narrow > 4) {
     // narrow rows (<= 4 lanes per row, K <= 16 floats): a lane moves 16 bytes per element, so the walk is
     // latency-bound; 16 elements in flight per lane instead of 4 (Reddit-sized segment_sum: K = 1
     // 1.73 -> 1.23 ms, K = 8 2.56 -> 2.12 ms, profiles/r1_smallk_probe.txt).  Not for max: its int64
     // argmax registers make the deeper unroll slower (2.79 -> 3.27 ms).
     GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 16>), grid, kBlock, stream, GGL_RR_ARGS);
   } else {
-    GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 4>), grid, kBlock, stream, GGL_RR_ARGS);
+    GGL_LAUNCH((row_reduce_kernel<T, VEC, OP, MODE, IDX, false, 4, RAG>), grid, kBlock, stream, GGL_RR_ARGS);
   }
 #undef GGL_RR_ARGS
   GGL_LAUNCH_CHECK();
@@ -538,7 +589,7 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
 }
 
 // STATIC_IDX: compile-time index modes (hot f32 segment / SpMM kernels); otherwise IDX_RUNTIME
-template <typename T, int VEC, int OP, int MODE, bool STATIC_IDX>
+template <typename T, int VEC, int OP, int MODE, bool STATIC_IDX, bool RAG = false>
 static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   ReduceDims d{};
   d.N = a.N; d.K = a.K; d.E = a.E; d.arg_fill = a.arg_fill; d.chunk = a.chunk; d.H = a.H; d.C = a.C;
@@ -556,8 +607,8 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   d.swizzle = (int)options().xcd_swizzle;
   GGL_REQUIRE(d.nblocks < ((int64_t)1 << 30), GGL_EINVAL, "too many rows for one launch");
   if (a.N <= 0 || a.K <= 0) return GGL_OK;
-  if constexpr (!STATIC_IDX) {
-    return launch_idx<T, VEC, OP, MODE, IDX_RUNTIME>(a, d, stream);
+  if constexpr (!STATIC_IDX || RAG) {   // (the ragged kernels resolve the index mode at run time: one variant each)
+    return launch_idx<T, VEC, OP, MODE, IDX_RUNTIME, RAG>(a, d, stream);
   } else if constexpr (seg_like(MODE)) {
     if (a.perm) return launch_idx<T, VEC, OP, MODE, IDX_PERM>(a, d, stream);
     return launch_idx<T, VEC, OP, MODE, IDX_DIRECT>(a, d, stream);
@@ -578,6 +629,14 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
                     (a.x_ld % 4 == 0) && (a.out_ld % 4 == 0) && (MODE != MODE_BSPMM || a.C % 4 == 0) &&
                     (!a.epi_add || (aligned16(a.epi_add) && a.add_ld % 4 == 0));
   if (vec4) return launch_typed<float, 4, OP, MODE, kStatic>(a, stream);
+  // rows that are not made of aligned float4s: four floats per lane all the same, ragged last lane (see RowIO).
+  // Measured on the products-sized graph (profiles/r2_ragged_rows.txt; same bits): gspmm max K = 101 12.5 -> 8.8 ms,
+  // K = 41 6.2 -> 5.5 ms, segment_sum [E, 47] 7.46 -> 7.22 ms; below 32 columns the VEC = 1 kernels with 16 loads in
+  // flight win by 3x and wave-per-row widths (K > 128) lose 7 %, so only 32 <= K <= 128 takes it.
+  if constexpr (seg_like(MODE) || spmm_like(MODE)) {
+    if (!options().force_generic && options().ragged4 && a.K >= 32 && a.K <= 128)
+      return launch_typed<float, 4, OP, MODE, kStatic, true>(a, stream);
+  }
   return launch_typed<float, 1, OP, MODE, kStatic>(a, stream);
 }
 

@@ -1018,7 +1018,7 @@ def check_epilogue_forms(eng, dev):
         for chunk in (0, 8):
             eng.chunk = chunk
             eng.graph_cache.clear(); eng.seg_cache.clear()
-            for (Nd, Ns, E, K) in ((40, 70, 600, 8), (64, 64, 900, 64), (50, 90, 700, 256), (6, 9, 0, 12)):
+            for (Nd, Ns, E, K) in ((40, 70, 600, 8), (64, 64, 900, 64), (50, 90, 700, 256), (6, 9, 0, 12), (45, 60, 500, 70)):
                 ei = torch.stack([torch.randint(0, Ns, (E,), generator=g), torch.randint(0, Nd, (E,), generator=g)])
                 if E:
                     ei[1, : E // 3] = 3
