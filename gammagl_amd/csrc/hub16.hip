@@ -18,7 +18,8 @@ constexpr int kHubStage = 256;              // elements per LDS half = producer 
 constexpr int kHubCols = 64;                // columns per slab = consumer lanes
 constexpr int kHubBlock = kWave + kHubStage;  // wavefront 0 consumes, wavefronts 1-4 produce
 
-template <typename T>
+// V16: K % 8 == 0 and 16-byte aligned rows — the slab of an element moves as 16-byte pieces; otherwise element by element
+template <typename T, bool V16>
 __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *__restrict__ x,
                                                                const int32_t *__restrict__ perm,
                                                                const int64_t *__restrict__ rowptr,
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
   const int64_t row = long_rows[j];
   const int64_t beg = rowptr[row], end = rowptr[row + 1], len = end - beg;
   const int64_t c0 = slab * kHubCols;
-  const int ncol = (int)((K - c0) < kHubCols ? (K - c0) : kHubCols);   // multiple of 8 (checked at launch)
+  const int ncol = (int)((K - c0) < kHubCols ? (K - c0) : kHubCols);   // (V16: a multiple of 8)
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t nst = (len + kHubStage - 1) / kHubStage;
   const int parts = ncol >> 3;                                          // 16-byte pieces per element of this slab
@@ -45,14 +46,27 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
     };
     auto fill = [&](int64_t src, int b) {
       if (src < 0) return;
-      const uint4 *g = reinterpret_cast<const uint4 *>(x + src * K + c0);
-      uint4 v[8];
+      if (V16) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(x + src * K + c0);
+        uint4 v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (q < parts) v[q] = g[q];
+        for (int q = 0; q < 8; ++q)
+          if (q < parts) v[q] = g[q];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (q < parts) *reinterpret_cast<uint4 *>(&buf[b][e][q * 8]) = v[q];
+        for (int q = 0; q < 8; ++q)
+          if (q < parts) *reinterpret_cast<uint4 *>(&buf[b][e][q * 8]) = v[q];
+      } else {
+        const uint16_t *g = x + src * K + c0;
+        for (int q0 = 0; q0 < ncol; q0 += 8) {  // 8 two-byte loads in flight
+          uint16_t v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q0 + q < ncol) v[q] = g[q0 + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q0 + q < ncol) buf[b][e][q0 + q] = v[q];
+        }
+      }
     };
     int64_t src = src_of(0);
     int64_t nxt = nst > 1 ? src_of(1) : -1;
@@ -100,8 +114,8 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
 using namespace ggl;
 
 extern "C" int ggl_segment_hub16_supported(int dtype, int64_t K, const void *x, const void *out) {
-  return ((dtype == GGL_F16 || dtype == GGL_BF16) && K > 0 && K % 8 == 0 &&
-          (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 1u) == 0) ? 1 : 0;
+  return ((dtype == GGL_F16 || dtype == GGL_BF16) && K > 0 && (reinterpret_cast<uintptr_t>(x) & 1u) == 0 &&
+          (reinterpret_cast<uintptr_t>(out) & 1u) == 0) ? 1 : 0;
 }
 
 // sum (mean = 0) / mean (mean = 1) of the plan's LONG rows only (plan->long_rows, n_long), each in the reference's
@@ -111,18 +125,22 @@ extern "C" int ggl_segment_hub16(int dtype, int mean, const void *x, const ggl_s
                                  void *stream) {
   GGL_REQUIRE(plan && plan->rowptr, GGL_EINVAL, "plan is NULL");
   GGL_REQUIRE(ggl_segment_hub16_supported(dtype, K, x, out), GGL_EINVAL,
-              "ggl_segment_hub16: f16 / bf16 rows of a multiple of 8 columns, 16-byte aligned");
+              "ggl_segment_hub16: f16 / bf16 rows");
   if (plan->n_long <= 0) return GGL_OK;
   GGL_REQUIRE(plan->long_rows && x && out, GGL_EINVAL, "NULL pointer");
   const int64_t slabs = ceil_div(K, (int64_t)kHubCols);
   const int64_t grid = plan->n_long * slabs;
   hipStream_t s = as_stream(stream);
-  if (dtype == GGL_F16)
-    GGL_LAUNCH((hub_rows16_kernel<f16_t>), grid, kHubBlock, s, static_cast<const uint16_t *>(x), plan->perm, plan->rowptr,
-               plan->long_rows, plan->n_long, K, slabs, mean ? 1 : 0, static_cast<uint16_t *>(out));
-  else
-    GGL_LAUNCH((hub_rows16_kernel<bf16_t>), grid, kHubBlock, s, static_cast<const uint16_t *>(x), plan->perm, plan->rowptr,
-               plan->long_rows, plan->n_long, K, slabs, mean ? 1 : 0, static_cast<uint16_t *>(out));
+  const bool v16 = K % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+#define GGL_HUB16(T, V)                                                                                          \
+  GGL_LAUNCH((hub_rows16_kernel<T, V>), grid, kHubBlock, s, static_cast<const uint16_t *>(x), plan->perm, plan->rowptr, \
+             plan->long_rows, plan->n_long, K, slabs, mean ? 1 : 0, static_cast<uint16_t *>(out))
+  if (dtype == GGL_F16) {
+    if (v16) GGL_HUB16(f16_t, true); else GGL_HUB16(f16_t, false);
+  } else {
+    if (v16) GGL_HUB16(bf16_t, true); else GGL_HUB16(bf16_t, false);
+  }
+#undef GGL_HUB16
   GGL_LAUNCH_CHECK();
   return GGL_OK;
 }

@@ -156,8 +156,8 @@ int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_
                      void *stream);
 /* f16 / bf16 sums accumulate in the storage type (segment_sum_cpu.cpp:47-56), so their hub rows cannot be chunked:
  * ggl_segment_hub16 reduces the plan's LONG rows (plan->long_rows) in the reference's serial order with a workgroup
- * per (row, 64-column slab) that prefetches through LDS (GPU build only; ggl_segment_hub16_supported: K % 8 == 0,
- * 16-byte aligned x).  Pair it with ggl_segment_{sum,mean} on the same plan with the long-row table withheld
+ * per (row, 64-column slab) that prefetches through LDS (GPU build only: ggl_segment_hub16_supported; rows of a
+ * multiple of 8 columns move as 16-byte pieces, other widths element by element).  Pair it with ggl_segment_{sum,mean} on the same plan with the long-row table withheld
  * (n_long = 0, chunk kept): that launch skips rows longer than chunk. */
 int ggl_segment_hub16_supported(int dtype, int64_t K, const void *x, const void *out);
 int ggl_segment_hub16(int dtype, int mean, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,

@@ -275,10 +275,10 @@ def check_long_rows(eng, dev, oracle, chunk=8):
             xi = rng.integers(-100, 100, size=(E, K)).astype(np.int32)
             assert_same(to_np(eng.c_segment_sum(to_t(xi, dev), it, N)), oracle.segment_sum(xi, ids, N), "long i32")
             assert_same(to_np(eng.c_segment_mean(to_t(xi, dev), it, N)), oracle.segment_mean(xi, ids, N), "long i32 mean")
-        # f16 / bf16 accumulate in the storage type: their hub rows are never chunked.  With K % 8 == 0 the GPU build
-        # hands them to the LDS-pipelined hub kernel (hub16.hip), otherwise (and in the emulated build) one lane group
-        # walks them: both must be the reference's serial result bit for bit — sums that saturate included.
-        for K in (8, 40, 64, 72, 256, 5):
+        # f16 / bf16 accumulate in the storage type: their hub rows are never chunked.  The GPU build
+        # hands them to the LDS-pipelined hub kernel (hub16.hip; 16-byte pieces / element by element), in the emulated
+        # build one lane group walks them: both must be the reference's serial result bit for bit — sums that saturate included.
+        for K in (8, 40, 64, 72, 256, 5, 1, 47, 130):
             ids = rng.integers(0, N, size=E).astype(np.int64)
             ids[:700] = 7       # 700 > 2 x 256: several LDS stages + a ragged last one
             ids[700:1000] = 0

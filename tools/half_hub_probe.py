@@ -36,7 +36,7 @@ hub[:109110] = 5                      # a Reddit-sized hub row on the arxiv-size
 for label, ids in (("arxiv R-MAT (max row %d)" % int(torch.bincount(dst).max()), dst), ("+ a 109 110-element hub", hub)):
     for dt in (torch.float32, torch.float16, torch.bfloat16):
         line = f"{label:32s} {str(dt):15s}"
-        for K in (16, 64, 256):
+        for K in (7, 16, 47, 64, 256):
             x = torch.randn(ids.shape[0], K, device=dev).to(dt)
             with torch.no_grad():
                 t = timed(lambda: eng.c_segment_sum(x, ids, n))
