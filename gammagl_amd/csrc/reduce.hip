@@ -633,7 +633,8 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
   // Measured on the products-sized graph (profiles/r2_ragged_rows.txt; same bits): gspmm max K = 101 12.5 -> 8.8 ms,
   // K = 41 6.2 -> 5.5 ms, segment_sum [E, 47] 7.46 -> 7.22 ms; below 32 columns the VEC = 1 kernels with 16 loads in
   // flight win by 3x and wave-per-row widths (K > 128) lose 7 %, so only 32 <= K <= 128 takes it.
-  if constexpr (seg_like(MODE) || spmm_like(MODE)) {
+  // (not segment_max: its int64 argmax registers make the 4-wide lanes slower there, [E, 47] 7.9 -> 9.1 ms)
+  if constexpr ((seg_like(MODE) && OP != OP_MAX) || spmm_like(MODE)) {
     if (!options().force_generic && options().ragged4 && a.K >= 32 && a.K <= 128)
       return launch_typed<float, 4, OP, MODE, kStatic, true>(a, stream);
   }
