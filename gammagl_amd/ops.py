@@ -101,6 +101,9 @@ class GraphPlan:
         engine._check_range(col_ind, gp.N_src)
         engine._check_range(row_ind, gp.N_dst)
         engine._check_range(permute, max(gp.E, 1))
+        for nm, ptr in (("row_ptr", row_ptr), ("col_ptr", col_ptr)):   # one-off (per plan) host reads
+            if int(ptr[0]) != 0 or int(ptr[-1]) != gp.E or (ptr.numel() > 1 and bool((ptr[1:] < ptr[:-1]).any())):
+                raise RuntimeError(f"{nm} must rise from 0 to the number of edges ({gp.E})")
         gp.fwd = engine.plan_from_rowptr(row_ptr, gp.E)
         gp.col = col_ind.to(torch.int32).contiguous()
         gp._bwd = engine.plan_from_rowptr(col_ptr, gp.E)
