@@ -5,7 +5,7 @@ share out of it, dist.PartitionedGraph.from_local builds the halo bookkeeping as
 buffers exactly as in the 8-rank run, nothing on the wire), and the step runs as the rank would run it minus link
 time: send-row gather, local SpMM, halo SpMM with the fused epilogue, the transposed walks, reverse scatter.
 
-    python tools/share_probe.py [papers100M|products] [parts] [rank] [out.json]"""
+    python tools/share_probe.py [papers100M|products] [parts] [rank] [out.json] [relabel: random|degree|none]"""
 import json
 import os
 import sys
@@ -24,13 +24,14 @@ name = sys.argv[1] if len(sys.argv) > 1 else "papers100M"
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 r = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 out_path = sys.argv[4] if len(sys.argv) > 4 else None
+relabel = sys.argv[5] if len(sys.argv) > 5 else "random"
 n, e, f_in, n_cls = DATASETS[name]
 K = 256
-res = {"workload": f"{name}-sized R-MAT N={n} E_dir={e}, rank {r} of {P} (dry partition on one GPU)"}
+res = {"workload": f"{name}-sized R-MAT N={n} E_dir={e}, rank {r} of {P} (dry partition on one GPU), relabel={relabel}"}
 torch.cuda.reset_peak_memory_stats()
 t0 = time.perf_counter()
 stats = {}
-pg = build_partition(n, e, 0, r, 1, None, dev, eng, parts=P, stats=stats)
+pg = build_partition(n, e, 0, r, 1, None, dev, eng, parts=P, stats=stats, relabel=relabel)
 torch.cuda.synchronize()
 res["build_s"] = round(time.perf_counter() - t0, 1)
 res["build_peak_GB"] = round(torch.cuda.max_memory_allocated() / 1e9, 1)
