@@ -234,3 +234,34 @@ def test_one_rank_share_of_an_8_way_partition(eng, dev):
     mine_src = (src >= pg.lo) & (src < pg.hi) & ((dst < pg.lo) | (dst >= pg.hi))
     assert torch.equal(torch.unique(pg.send_idx), torch.unique(src[mine_src]) - pg.lo)
     assert isinstance(pg, PartitionedGraph)
+
+
+@pytest.mark.parametrize("dt", ["float16", "bfloat16"])
+def test_arxiv_size_16bit_sums_with_a_reddit_sized_hub_row(eng, dev, oracle, dt):
+    """f16 / bf16 unsorted_segment_sum / mean at config 2's size with a 109 110-element hub row (the Reddit-sized
+    graph's longest): sums that accumulate in the storage type depend on the serial order far beyond rounding, and the
+    hub rows go through the LDS-pipelined kernel (hub16.hip) — bit for bit the oracle's result, and the row walk's."""
+    import numpy as np
+
+    import parity_cases as pc
+    from gammagl_amd.synth import DATASETS, rmat_graph
+
+    n, e, _, _ = DATASETS["arxiv"]
+    ids = rmat_graph(n, e, seed=0, device=dev)[1].contiguous()
+    ids[:109110] = 5
+    g = torch.Generator(device=dev).manual_seed(13)
+    for K in (16, 7):
+        xf = (torch.randn(ids.shape[0], K, generator=g, device=dev) * 3 + 0.5).cpu().numpy()
+        xh = oracle.f32_to_bf16_bits(xf) if dt == "bfloat16" else xf.astype(np.float16)
+        xt = pc.to_t(xh, dev, dt)
+        ids_h = ids.cpu().numpy()
+        want_s = oracle.segment_sum(xh, ids_h, n, bf16=dt == "bfloat16")
+        want_m = oracle.segment_mean(xh, ids_h, n, bf16=dt == "bfloat16")
+        assert eng.seg_plan(ids, n).n_long >= 1
+        for hub16 in (True, False):
+            eng.hub16 = hub16
+            try:
+                pc.assert_same(pc.to_np(eng.c_segment_sum(xt, ids, n)), want_s, f"{dt} K{K} sum hub16={hub16}")
+                pc.assert_same(pc.to_np(eng.c_segment_mean(xt, ids, n)), want_m, f"{dt} K{K} mean hub16={hub16}")
+            finally:
+                eng.hub16 = True
