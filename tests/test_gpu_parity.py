@@ -775,3 +775,33 @@ def test_fusedgat_prebuilt_csr_keyword_arguments(eng, dev):
     finally:
         eng.chunk = old
         eng.clear_caches()
+
+
+def test_integration_md_ctypes_stub_runs(dev):
+    """The reference-side binding INTEGRATION.md shows a maintainer (Option B: `_hip_ext.py`, ctypes over the C ABI,
+    one op) is executed as written — only the library path is pointed at the in-tree build — and its c_segment_sum
+    matches unsorted_segment_sum's definition, forward and backward, and raises IndexError on an id out of range
+    (segment_sum_cpu.cpp:13-19)."""
+    import os
+    import re
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(repo, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# gammagl/mpops/torch_ext/_hip_ext\.py.*?)```", text, re.S)
+    assert m, "the _hip_ext.py block is missing from INTEGRATION.md"
+    src = m.group(1).replace('ctypes.CDLL("libggl_mpops_hip.so")',
+                             'ctypes.CDLL(%r)' % os.path.join(repo, "gammagl_amd", "lib", "libggl_mpops_hip.so"))
+    ns = {}
+    exec(compile(src, "INTEGRATION.md:_hip_ext.py", "exec"), ns)   # noqa: S102
+    g = torch.Generator().manual_seed(5)
+    N, E, K = 50, 700, 12
+    ids = torch.randint(0, N, (E,), generator=g).to(dev)
+    x = torch.randn(E, K, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(N, K, generator=g).to(dev)
+    y = ns["c_segment_sum"](x, ids, N)
+    y.backward(go)
+    ref = torch.zeros(N, K, dtype=torch.float64, device=dev).index_add_(0, ids, x.detach().double())
+    torch.testing.assert_close(y.detach().double(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(x.grad, go[ids])
+    with pytest.raises(IndexError):
+        ns["c_segment_sum"](x.detach(), torch.full((E,), N, device=dev), N)
