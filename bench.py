@@ -146,7 +146,7 @@ def cpu_baseline(hidden, classes, seed, full_graph=None):
     return out
 
 
-def measure_traffic(args, hidden):
+def measure_traffic(args, hidden, launches=1):
     """HBM-side bytes per launch of the dominant kernel, measured NOW on this box: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 --pmc passes (MI355X_MICROARCH.md, HBM section: KiB units, x2 on the read side for gfx950) of
     tools/pmc_probe.py, which rebuilds this run's graph and launches the K=hidden SpMM-sum a few times.  Returns
@@ -174,7 +174,10 @@ def measure_traffic(args, hidden):
             xs = []
             with open(files[0], newline="") as f:
                 for row in csv.DictReader(f):
-                    if row["Counter_Name"] == counter and "row_reduce_kernel<float, 4, 0, 1, 1, true" in row["Kernel_Name"]:
+                    # one wavefront per row (true) for a one-launch K = 256 aggregate, 16 lanes per row (false) for its
+                    # 64-column blocks
+                    want = "row_reduce_kernel<float, 4, 0, 1, 1, " + ("true" if launches == 1 else "false, 4")
+                    if row["Counter_Name"] == counter and want in row["Kernel_Name"]:
                         xs.append(float(row["Counter_Value"]))
             if not xs:
                 return None, "kernel not found in the counter file"
@@ -264,7 +267,7 @@ def main():
         assert dist.get_world_size() == args.gpus
     if rank == 0:
         if world == 1 and not emul and args.pmc_traffic == "auto" and args.workload == "products":
-            t, src = measure_traffic(args, args.hidden)
+            t, src = measure_traffic(args, args.hidden, int(out["roofline"].get("launches_per_aggregate", 1)))
             if t is not None:
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t, src
             elif out["roofline"].get("traffic") is not None:

@@ -641,6 +641,50 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
   return launch_typed<float, 1, OP, MODE, kStatic>(a, stream);
 }
 
+// Wide f32 aggregates run as launches over 64-column blocks of the same matrices (row strides passed down: no copy).
+// A 256-byte slice keeps four times as many distinct hub rows in the 4 MiB L2 of an XCD as a 1 KiB row does, and L2
+// hits are the only bytes of this walk that do not cross the fabric (profiles/r2_mall_probe.txt): products-sized
+// graph, K = 256: 16.5 -> 14.8 ms, K = 128: 8.0 -> 7.5 ms; 32-wide blocks lose again (17.3 ms: a 128-byte line per
+// gather whatever the width), as do blocks that are not line multiples (K = 96 as 2 x 48: 5.5 -> 7.3 ms).  The
+// columns of a row are independent sums: same bits; the dropout word of element (row, col) is the full-width one
+// (epi_K / epi_col0).  Small graphs (an arxiv-sized launch is 0.3 ms) take two 128-wide blocks at most.
+static int64_t col_block_width(int64_t E, int64_t K) {   // 0 = one launch
+  int64_t bw = options().col_block;
+  if (bw > 0 && E < options().col_block_min_edges) bw *= 2;
+  if (bw <= 0 || bw % 4 != 0 || K < 2 * bw || K % bw != 0) return 0;
+  return bw;
+}
+// launches one f32 SpMM-sum / mean over E edges and K columns is made of (bench.py's roofline leg reports per launch)
+extern "C" int64_t ggl_spmm_col_blocks(int64_t E, int64_t K) {
+  const int64_t bw = col_block_width(E, K);
+  return bw > 0 ? K / bw : 1;
+}
+
+template <int OP, int MODE>
+static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
+  static_assert(OP != OP_MAX && (MODE == MODE_SPMM || MODE == MODE_SPMM_EPI), "column blocks: sum / mean SpMM only");
+  const int64_t bw = col_block_width(a0.E, a0.K);
+  if (bw <= 0 || a0.N <= 0) return launch_f32<OP, MODE>(a0, stream);
+  for (int64_t c0 = 0; c0 < a0.K; c0 += bw) {
+    ReduceArgs a = a0;
+    a.K = bw;
+    a.x = static_cast<const float *>(a0.x) + c0;
+    a.out = static_cast<float *>(a0.out) + c0;
+    a.x_ld = a0.x_ld > 0 ? a0.x_ld : a0.K;
+    a.out_ld = a0.out_ld > 0 ? a0.out_ld : a0.K;
+    if (a0.epi_bias) a.epi_bias = a0.epi_bias + c0;
+    if (a0.epi_add) {
+      a.epi_add = a0.epi_add + c0;
+      a.add_ld = a0.add_ld > 0 ? a0.add_ld : a0.K;
+    }
+    a.epi_K = a0.epi_K > 0 ? a0.epi_K : a0.K;
+    a.epi_col0 = a0.epi_col0 + c0;
+    const int rc = launch_f32<OP, MODE>(a, stream);
+    if (rc) return rc;
+  }
+  return GGL_OK;
+}
+
 // 16-byte vector path usable: K a multiple of the vector width and every base pointer 16-byte aligned
 static bool wide_ok(const ReduceArgs &a, int vec) {
   return !options().force_generic && a.K % vec == 0 && aligned16(a.x) && aligned16(a.out) &&
@@ -791,7 +835,7 @@ extern "C" int ggl_spmm_sum(const ggl_segplan_t *plan, const int32_t *col, const
   ReduceArgs a{};
   int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
   if (rc) return rc;
-  return launch_f32<OP_SUM, MODE_SPMM>(a, as_stream(stream));
+  return launch_f32_cols<OP_SUM, MODE_SPMM>(a, as_stream(stream));
 }
 
 extern "C" int ggl_spmm_sum_ex(const ggl_segplan_t *plan, const int32_t *col, const float *w, int w_by_pos,
@@ -802,7 +846,7 @@ extern "C" int ggl_spmm_sum_ex(const ggl_segplan_t *plan, const int32_t *col, co
   if (rc) return rc;
   GGL_REQUIRE((x_ld == 0 || x_ld >= K) && (out_ld == 0 || out_ld >= K), GGL_EINVAL, "row stride < K");
   a.x_ld = x_ld; a.out_ld = out_ld; a.accumulate = accumulate ? 1 : 0;
-  return launch_f32<OP_SUM, MODE_SPMM>(a, as_stream(stream));
+  return launch_f32_cols<OP_SUM, MODE_SPMM>(a, as_stream(stream));
 }
 
 // out = dropout(relu(A x + bias)) with the epilogue applied to each finished row in registers: what
@@ -821,7 +865,7 @@ extern "C" int ggl_spmm_sum_bias_act(const ggl_segplan_t *plan, const int32_t *c
   a.epi_relu = relu ? 1 : 0;
   a.epi_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
   a.epi_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-  rc = launch_f32<OP_SUM, MODE_SPMM_EPI>(a, as_stream(stream));
+  rc = launch_f32_cols<OP_SUM, MODE_SPMM_EPI>(a, as_stream(stream));
   if (rc) return rc;
   if (a.epi_thresh && plan->N > 0 && K > 0) return rng_advance(rng_state, stream);
   return GGL_OK;
@@ -856,8 +900,8 @@ extern "C" int ggl_spmm_epi_ex(const ggl_segplan_t *plan, const int32_t *col, co
   a.epi_thresh = p_drop > 0.0f ? (uint32_t)((double)p_drop * 4294967296.0) : 0u;
   a.epi_scale = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
   a.epi_K = epi_K; a.epi_col0 = epi_col0;
-  rc = mean ? launch_f32<OP_MEAN, MODE_SPMM_EPI>(a, as_stream(stream))
-            : launch_f32<OP_SUM, MODE_SPMM_EPI>(a, as_stream(stream));
+  rc = mean ? launch_f32_cols<OP_MEAN, MODE_SPMM_EPI>(a, as_stream(stream))
+            : launch_f32_cols<OP_SUM, MODE_SPMM_EPI>(a, as_stream(stream));
   if (rc) return rc;
   if (a.epi_thresh && advance_rng && plan->N > 0 && K > 0) return rng_advance(rng_state, stream);
   return GGL_OK;
@@ -896,7 +940,7 @@ extern "C" int ggl_spmm_mean(const ggl_segplan_t *plan, const int32_t *col, cons
   ReduceArgs a{};
   int rc = spmm_common(a, plan, col, w, w_by_pos, x, K, out, false);
   if (rc) return rc;
-  return launch_f32<OP_MEAN, MODE_SPMM>(a, as_stream(stream));
+  return launch_f32_cols<OP_MEAN, MODE_SPMM>(a, as_stream(stream));
 }
 
 extern "C" int ggl_spmm_max(const ggl_segplan_t *plan, const int32_t *col, const float *w,
