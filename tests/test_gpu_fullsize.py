@@ -265,3 +265,46 @@ def test_arxiv_size_16bit_sums_with_a_reddit_sized_hub_row(eng, dev, oracle, dt)
                 pc.assert_same(pc.to_np(eng.c_segment_mean(xt, ids, n)), want_m, f"{dt} K{K} mean hub16={hub16}")
             finally:
                 eng.hub16 = True
+
+
+def test_products_size_column_blocks_same_bits(eng, dev):
+    """The K = 256 aggregate as 4 launches over 64-column blocks (reduce.hip launch_f32_cols) == one launch over the
+    1 KiB rows, bit for bit, at the products size: plain sum, its transpose, mean, and the fused epilogue with bias,
+    ReLU and dropout (the blocks draw the full-width mask: epi_K / epi_col0)."""
+    from gammagl_amd.synth import DATASETS, rmat_graph
+
+    n, e, _, _ = DATASETS["products"]
+    ei = rmat_graph(n, e, seed=0, device=dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    w = torch.rand(ei.shape[1], generator=g, device=dev)
+    gp = eng.graph_plan(ei, n)
+    K = 256
+    x = torch.randn(n, K, generator=g, device=dev)
+    bias = torch.randn(K, generator=g, device=dev)
+    assert eng.lib.ggl_spmm_col_blocks(gp.E, K) == 4 and eng.lib.ggl_spmm_col_blocks(gp.E, 100) == 1
+    old = eng.lib.ggl_get_option(b"col_block")
+    res = {}
+    try:
+        for cb in (0, 64):
+            eng.set_option("col_block", cb)
+            outs = []
+            a = torch.empty(n, K, device=dev)
+            eng.spmm_sum_into(gp.fwd, gp.col, w, x, a)
+            outs.append(a.clone())
+            eng.spmm_sum_into(gp.bwd, gp.colT, w, x, a)
+            outs.append(a.clone())
+            eng.spmm_epi_into(gp.fwd, gp.col, w, x, a, mean=True, epi_K=K)
+            outs.append(a.clone())
+            eng.reseed(77)
+            rng = eng._rng_state(dev)
+            st = rng.clone()
+            eng.spmm_epi_into(gp.fwd, gp.col, w, x, a, bias=bias, relu=True, p_drop=0.5, rng=rng, epi_K=K)
+            assert int(rng[1]) != int(st[1])          # the state advanced once for the whole aggregate
+            outs.append(a.clone())
+            res[cb] = outs
+    finally:
+        eng.set_option("col_block", old)
+    for a, b, nm in zip(res[0], res[64], ("sum", "transposed sum", "mean", "bias+relu+dropout")):
+        assert torch.equal(a, b), nm
+    kept = (res[64][3] != 0).float().mean()
+    assert 0.2 < float(kept) < 0.3                    # relu x dropout(0.5) of a zero-mean aggregate
