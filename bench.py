@@ -57,6 +57,10 @@ def parse():
     p.add_argument("--transform-first", action="store_true",
                    help="A (X W) in every layer, as GammaGL's GCNConv writes it (default: a layer whose input is narrower "
                         "than its output computes (A X) W — same product, fewer bytes, no aggregation in layer 1's backward)")
+    p.add_argument("--matmul-precision", default="highest", choices=["highest", "high"],
+                   help="torch.set_float32_matmul_precision for the dense X W products: 'highest' = IEEE f32 MFMA (the "
+                        "line of record); 'high' lets hipBLASLt emulate f32 with bf16 triples on gfx950 (2x faster GEMMs, "
+                        "~5e-6 relative error instead of ~8e-7) — reported only as a side figure")
     p.add_argument("--no-comparison", action="store_true",
                    help="skip the like-for-like transform-first trainer timed beside the default (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -253,12 +257,16 @@ def main():
     from gammagl_amd.dist import run_distributed_bench
     from gammagl_amd.synth import DATASETS
 
+    torch.set_float32_matmul_precision(args.matmul_precision)
+
     if args.workload == "tiny":
         n_nodes, n_edges, f_in, n_cls = 20000, 400000, 100, 47
     else:
         n_nodes, n_edges, f_in, n_cls = DATASETS[args.workload]
     out, pg = run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls, eng=eng)
     out["engine"] = "host-emulation (launcher test, not a measurement)" if emul else "hip"
+    out["config"]["matmul_precision"] = args.matmul_precision + (" (IEEE f32)" if args.matmul_precision == "highest"
+                                                                   else " (hipBLASLt f32 emulated with bf16 triples: NOT the line of record)")
     if emul:
         out["roofline"] = None
     if world > 1:
