@@ -372,16 +372,20 @@ class DistGCN(torch.nn.Module):
 
 class DistGCNTrainer:
     def __init__(self, pg, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, lr=0.01,
-                 l2_coef=5e-4, seed=0, device="cuda", aggregate_first=True):
+                 l2_coef=5e-4, seed=0, device="cuda", aggregate_first=True, capturable=False):
+        """`capturable`: Adam keeps its step counter on the device so that `capture()` can record the whole step
+        into one hipGraph (launch-bound graphs: an arxiv-sized step is ~90 launches of 5-300 us)."""
         self.pg = pg
         torch.manual_seed(seed)  # identical initial weights on every rank
         self.net = DistGCN(feature_dim, hidden_dim, num_class, num_layers, drop_rate,
                            aggregate_first=aggregate_first).to(device)
+        on_gpu = torch.device(device).type == "cuda"
         try:    # one fused optimizer kernel for all parameters on the GPU
-            self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef,
-                                        fused=torch.device(device).type == "cuda")
+            self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef, fused=on_gpu,
+                                        capturable=bool(capturable) and on_gpu)
         except (RuntimeError, TypeError):
             self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef)
+        self.graph = None
         torch.manual_seed(seed + 1000 * (pg.rank + 1))  # independent dropout masks per rank
 
     def step(self, x_local, y_local, train_local, n_train_global):
@@ -403,6 +407,20 @@ class DistGCNTrainer:
                 o += n
         self.opt.step()
         return loss.detach()
+
+    def capture(self, x_local, y_local, train_local, n_train_global, warmup=3):
+        """Record step(...) on these very tensors into one hipGraph (single rank, `capturable=True`); afterwards
+        `replay()` runs a training step — the kernels never sync or allocate outside the graph's pool, the side
+        stream's weight-gradient GEMMs and the dropout draws (state advanced on the device) are part of it."""
+        if self.pg.world > 1:
+            raise RuntimeError("capture() records a single-rank step (the exchange is not recorded into the graph)")
+        from .trainer import GraphedStep
+
+        self.graph = GraphedStep(lambda: self.step(x_local, y_local, train_local, n_train_global), warmup=warmup)
+        return self.graph
+
+    def replay(self):
+        return self.graph()
 
 
 def build_partition(n_nodes, n_edges, seed, rank, world, group, dev, eng, relabel="random", order="src",
