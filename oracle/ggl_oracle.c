@@ -418,7 +418,7 @@ int ggl_oracle_gat_fwd(const int64_t *index, const float *el, const float *er, c
   if (check_coo(index, E, N)) return GGL_ORACLE_EINDEX;
   const int64_t *src = index, *dst = index + E;
   size_t eh = (size_t)(E * H > 0 ? E * H : 1), nh = (size_t)(N * H > 0 ? N * H : 1);
-  float *s = (float *)malloc(eh * 4), *ex = (float *)malloc(eh * 4);
+  float *s = (float *)calloc(eh, 4), *ex = (float *)malloc(eh * 4);
   float *m = (float *)malloc(nh * 4), *d = (float *)malloc(nh * 4);
   int64_t *arg = (int64_t *)malloc(nh * 8);
   float *msg = (float *)malloc((size_t)(E * H * C > 0 ? E * H * C : 1) * 4);
