@@ -674,13 +674,17 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
 static int64_t col_block_width(int64_t E, int64_t K) {   // 0 = one launch
   int64_t bw = options().col_block;
   if (bw > 0 && E < options().col_block_min_edges) bw *= 2;
-  if (bw <= 0 || bw % 4 != 0 || K < 2 * bw || K % bw != 0) return 0;
+  if (bw <= 0 || bw % 4 != 0 || K < 2 * bw || K % 4 != 0) return 0;
+  // up to 256 columns a row is walked once by its lane group: blocks must tile it exactly (a narrow remainder block
+  // would cost a launch of its own for a few columns).  Wider rows are walked once per 256 columns anyway, the last
+  // pass with most lanes idle (K = 604: 55 ms where 19 lines per edge should take 35): full blocks + a remainder block
+  if (K % bw != 0 && K <= 256) return 0;
   return bw;
 }
 // launches one f32 SpMM-sum / mean over E edges and K columns is made of (bench.py's roofline leg reports per launch)
 extern "C" int64_t ggl_spmm_col_blocks(int64_t E, int64_t K) {
   const int64_t bw = col_block_width(E, K);
-  return bw > 0 ? K / bw : 1;
+  return bw > 0 ? (K + bw - 1) / bw : 1;
 }
 
 template <int OP, int MODE>
@@ -690,7 +694,7 @@ static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
   if (bw <= 0 || a0.N <= 0) return launch_f32<OP, MODE>(a0, stream);
   for (int64_t c0 = 0; c0 < a0.K; c0 += bw) {
     ReduceArgs a = a0;
-    a.K = bw;
+    a.K = (a0.K - c0) < bw ? (a0.K - c0) : bw;
     a.x = static_cast<const float *>(a0.x) + c0;
     a.out = static_cast<float *>(a0.out) + c0;
     a.x_ld = a0.x_ld > 0 ? a0.x_ld : a0.K;

@@ -547,6 +547,14 @@ class Engine:
         """op in sum/mean/max/mean_bwd/max_bwd.  x [N_in, *]; returns out [n_out, *] (+argsrc)."""
         dev = x.device
         K = int(math.prod(x.shape[1:]))
+        if op in ("sum", "mean") and x.dim() == 2 and K > 256 and K % 64 != 0 and plan.E >= 8 * x.shape[0]:
+            # rows wider than 256 columns that are not whole cache lines (602 Reddit features: 2408-byte rows): the
+            # 64-column blocks of such a matrix straddle lines (a 256-byte slice touches 2.9 lines on average instead
+            # of 2).  One copy padded to a multiple of 64 columns makes every block two aligned lines
+            # (products-sized graph, K = 602: 55 -> 42 ms, copies included); the pad columns sum to zero and are dropped.
+            xp = torch.nn.functional.pad(x, (0, (-K) % 64))
+            out, _ = self._spmm_fwd(op, plan, col, w, xp, n_out, perm_override, aux)
+            return out[:, :K].contiguous(), None
         if op in ("sum", "mean") and x.dim() == 2 and K % 4 != 0 and K >= 8 and plan.E >= 8 * x.shape[0]:
             # class-count widths (47, 41, 7 ...): rows of 4K bytes are not 16-byte aligned, so the float4
             # kernel cannot read them.  One padded copy of x (N*K floats) is far cheaper than walking E
