@@ -280,6 +280,12 @@ def main():
                 out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t, src
             elif out["roofline"].get("traffic") is not None:
                 out["roofline"]["traffic_source"] += f" [in-run collection unavailable: {src}]"
+        rf = out.get("roofline") or {}
+        if rf.get("traffic") and rf.get("ms_per_launch"):
+            # the HBM side of the same launch: measured bytes / its duration against the peak (frac above is algorithmic:
+            # it counts the gathers that L2 served as if they had crossed the fabric)
+            rf["traffic_GBps"] = rf["traffic"] / (rf["ms_per_launch"] * 1e-3) / 1e9
+            rf["traffic_frac"] = rf["traffic_GBps"] / rf["peak"]
         if world == 1 and not args.no_cpu_baseline and not emul:
             # the benchmark graph itself on the host (rank 0 holds all of it at N = 1)
             ei = torch.cat([torch.stack([pg.ei_loc[0] + pg.lo, pg.ei_loc[1] + pg.lo]).cpu()], dim=1)
