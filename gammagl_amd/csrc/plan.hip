@@ -47,6 +47,7 @@ Options &options() {
     t.ragged4 = env_i64("GGL_RAGGED4", t.ragged4);
     t.col_block = env_i64("GGL_COL_BLOCK", t.col_block);
     t.col_block_min_edges = env_i64("GGL_COL_BLOCK_MIN_EDGES", t.col_block_min_edges);
+    t.col_block_min_degree = env_i64("GGL_COL_BLOCK_MIN_DEGREE", t.col_block_min_degree);
     t.row_order = env_i64("GGL_ROW_ORDER", t.row_order);
     t.max_grid_x = env_i64("GGL_MAX_GRID_X", t.max_grid_x);
     return t;
@@ -255,6 +256,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "ragged4")) o.ragged4 = value;
   else if (!strcmp(name, "col_block")) o.col_block = value;
   else if (!strcmp(name, "col_block_min_edges")) o.col_block_min_edges = value;
+  else if (!strcmp(name, "col_block_min_degree")) o.col_block_min_degree = value;
   else if (!strcmp(name, "row_order")) o.row_order = value;
   else if (!strcmp(name, "max_grid_x")) o.max_grid_x = value > 0 ? value : 1;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
@@ -270,6 +272,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "ragged4")) return o.ragged4;
   if (!strcmp(name, "col_block")) return o.col_block;
   if (!strcmp(name, "col_block_min_edges")) return o.col_block_min_edges;
+  if (!strcmp(name, "col_block_min_degree")) return o.col_block_min_degree;
   if (!strcmp(name, "row_order")) return o.row_order;
   if (!strcmp(name, "max_grid_x")) return o.max_grid_x;
   return -1;

@@ -671,7 +671,10 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
 // gather whatever the width), as do blocks that are not line multiples (K = 96 as 2 x 48: 5.5 -> 7.3 ms).  The
 // columns of a row are independent sums: same bits; the dropout word of element (row, col) is the full-width one
 // (epi_K / epi_col0).  Small graphs (an arxiv-sized launch is 0.3 ms) take two 128-wide blocks at most.
-static int64_t col_block_width(int64_t E, int64_t K) {   // 0 = one launch
+static int64_t col_block_width(int64_t E, int64_t K, int64_t N) {   // 0 = one launch
+  // the blocks pay through L2 reuse of hub rows: a walk with few edges per row (a rank's local-source block of the
+  // papers100M-sized partition: 4.6) has little to reuse and only re-reads its indices per block (10.9 -> 12.6 ms)
+  if (N > 0 && E < options().col_block_min_degree * N) return 0;
   int64_t bw = options().col_block;
   if (bw > 0 && E < options().col_block_min_edges) bw *= 2;
   if (bw <= 0 || bw % 4 != 0 || K < 2 * bw || K % 4 != 0) return 0;
@@ -682,15 +685,15 @@ static int64_t col_block_width(int64_t E, int64_t K) {   // 0 = one launch
   return bw;
 }
 // launches one f32 SpMM-sum / mean over E edges and K columns is made of (bench.py's roofline leg reports per launch)
-extern "C" int64_t ggl_spmm_col_blocks(int64_t E, int64_t K) {
-  const int64_t bw = col_block_width(E, K);
+extern "C" int64_t ggl_spmm_col_blocks(int64_t E, int64_t K, int64_t N) {
+  const int64_t bw = col_block_width(E, K, N);
   return bw > 0 ? (K + bw - 1) / bw : 1;
 }
 
 template <int OP, int MODE>
 static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
   static_assert(OP != OP_MAX && (MODE == MODE_SPMM || MODE == MODE_SPMM_EPI), "column blocks: sum / mean SpMM only");
-  const int64_t bw = col_block_width(a0.E, a0.K);
+  const int64_t bw = col_block_width(a0.E, a0.K, a0.N);
   if (bw <= 0 || a0.N <= 0) return launch_f32<OP, MODE>(a0, stream);
   for (int64_t c0 = 0; c0 < a0.K; c0 += bw) {
     ReduceArgs a = a0;

@@ -507,7 +507,7 @@ def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls,
     h = torch.randn(rows_t, K, generator=gen, device=dev)
     ms_op = eng.time_spmm_sum(gp_t, w_t, h, reps=10)     # one K-wide aggregate = `launches` kernel launches
     e_loc = gp_t.E
-    launches = int(eng.lib.ggl_spmm_col_blocks(e_loc, K))   # 64-column blocks (reduce.hip launch_f32_cols)
+    launches = int(eng.lib.ggl_spmm_col_blocks(e_loc, K, pg.n_local))   # 64-column blocks (reduce.hip launch_f32_cols)
     Kl = K // launches
     ms = max(ms_op / launches, 1e-9)  # (the host-emulated test build reports 0)
     alg = e_loc * (4 * Kl + 8) + pg.n_local * (4 * Kl + 8)   # SURVEY §8d per launch: its Kl columns, ids and weights

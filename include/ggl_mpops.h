@@ -155,8 +155,9 @@ int ggl_segment_sum(int dtype, const void *x, const ggl_segplan_t *plan, int64_t
 int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_t K, void *out,
                      void *stream);
 /* Wide f32 SpMM-sum / mean launches are cut into column blocks (64 wide; csrc/reduce.hip launch_f32_cols, options
- * "col_block" / "col_block_min_edges"): the number of kernel launches one call over E edges and K columns makes. */
-int64_t ggl_spmm_col_blocks(int64_t E, int64_t K);
+ * "col_block" / "col_block_min_edges" / "col_block_min_degree"): the number of kernel launches one call over E edges,
+ * K columns and N output rows makes. */
+int64_t ggl_spmm_col_blocks(int64_t E, int64_t K, int64_t N);
 
 /* f16 / bf16 sums accumulate in the storage type (segment_sum_cpu.cpp:47-56), so their hub rows cannot be chunked:
  * ggl_segment_hub16 reduces the plan's LONG rows (plan->long_rows) in the reference's serial order with a workgroup

@@ -16,6 +16,20 @@ DT = {"uint8": torch.uint8, "int8": torch.int8, "int16": torch.int16, "int32": t
 KAT_DT = ["int8", "int16", "int32", "int64", "float16", "float32", "float64"]
 
 
+class option:
+    """`with option(eng, "col_block_min_degree", 0): ...` — a library option for the duration of a block"""
+
+    def __init__(self, eng, name, value):
+        self.eng, self.name, self.value = eng, name, value
+
+    def __enter__(self):
+        self.old = int(self.eng.lib.ggl_get_option(self.name.encode()))
+        self.eng.set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        self.eng.set_option(self.name, self.old)
+
+
 def to_t(a, dev, dt=None):
     a = np.asarray(a)
     if dt == "bfloat16":
@@ -1014,6 +1028,8 @@ def check_epilogue_forms(eng, dev):
     matrix assemble the full-width result (same dropout mask); the send-row gather == index_select."""
     g = torch.Generator(device="cpu").manual_seed(41)
     old = eng.chunk
+    old_deg = int(eng.lib.ggl_get_option(b"col_block_min_degree"))
+    eng.set_option("col_block_min_degree", 0)     # the wide cases run as column blocks whatever the graph's degree
     try:
         for chunk in (0, 8):
             eng.chunk = chunk
@@ -1099,6 +1115,7 @@ def check_epilogue_forms(eng, dev):
         assert torch.equal(wide[:, 32:48], src[:, 8:24][idx]) and float(wide[:, :32].abs().sum()) == 0
     finally:
         eng.chunk = old
+        eng.set_option("col_block_min_degree", old_deg)
         eng.graph_cache.clear(); eng.seg_cache.clear()
 
 

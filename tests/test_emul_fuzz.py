@@ -98,6 +98,8 @@ def run_gspmm_case(eng, DEV, oracle, prob):
     old = eng.chunk
     eng.chunk = chunk
     eng.seg_cache.clear(); eng.graph_cache.clear(); eng.w_cache.clear()
+    old_deg = int(eng.lib.ggl_get_option(b"col_block_min_degree"))
+    eng.set_option("col_block_min_degree", 0)   # wide cases take the column-block launches whatever the degree
     try:
         it, wt = pc.to_t(index, DEV), pc.to_t(w, DEV)
         for red, fn in (("sum", eng.c_spmm_sum), ("mean", eng.c_spmm_mean), ("max", eng.c_spmm_max)):
@@ -120,6 +122,7 @@ def run_gspmm_case(eng, DEV, oracle, prob):
                 np.testing.assert_allclose(pc.to_np(xt.grad), ogx, rtol=1e-6, atol=1e-6)
     finally:
         eng.chunk = old
+        eng.set_option("col_block_min_degree", old_deg)
         eng.seg_cache.clear(); eng.graph_cache.clear(); eng.w_cache.clear()
 
 

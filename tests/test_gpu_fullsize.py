@@ -281,7 +281,8 @@ def test_products_size_column_blocks_same_bits(eng, dev):
     K = 256
     x = torch.randn(n, K, generator=g, device=dev)
     bias = torch.randn(K, generator=g, device=dev)
-    assert eng.lib.ggl_spmm_col_blocks(gp.E, K) == 4 and eng.lib.ggl_spmm_col_blocks(gp.E, 100) == 1
+    assert eng.lib.ggl_spmm_col_blocks(gp.E, K, n) == 4 and eng.lib.ggl_spmm_col_blocks(gp.E, 100, n) == 1
+    assert eng.lib.ggl_spmm_col_blocks(gp.E, K, gp.E // 5) == 1      # 5 edges per row: nothing to keep in L2
     old = eng.lib.ggl_get_option(b"col_block")
     res = {}
     try:
