@@ -86,7 +86,7 @@ struct Options {
   int64_t xcd_swizzle = 0;
   int64_t force_generic = 0; // route f32 through the VEC=1 generic kernel (A/B aid)
   int64_t col_block = 64;    // wide f32 SpMM-sum / mean: launches over column blocks of this width (0 = one launch)
-  int64_t col_block_min_degree = 32;      // ... and only where a row averages at least this many edges (reuse to find)
+  int64_t col_block_min_degree = 24;      // ... and only where a row averages at least this many edges (reuse to find)
   int64_t col_block_min_edges = 8000000;  // below this many edges the blocks are twice as wide (launch-bound graphs)
   int64_t ragged4 = 1;       // f32 rows that are not aligned float4s (K % 4 != 0): 4 floats per lane + ragged last lane
   // 0 = natural row order; 1 = length-sorted rows where several rows share a wavefront (balances
