@@ -61,6 +61,9 @@ def parse():
                    help="torch.set_float32_matmul_precision for the dense X W products: 'highest' = IEEE f32 MFMA (the "
                         "line of record); 'high' lets hipBLASLt emulate f32 with bf16 triples on gfx950 (2x faster GEMMs, "
                         "~5e-6 relative error instead of ~8e-7) — reported only as a side figure")
+    p.add_argument("--no-tuned-gemm", action="store_true",
+                   help="do not load gammagl_amd/tuned/*.csv (PyTorch TunableOp results: which rocBLAS / hipBLASLt f32 "
+                        "kernel runs each GEMM shape of the step, chosen offline by tools/tune_gemms.sh)")
     p.add_argument("--no-comparison", action="store_true",
                    help="skip the like-for-like transform-first trainer timed beside the default (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -258,6 +261,23 @@ def main():
     from gammagl_amd.synth import DATASETS
 
     torch.set_float32_matmul_precision(args.matmul_precision)
+    tuned = None
+    if not emul and not args.no_tuned_gemm and args.matmul_precision == "highest":
+        # library GEMM selection only: the same IEEE f32 products, each shape on the rocBLAS / hipBLASLt kernel an offline
+        # TunableOp pass measured fastest on this part (the file's validators — torch / HIP / library versions, gfx
+        # arch — must match, otherwise torch ignores it and the default heuristics pick)
+        path = os.path.join(REPO, "gammagl_amd", "tuned", f"tunableop_gfx950_{args.workload}.csv")
+        if os.path.exists(path):
+            try:
+                import torch.cuda.tunable as tun
+
+                tun.enable(True)
+                tun.tuning_enable(False)
+                tuned = os.path.relpath(path, REPO) if tun.read_file(path) else None
+                if tuned is None:
+                    tun.enable(False)
+            except Exception:  # noqa: BLE001
+                tuned = None
 
     if args.workload == "tiny":
         n_nodes, n_edges, f_in, n_cls = 20000, 400000, 100, 47
@@ -265,6 +285,7 @@ def main():
         n_nodes, n_edges, f_in, n_cls = DATASETS[args.workload]
     out, pg = run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls, eng=eng)
     out["engine"] = "host-emulation (launcher test, not a measurement)" if emul else "hip"
+    out["config"]["tuned_gemm_selection"] = tuned
     out["config"]["matmul_precision"] = args.matmul_precision + (" (IEEE f32)" if args.matmul_precision == "highest"
                                                                    else " (hipBLASLt f32 emulated with bf16 triples: NOT the line of record)")
     if emul:
