@@ -163,7 +163,8 @@ def run_gat_case(eng, DEV, oracle, prob):
         elt, ert, xt = (pc.to_t(a, DEV).requires_grad_(True) for a in (el, er, x))
         y = eng.gat_fused(pc.to_t(index, DEV), elt, ert, xt, 0.2)
         oy = oracle.gat_fwd(index, el, er, x, 0.2)
-        np.testing.assert_allclose(pc.to_np(y), oy, rtol=2e-5, atol=2e-6)
+        # (an output that cancels to ~0 carries the rounding of its O(|x|) terms)
+        np.testing.assert_allclose(pc.to_np(y), oy, rtol=2e-5, atol=2e-6 * (1.0 + float(np.abs(x).max() if x.size else 0)))
         y.backward(pc.to_t(go, DEV))
         gel, ger, gx = oracle.gat_bwd(index, el, er, x, go, 0.2)
         # one ulp of a logit of magnitude L is 1.2e-7 L in the exponent of its softmax term: the tolerance follows the
