@@ -12,27 +12,36 @@ its own share of the graph (gammagl_amd.synth.rmat_partitioned): no rank holds t
   precomputed symmetric-normalised edge weights (edge_weight = calc_gcn_norm(edge_index), the
   configuration examples/gcn/gcn_trainer.py:59 sketches) over the whole graph: forward (Linear,
   aggregate, +bias, ReLU, dropout per layer), softmax cross-entropy on the train nodes, backward, Adam
-  with weight decay.  GammaGL's GCNConv always computes A (X W) (gcn_conv.py:79): 3 forward CSR SpMMs + 3
-  transposed ones per step (--transform-first).  By default a layer whose input is narrower than its output
-  computes the same product as (A X) W: the first layer then aggregates 100-wide rows, and its backward needs
-  no aggregation (the input features carry no gradient, dW = (A X)^T dH): 5 aggregations per step.
+  with weight decay.  Every layer computes A (X W) as GammaGL's GCNConv does (gcn_conv.py:79): 3 forward
+  CSR SpMMs + 3 transposed ones per step — that step is the line's `value` / `ms_per_step`.  The cheaper
+  association (a layer whose input is narrower than its output computes (A X) W: 5 aggregations) is timed in
+  the same run and reported beside it as `config.aggregate_first` (--aggregate-first makes it the main line).
   Same code path for every N (N = 1: no halo exchange);
-* value = (aggregations actually executed per step) * E * steps / time over the whole job (max over ranks),
-  inputs resident in HBM; "aggregations_per_step" is in the line;
-  scaling = "strong": the graph is fixed and node-partitioned over the N GPUs;
-* roofline = the dominant kernel (CSR SpMM-sum, feature width 256, forward, rank 0's rows) timed
-  with hipEvents on its launch stream: algorithmic bytes E*(4*256+8) + N*(4*256+8) per launch
-  (SURVEY.md §8d) / time, against the 8 TB/s HBM3E peak;
+* value = (aggregations per step) * E * steps / time over the whole job (max over ranks), inputs resident
+  in HBM; scaling = "strong": the graph is fixed and node-partitioned over the N GPUs;
+* both node orders of SURVEY.md §8d in ONE run: the random relabel (worst-case locality; the headline) and the
+  degree-sorted one (`config.orderings`);
+* roofline = the dominant kernel (CSR SpMM-sum, feature width 256, rank 0's largest edge block) timed with
+  hipEvents on its launch stream.  `achieved` / `frac` = HBM-side bytes per launch MEASURED in this run
+  (two rocprofv3 --pmc passes over `bench.py --pmc-probe`, same graph) / launch duration, against the 8 TB/s
+  HBM3E peak: a fraction that cannot exceed 1.  The algorithmic rate E*(4K+8) + N*(4K+8) bytes per aggregate
+  (SURVEY.md §8d, no-reuse model) / duration is `eff_GBps` — it exceeds the peak when L2 serves gathers;
+  `compulsory_bytes` (every row once) and `traffic_over_compulsory` say how much re-reading is left;
 * cpu_baseline (N = 1 only) = the reference's own CPU extension (oracle/_ref, compiled from the
   reference sources; our C restatement if it is absent), 1 core (the shipped extension is serial:
   setup.py:50 never defines its OpenMP macro): ONE full-size K=256 aggregate of the benchmark graph itself
-  (~20 s), plus the 6 aggregations of a step on a bounded R-MAT sample as a secondary figure.
+  (~35 s); `torch_fallback` = the reference's pure-torch formulation (mpops/torch.py:16-18,335-342) on an
+  edge sample of the SAME graph, all host threads, median of 3;
+* other workloads (--workload): arxiv | tiny | products-planted (a graph with community structure, random ids vs
+  partition.cluster_order) | papers-share (config 5: one rank's share of the 8-way papers100M-sized partition on
+  one GPU) | reddit-gat (config 3) | sage-minibatch (config 4) — same JSON shape;
 * GGL_BENCH_EMUL=1 (tests only): gloo + the host-emulated kernels on CPU, to exercise the launcher and the
   N-rank code path where there is no GPU; the line then says "engine": "host-emulation" and is no measurement.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -48,15 +57,20 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default=os.environ.get("GGL_BENCH_WORKLOAD", "products"),
-                   help="products | arxiv | tiny  (node/edge counts of the named dataset, R-MAT)")
+                   help="products | arxiv | tiny | products-planted | papers-share | reddit-gat | sage-minibatch")
     p.add_argument("--hidden", type=int, default=256)
     p.add_argument("--layers", type=int, default=3)
     p.add_argument("--order", default="src", choices=["src", "dst"],
                    help="edge order of the synthetic edge_index (src = coalesced COO as in GammaGL/PyG)")
-    p.add_argument("--relabel", default="random", choices=["random", "degree", "none"])
-    p.add_argument("--transform-first", action="store_true",
-                   help="A (X W) in every layer, as GammaGL's GCNConv writes it (default: a layer whose input is narrower "
-                        "than its output computes (A X) W — same product, fewer bytes, no aggregation in layer 1's backward)")
+    p.add_argument("--relabel", default="random", choices=["random", "degree", "none", "cluster"],
+                   help="node order of the main line (cluster = partition.cluster_order on the randomly labelled graph)")
+    p.add_argument("--also-relabel", default="auto", choices=["auto", "none", "random", "degree", "cluster"],
+                   help="a second node order timed in the same run and reported in config.orderings (auto: degree for the "
+                        "R-MAT workloads, cluster for products-planted; N = 1 only)")
+    p.add_argument("--aggregate-first", action="store_true",
+                   help="main line = the step in which a layer whose input is narrower than its output computes (A X) W "
+                        "(default: A (X W) in every layer, as GammaGL's GCNConv writes it; the other association is the side figure)")
+    p.add_argument("--transform-first", action="store_true", help="(accepted for compatibility: it is the default)")
     p.add_argument("--matmul-precision", default="highest", choices=["highest", "high"],
                    help="torch.set_float32_matmul_precision for the dense X W products: 'highest' = IEEE f32 MFMA (the "
                         "line of record); 'high' lets hipBLASLt emulate f32 with bf16 triples on gfx950 (2x faster GEMMs, "
@@ -65,16 +79,21 @@ def parse():
                    help="do not load gammagl_amd/tuned/*.csv (PyTorch TunableOp results: which rocBLAS / hipBLASLt f32 "
                         "kernel runs each GEMM shape of the step, chosen offline by tools/tune_gemms.sh)")
     p.add_argument("--no-comparison", action="store_true",
-                   help="skip the like-for-like transform-first trainer timed beside the default (profiling runs)")
+                   help="skip the other association and the second node order (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
-                   help="auto: after the timed region (N = 1, products), collect the dominant kernel's HBM-side traffic "
-                        "with two rocprofv3 --pmc passes of tools/pmc_probe.py on the same graph (skipped when rocprofv3 "
-                        "is not on PATH; falls back to the committed profile)")
+    p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off", "l2"],
+                   help="auto: after the timed region (N = 1), measure the dominant kernel's HBM-side traffic with two "
+                        "rocprofv3 --pmc passes of `bench.py --pmc-probe` on the same graph (skipped when rocprofv3 is not "
+                        "on PATH; falls back to the committed profile); l2: a third pass for the L2 hit rate")
+    p.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# cpu_baseline legs: the ONLY place outside tests/ and smoke() that touches oracle/ — as the thing timed beside the
+# GPU number, never as part of the product path
+# ---------------------------------------------------------------------------------------------------------------
 def _ref_or_port():
     from oracle import oracle as orc
 
@@ -85,10 +104,34 @@ def _ref_or_port():
         return None, "port", orc
 
 
-def cpu_baseline(hidden, classes, seed, full_graph=None):
+def _torch_fallback(ei, w, x, n_sample=2_000_000, reps=3):
+    """The reference's pure-torch formulation of the same aggregate (mpops/torch.py:16-18,335-342:
+    x[src] * w -> zeros().scatter_add_) on a strided edge sample of the benchmark graph itself (gathers and
+    scatters as random as the full list's), all host threads, 1 warm-up + `reps`, median."""
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    E = int(ei.shape[1])
+    stride = max(1, E // n_sample)
+    src, dst, wt = ei[0, ::stride].contiguous(), ei[1, ::stride].contiguous(), w[::stride].contiguous()
+    e_t = int(src.numel())
+    ts = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        msg = x[src] * wt.view(-1, 1)
+        torch.zeros_like(x).scatter_add_(0, dst.view(-1, 1).expand_as(msg), msg)
+        if i > 0:
+            ts.append(time.perf_counter() - t0)
+    dt = statistics.median(ts)
+    return {"value": e_t / dt, "unit": "edges/s", "cores": cores,
+            "sample": f"pure-torch mpops formulation (gather * w -> scatter_add_), ONE K={x.shape[1]} aggregate over every "
+                      f"{stride}-th edge of the benchmark graph itself ({e_t} edges into its {x.shape[0]} rows), median of "
+                      f"{reps} after 1 warm-up, {dt:.2f} s on {cores} threads"}
+
+
+def cpu_baseline_gcn(hidden, classes, seed, full_graph=None):
     """Reference CPU extension (or the oracle port), 1 core.  `full_graph` = (edge_index [2,E] int64 on the
-    host, weights [E], N): one K=hidden forward aggregate of the benchmark graph itself; then the 6 aggregations
-    of a step on a bounded sample (~8 s)."""
+    host, weights [E], N): one K=hidden forward aggregate of the benchmark graph itself; the 6 aggregations of a step on
+    a bounded R-MAT sample as a secondary figure; the pure-torch fallback on the same graph."""
     from gammagl_amd.synth import rmat_graph
 
     ref, kind, orc = _ref_or_port()
@@ -97,34 +140,34 @@ def cpu_baseline(hidden, classes, seed, full_graph=None):
     torch.set_num_threads(1)
     gen = torch.Generator().manual_seed(seed)
     out = {}
+    x_full = None
     if full_graph is not None:
         ei, w, n = full_graph
         E = int(ei.shape[1])
-        x = torch.randn(n, hidden, generator=gen)
+        x_full = torch.randn(n, hidden, generator=gen)
         t0 = time.perf_counter()
         if ref is not None:
-            ref.c_spmm_sum(ei, w, x)
+            ref.c_spmm_sum(ei, w, x_full)
         else:
-            orc.spmm_sum_fwd(ei.numpy(), w.numpy(), x.numpy())
+            orc.spmm_sum_fwd(ei.numpy(), w.numpy(), x_full.numpy())
         dt = time.perf_counter() - t0
         out = {"value": E / dt, "unit": "edges/s", "cores": 1, "kind": kind,
                "sample": f"ONE forward aggregate (K={hidden}) of the full benchmark graph: N={n}, E={E}, {impl}, "
                          f"{dt:.1f} s on 1 core of {cores}"}
-        del x
     n_s, e_s = 400000, (8_000_000 if full_graph is not None else 16_000_000)
-    ei = rmat_graph(n_s, e_s, seed=seed + 17, device="cpu")
-    E = ei.shape[1]
-    w = torch.rand(E, generator=gen)
+    ei_s = rmat_graph(n_s, e_s, seed=seed + 17, device="cpu")
+    E = ei_s.shape[1]
+    w_s = torch.rand(E, generator=gen)
     widths = [hidden, hidden, classes]
     feats = [torch.randn(n_s, k, generator=gen) for k in widths]
     t0 = time.perf_counter()
     if ref is not None:
-        eiT = ei.flip(0).contiguous()
+        eiT = ei_s.flip(0).contiguous()
         for x in feats:
-            ref.c_spmm_sum(ei, w, x)        # forward aggregate (spmm_sum_cpu_forward)
-            ref.c_spmm_sum(eiT, w, x)       # backward = the same loop on the transposed edge list
+            ref.c_spmm_sum(ei_s, w_s, x)        # forward aggregate (spmm_sum_cpu_forward)
+            ref.c_spmm_sum(eiT, w_s, x)         # backward = the same loop on the transposed edge list
     else:
-        ein, wn = ei.numpy(), w.numpy()
+        ein, wn = ei_s.numpy(), w_s.numpy()
         for x in feats:
             orc.spmm_sum_fwd(ein, wn, x.numpy())
             orc.spmm_sum_bwd(ein, wn, x.numpy())
@@ -136,28 +179,83 @@ def cpu_baseline(hidden, classes, seed, full_graph=None):
         out["step_sample"] = step
     else:
         out = step
-    # second baseline: the reference's pure-torch formulation of the same aggregate
-    # (mpops/torch.py:16-18,335-342: x[src] * w -> zeros().scatter_add_), all host threads, smaller sample
-    torch.set_num_threads(cores)
-    e_t = min(E, 1_000_000)
-    src, dst, wt = ei[0, :e_t], ei[1, :e_t], w[:e_t]
-    t1 = time.perf_counter()
-    for x in feats:
-        for s_, d_ in ((src, dst), (dst, src)):
-            msg = x[s_] * wt.view(-1, 1)
-            torch.zeros_like(x).scatter_add_(0, d_.view(-1, 1).expand_as(msg), msg)
-    dt_t = time.perf_counter() - t1
-    out["torch_fallback"] = {"value": 6 * e_t / dt_t, "unit": "edges/s", "cores": cores,
-                             "sample": f"pure-torch mpops formulation (gather * w -> scatter_add_), first {e_t} edges "
-                                       f"of the sample, {dt_t:.1f} s on {cores} threads"}
+    # second baseline: the reference's pure-torch formulation, same graph
+    if full_graph is not None:
+        out["torch_fallback"] = _torch_fallback(full_graph[0], full_graph[1], x_full)
+    else:
+        out["torch_fallback"] = _torch_fallback(ei_s, w_s, feats[0])
     return out
 
 
-def measure_traffic(args, hidden, launches=1):
+def cpu_baseline_gat(ctx, seed):
+    """Config 3's CPU counterpart: the reference ops composed as gat_conv.py:103-112 + softmax.py:29-35 write the
+    layer (gather, LeakyReLU, c_segment_max, exp, c_segment_sum, divide, gather * alpha, c_segment_sum) for the 8 x 8
+    head shape, on every 32nd edge of the benchmark graph (its own node set), 1 core."""
+    ref, kind, orc = _ref_or_port()
+    ei, n = ctx["ei"].cpu(), ctx["n"]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(1)
+    stride = 32
+    ei = ei[:, ::stride].contiguous()
+    E = int(ei.shape[1])
+    H, C = 8, 8
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, H, C, generator=g)
+    el, er = torch.randn(n, H, generator=g), torch.randn(n, H, generator=g)
+    src, dst = ei[0], ei[1]
+    t0 = time.perf_counter()
+    if ref is not None:
+        e = torch.nn.functional.leaky_relu(el[src] + er[dst], 0.2)
+        m = ref.c_segment_max(e, dst, n)
+        ex = torch.exp(e - m[dst])
+        s = ref.c_segment_sum(ex, dst, n)
+        alpha = ex / (s[dst] + 1e-16)
+        ref.c_segment_sum(x[src] * alpha.unsqueeze(-1), dst, n)
+        impl = "reference c_segment_max / c_segment_sum (oracle/_ref) composed as gat_conv.py:103-112"
+    else:
+        orc.gat_fwd(ei.numpy(), el.numpy(), er.numpy(), x.numpy(), 0.2)
+        impl = "oracle C port of the GATConv math"
+    dt = time.perf_counter() - t0
+    return {"value": E / dt, "unit": "edges/s", "cores": 1, "kind": kind,
+            "sample": f"ONE GAT layer forward ({H} heads x {C} channels) over every {stride}-th edge of the benchmark graph "
+                      f"({E} edges, N={n}), {impl}, {dt:.1f} s on 1 core of {cores}"}
+
+
+def cpu_baseline_sage(ctx, hidden, seed):
+    """Config 4's CPU counterpart: the reference's c_segment_mean on messages shaped like the batch's blocks
+    ([edges, hidden] -> [destination rows, hidden]), 1 core, 20 repetitions."""
+    ref, kind, orc = _ref_or_port()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(seed)
+    tot_e, reps = 0, 20
+    t_all = 0.0
+    for blk, (n_src, n_e) in zip(ctx["blocks"], ctx["valid"]):
+        n_dst = int(blk.n_dst_cap)
+        dst = torch.sort(torch.randint(0, n_dst, (n_e,), generator=g)).values
+        msg = torch.randn(n_e, hidden, generator=g)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            if ref is not None:
+                ref.c_segment_mean(msg, dst, n_dst)
+            else:
+                orc.segment_mean(msg.numpy(), dst.numpy(), n_dst)
+        t_all += time.perf_counter() - t0
+        tot_e += n_e
+    impl = "reference c_segment_mean (oracle/_ref)" if kind == "reference" else "oracle C port"
+    return {"value": tot_e * reps / t_all, "unit": "edges/s", "cores": 1, "kind": kind,
+            "sample": f"segment_mean of [edges, {hidden}] messages shaped like one batch's two sampled blocks ({tot_e} edges), "
+                      f"{reps} repetitions, {impl}, {t_all:.1f} s on 1 core of {cores}"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# measured HBM traffic of the dominant kernel (rocprofv3 --pmc around `bench.py --pmc-probe`)
+# ---------------------------------------------------------------------------------------------------------------
+def measure_traffic(args, kernel_substr, relabel=None, with_l2=False):
     """HBM-side bytes per launch of the dominant kernel, measured NOW on this box: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 --pmc passes (MI355X_MICROARCH.md, HBM section: KiB units, x2 on the read side for gfx950) of
-    tools/pmc_probe.py, which rebuilds this run's graph and launches the K=hidden SpMM-sum a few times.  Returns
-    (bytes, source) or (None, reason)."""
+    `bench.py --pmc-probe`, which rebuilds this run's graph and launches the kernel a few times.  Returns
+    (bytes, source, extra) or (None, reason, {})."""
     import csv
     import glob
     import shutil
@@ -166,36 +264,58 @@ def measure_traffic(args, hidden, launches=1):
 
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", {}
     vals = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    passes = [("FETCH_SIZE",), ("WRITE_SIZE",)] + ([("TCC_HIT_sum", "TCC_MISS_sum")] if with_l2 else [])
+    for counters in passes:
         d = tempfile.mkdtemp(prefix="ggl_pmc_")
         try:
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-                   os.path.join(REPO, "tools", "pmc_probe.py"), args.workload, str(hidden), str(args.seed), args.relabel,
-                   args.order]
-            r = subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR=d), capture_output=True, text=True, timeout=90)
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-probe", "--workload", args.workload, "--hidden", str(args.hidden),
+                   "--seed", str(args.seed), "--relabel", relabel or args.relabel, "--order", args.order]
+            r = subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR=d), capture_output=True, text=True, timeout=240)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
-            xs = []
+                return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-200:]}", {}
+            acc = {c: [] for c in counters}
             with open(files[0], newline="") as f:
                 for row in csv.DictReader(f):
-                    # one wavefront per row (true) for a one-launch K = 256 aggregate, 16 lanes per row (false) for its
-                    # 64-column blocks
-                    want = "row_reduce_kernel<float, 4, 0, 1, 1, " + ("true" if launches == 1 else "false, 4")
-                    if row["Counter_Name"] == counter and want in row["Kernel_Name"]:
-                        xs.append(float(row["Counter_Value"]))
-            if not xs:
-                return None, "kernel not found in the counter file"
-            vals[counter] = sum(xs) / len(xs)
+                    if row["Counter_Name"] in acc and kernel_substr in row["Kernel_Name"]:
+                        acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            for c, xs in acc.items():
+                if not xs:
+                    return None, f"kernel '{kernel_substr}' not found in the {c} counter file", {}
+                vals[c] = sum(xs) / len(xs)
         except Exception as ex:  # noqa: BLE001
-            return None, f"{type(ex).__name__}: {ex}"
+            return None, f"{type(ex).__name__}: {ex}", {}
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    extra = {}
+    if with_l2:
+        h, m = vals["TCC_HIT_sum"], vals["TCC_MISS_sum"]
+        extra["l2_hit_rate"] = h / (h + m) if h + m > 0 else None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
-        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_probe.py on the same graph " \
-        "((2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 read-side correction)"
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --pmc-probe` on the same graph " \
+        "((2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, gfx950 read-side correction)", extra
+
+
+def committed_traffic(args, launches, E):
+    """Fallback when rocprofv3 cannot run here: the committed --pmc profile of THIS workload (never another one's)."""
+    if not (args.workload == "products" and args.hidden == 256 and args.order == "src" and args.relabel == "random"
+            and args.seed == 0):
+        return None, None
+    for name in ("r3_pmc_products_k256.json", "r2_pmc_products_k256.json"):
+        try:
+            rec = json.load(open(os.path.join(REPO, "profiles", name)))
+            if int(rec.get("graph_edges", -1)) == E and int(rec.get("launches_per_aggregate", 1)) == launches:
+                return rec["spmm_sum_k256"]["hbm_bytes_per_launch"], \
+                    f"profiles/{name} (rocprofv3 --pmc passes on this graph, NOT collected in this run)"
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
+
+
+KERNEL_OF = {"gcn": "row_reduce_kernel<float, 4, 0, 1,", "gat": "gat_fwd2_kernel"}
 
 
 def _free_port():
@@ -226,6 +346,18 @@ def spawn(args):
 
 def main():
     args = parse()
+    from gammagl_amd.benchmarks import PROBES, RUNNERS, WORKLOADS, set_traffic, sizes_of
+
+    if args.workload not in WORKLOADS:
+        raise SystemExit(f"bench.py: unknown --workload {args.workload}; choose from {', '.join(WORKLOADS)}")
+    kind = WORKLOADS[args.workload]["kind"]
+    if args.pmc_probe:   # child of measure_traffic: the dominant kernel alone, under rocprofv3 --pmc
+        from gammagl_amd import engine
+
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        PROBES[kind](args, dev, engine())
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -257,17 +389,15 @@ def main():
         else:
             dist.init_process_group(backend, device_id=dev)
 
-    from gammagl_amd.dist import run_distributed_bench
-    from gammagl_amd.synth import DATASETS
-
     torch.set_float32_matmul_precision(args.matmul_precision)
     tuned = None
     if not emul and not args.no_tuned_gemm and args.matmul_precision == "highest":
         # library GEMM selection only: the same IEEE f32 products, each shape on the rocBLAS / hipBLASLt kernel an offline
         # TunableOp pass measured fastest on this part (the file's validators — torch / HIP / library versions, gfx
         # arch — must match, otherwise torch ignores it and the default heuristics pick)
-        path = os.path.join(REPO, "gammagl_amd", "tuned", f"tunableop_gfx950_{args.workload}.csv")
-        if os.path.exists(path):
+        ds = WORKLOADS[args.workload]["dataset"] or "tiny"
+        path = os.path.join(REPO, "gammagl_amd", "tuned", f"tunableop_gfx950_{ds}.csv")
+        if os.path.exists(path) and kind == "gcn":
             try:
                 import torch.cuda.tunable as tun
 
@@ -279,39 +409,57 @@ def main():
             except Exception:  # noqa: BLE001
                 tuned = None
 
-    if args.workload == "tiny":
-        n_nodes, n_edges, f_in, n_cls = 20000, 400000, 100, 47
-    else:
-        n_nodes, n_edges, f_in, n_cls = DATASETS[args.workload]
-    out, pg = run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls, eng=eng)
+    want_cpu = world == 1 and not args.no_cpu_baseline and not emul
+    args.keep_host_graph = want_cpu and kind == "gcn" and args.workload != "tiny"
+    out, ctx = RUNNERS[kind](args, dev, rank, world, eng=eng)
     out["engine"] = "host-emulation (launcher test, not a measurement)" if emul else "hip"
     out["config"]["tuned_gemm_selection"] = tuned
     out["config"]["matmul_precision"] = args.matmul_precision + (" (IEEE f32)" if args.matmul_precision == "highest"
                                                                    else " (hipBLASLt f32 emulated with bf16 triples: NOT the line of record)")
-    if emul:
-        out["roofline"] = None
     if world > 1:
         import torch.distributed as dist
 
         assert dist.get_world_size() == args.gpus
     if rank == 0:
-        if world == 1 and not emul and args.pmc_traffic == "auto" and args.workload == "products":
-            t, src = measure_traffic(args, args.hidden, int(out["roofline"].get("launches_per_aggregate", 1)))
-            if t is not None:
-                out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t, src
-            elif out["roofline"].get("traffic") is not None:
-                out["roofline"]["traffic_source"] += f" [in-run collection unavailable: {src}]"
-        rf = out.get("roofline") or {}
-        if rf.get("traffic") and rf.get("ms_per_launch"):
-            # the HBM side of the same launch: measured bytes / its duration against the peak (frac above is algorithmic:
-            # it counts the gathers that L2 served as if they had crossed the fabric)
-            rf["traffic_GBps"] = rf["traffic"] / (rf["ms_per_launch"] * 1e-3) / 1e9
-            rf["traffic_frac"] = rf["traffic_GBps"] / rf["peak"]
-        if world == 1 and not args.no_cpu_baseline and not emul:
-            # the benchmark graph itself on the host (rank 0 holds all of it at N = 1)
-            ei = torch.cat([torch.stack([pg.ei_loc[0] + pg.lo, pg.ei_loc[1] + pg.lo]).cpu()], dim=1)
-            full = (ei.contiguous(), pg.w_loc.cpu(), n_nodes) if args.workload != "tiny" else None
-            out["cpu_baseline"] = cpu_baseline(args.hidden, n_cls, args.seed, full)
+        rf = out.get("roofline")
+        if rf and world == 1 and not emul and kind in KERNEL_OF:
+            t = src = None
+            extra = {}
+            if args.pmc_traffic != "off":
+                t, src, extra = measure_traffic(args, KERNEL_OF[kind], with_l2=args.pmc_traffic == "l2")
+            if t is None and kind == "gcn":
+                why = src
+                t, src = committed_traffic(args, int(rf["launches_per_aggregate"]), int(out["config"].get("rank0_local_edges", -1)))
+                if t is not None and why:
+                    src += f" [in-run collection unavailable: {why}]"
+                elif why:
+                    src = f"unavailable: {why}"
+            set_traffic(rf, t, src)
+            rf.update(extra)
+            also = [o for o in out["config"].get("orderings", [])[1:]]
+            if also and args.pmc_traffic == "l2":   # the second node order's traffic too (locality workloads)
+                t2, src2, extra2 = measure_traffic(args, KERNEL_OF[kind], relabel=also[0]["relabel"], with_l2=True)
+                also[0]["traffic_per_aggregate"] = None if t2 is None else t2 * int(rf["launches_per_aggregate"])
+                also[0]["traffic_source"] = src2
+                also[0].update(extra2)
+        if want_cpu:
+            if kind == "gcn":
+                n_nodes = int(out["config"].get("rank0_owned_rows", 0))
+                full = None
+                if args.workload != "tiny":
+                    if ctx.get("host_graph") is not None:
+                        ei, w = ctx["host_graph"]
+                    else:
+                        pg = ctx["pg"]    # N = 1: rank 0 holds the whole graph (a dry share: its local-source block)
+                        ei, w = torch.stack([pg.ei_loc[0], pg.ei_loc[1]]).cpu().contiguous(), pg.w_loc.cpu()
+                    full = (ei, w, n_nodes)
+                n_cls = sizes_of(args.workload)[3]
+                ctx.clear()
+                out["cpu_baseline"] = cpu_baseline_gcn(args.hidden, n_cls, args.seed, full)
+            elif kind == "gat":
+                out["cpu_baseline"] = cpu_baseline_gat(ctx, args.seed)
+            else:
+                out["cpu_baseline"] = cpu_baseline_sage(ctx, args.hidden, args.seed)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

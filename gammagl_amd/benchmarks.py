@@ -1,0 +1,504 @@
+"""The benchmark bodies behind bench.py: one function per workload family, each
+returning the JSON line's dict.  Harness code only — graphs are synthetic (`synth`), the work runs through the
+same Engine / layers / trainers a user gets; nothing here touches `oracle/` (bench.py's cpu_baseline leg does).
+
+  gcn   : full-graph 3-layer GCN training step (BASELINE metric) on `products` | `arxiv` | `tiny` (R-MAT),
+          `products-planted` (hierarchical planted communities: a graph WITH locality, beside R-MAT which has none)
+          and `papers-share` (config 5: rank 3's share of the 8-way papers100M-sized partition, dry, on one GPU);
+  gat   : `reddit-gat` — config 3, the 2-layer 8-head GAT training step on the Reddit-sized graph;
+  sage  : `sage-minibatch` — config 4, neighbour-sampled GraphSAGE mini-batches on the products-sized graph.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import engine as _default_engine
+from .dist import DistGCNTrainer, _HaloAggregate, build_partition
+from .synth import DATASETS
+
+PEAK_GBPS = 8000.0     # HBM3E peak of one MI355X (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: family, dataset sizes, generator, (dry partition: parts / rank played), second node order reported beside the main one
+    "products": dict(kind="gcn", dataset="products", gen="rmat", also="degree"),
+    "arxiv": dict(kind="gcn", dataset="arxiv", gen="rmat", also="degree"),
+    "tiny": dict(kind="gcn", dataset=None, gen="rmat", also=None),
+    "tiny-planted": dict(kind="gcn", dataset=None, gen="planted", also="cluster"),
+    "products-planted": dict(kind="gcn", dataset="products", gen="planted", also="cluster"),
+    "papers-share": dict(kind="gcn", dataset="papers100M", gen="rmat", parts=8, play=3, also=None),
+    "reddit-gat": dict(kind="gat", dataset="reddit"),
+    "sage-minibatch": dict(kind="sage", dataset="products"),
+}
+
+
+def sizes_of(workload):
+    spec = WORKLOADS[workload]
+    if spec["dataset"] is None:
+        return 20000, 400000, 100, 47
+    return DATASETS[spec["dataset"]]
+
+
+def _sync(dev, world):
+    if world > 1:
+        dist.barrier()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def roofline_block(kernel, launches, ms_per_aggregate, alg_bytes_aggregate, compulsory_bytes, edges,
+                   traffic_per_launch=None, traffic_source=None, extra=None):
+    """The `roofline` object of the line.  `frac` is a fraction of the HBM peak that cannot exceed 1: measured
+    HBM-side bytes per launch (PMC) / launch duration / peak.  The algorithmic rate (SURVEY.md §8d's no-reuse
+    byte count per AGGREGATE, ids and weights counted once, / the aggregate's duration) is `eff_GBps`: it may
+    exceed the peak when L2 serves part of the gathers, so it is reported as a rate, never as a fraction."""
+    ms_launch = max(ms_per_aggregate / max(launches, 1), 1e-9)
+    eff = alg_bytes_aggregate / (max(ms_per_aggregate, 1e-9) * 1e-3) / 1e9
+    rf = {"bound": "hbm", "kernel": kernel, "launches_per_aggregate": launches, "ms_per_aggregate": ms_per_aggregate,
+          "ms_per_launch": ms_launch, "peak": PEAK_GBPS, "unit": "GB/s",
+          "eff_GBps": eff, "alg_bytes_per_aggregate": alg_bytes_aggregate,
+          "compulsory_bytes": compulsory_bytes, "edges_per_s_aggregate": edges / (max(ms_per_aggregate, 1e-9) * 1e-3)}
+    set_traffic(rf, traffic_per_launch, traffic_source)
+    if extra:
+        rf.update(extra)
+    return rf
+
+
+def set_traffic(rf, traffic_per_launch, source):
+    """Fill `achieved` / `frac` / `traffic*` of a roofline block from measured bytes per launch (or mark them as
+    the algorithmic estimate, capped at the peak, when no counter data exists for this workload)."""
+    rf["traffic"], rf["traffic_source"] = traffic_per_launch, source
+    if traffic_per_launch:
+        rf["achieved"] = traffic_per_launch / (rf["ms_per_launch"] * 1e-3) / 1e9
+        rf["achieved_basis"] = "measured HBM-side bytes per launch (rocprofv3 --pmc: (2 x FETCH_SIZE + WRITE_SIZE) KiB) / launch duration"
+        rf["traffic_per_aggregate"] = traffic_per_launch * rf["launches_per_aggregate"]
+        rf["traffic_over_compulsory"] = rf["traffic_per_aggregate"] / max(rf["compulsory_bytes"], 1)
+    else:
+        rf["achieved"] = min(rf["eff_GBps"], PEAK_GBPS)
+        rf["achieved_basis"] = "no counter data for this workload: algorithmic bytes / duration, capped at the peak"
+    rf["frac"] = rf["achieved"] / PEAK_GBPS
+    return rf
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gcn: the BASELINE metric
+# ---------------------------------------------------------------------------------------------------------------
+def _gcn_data(pg, f_in, n_cls, seed, rank, dev, world):
+    """features / labels / train mask of the local rows only (no [N, F] tensor on any rank)"""
+    gen = torch.Generator(device=dev).manual_seed(seed + 7919 * (rank + 1))
+    x = torch.randn(pg.n_local, f_in, generator=gen, device=dev)
+    y = torch.randint(0, n_cls, (pg.n_local,), generator=gen, device=dev)
+    train_local = torch.nonzero(torch.rand(pg.n_local, generator=gen, device=dev) < 0.08).reshape(-1)
+    nt = torch.tensor([train_local.numel()], device=dev, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(nt)  # the global train-set size every rank normalises its loss by
+    return x, y, train_local, max(int(nt), 1), gen
+
+
+def _time_steps(trainer, data, args, dev, world):
+    x, y, train_local, n_train, _ = data
+    for _ in range(args.warmup):
+        trainer.step(x, y, train_local, n_train)
+    _sync(dev, world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, y, train_local, n_train)
+    _sync(dev, world)
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    lsum = loss.detach().double().reshape(1).clone()
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lsum)
+    return float(dt), float(lsum)
+
+
+def _exchange_report(pg, trainer, data, args, dev, world, widths):
+    """What the N > 1 step does on the wire, measured AFTER the timed region (events around every work.wait() would
+    perturb it): per-step exchange volume, the time the compute stream stalled waiting for all-to-alls
+    (`halo_exposed_ms`), each distinct exchange timed on its own (no compute beside it) and the overlap they imply."""
+    x, y, train_local, n_train, _ = data
+    k = max(1, min(int(args.steps), 5))
+    pg.profile = {}
+    for _ in range(k):
+        trainer.step(x, y, train_local, n_train)
+    _sync(dev, world)
+    rep = pg.profile_summary(k)
+    pg.profile = None
+    iso, iso_total = [], 0.0
+    P = max(pg.world, len(pg.send_splits)) if pg.dry else pg.world
+    for K, per_step in widths:
+        chunks = _HaloAggregate._chunks(K)
+        ms = {}
+        for direction, (n_out, n_in, osp, isp) in (("fwd", (pg.n_halo, pg.n_send, pg.recv_splits, pg.send_splits)),
+                                                   ("bwd", (pg.n_send, pg.n_halo, pg.send_splits, pg.recv_splits))):
+            bufs = [torch.zeros((n_in, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in chunks]
+            for rep_i in range(3):
+                if rep_i == 1:
+                    _sync(dev, world)
+                    t0 = time.perf_counter()
+                for ci, b in enumerate(bufs):
+                    _, w = pg._a2a(n_out, b, osp, isp, tag=("probe", direction, ci))
+                    w.wait()
+            _sync(dev, world)
+            ms[direction] = (time.perf_counter() - t0) / 2 * 1e3
+            del bufs
+        gb_in = pg.n_halo * K * 4 / 1e9
+        e = {"K": K, "exchanges_per_step": per_step, "chunks": len(chunks), "fwd_ms": ms["fwd"], "bwd_ms": ms["bwd"],
+             "GB_in_fwd": gb_in, "GBps_in_fwd": gb_in / max(ms["fwd"], 1e-9) * 1e3,
+             "GBps_per_link_fwd": gb_in / max(ms["fwd"], 1e-9) * 1e3 / max(P - 1, 1)}
+        iso.append(e)
+        iso_total += per_step * (ms["fwd"] + ms["bwd"]) / 2
+    for key in [k_ for k_ in pg._bufs if isinstance(k_[0], tuple) and k_[0][0] == "probe"]:
+        del pg._bufs[key]
+    rep["a2a_isolated"] = iso
+    rep["a2a_isolated_ms_per_step"] = iso_total
+    rep["overlap_frac"] = (1.0 - rep["halo_exposed_ms"] / iso_total) if iso_total > 0 and not pg.dry else None
+    rep["note"] = ("rank 0's figures; exposed = compute-stream stalls at work.wait(); isolated = the same all-to-all-v "
+                   "shapes with nothing beside them" + ("; DRY partition: nothing travels, times are buffer handling only"
+                                                        if pg.dry else ""))
+    return rep
+
+
+def dominant_spmm(pg, eng, K, gen, dev, reps=10):
+    """(ms per K-wide aggregate, launches, plan, weights, source rows, edges) of the step's dominant kernel on this
+    rank: the CSR SpMM-sum over its largest edge block (local-source edges on one GPU, halo-source edges in a
+    partition where most edges have a remote source)."""
+    use_halo = pg.gp_halo is not None and pg.gp_halo.E > pg.gp_loc.E
+    gp, w, rows = (pg.gp_halo, pg.w_halo, pg.n_halo) if use_halo else (pg.gp_loc, pg.w_loc, pg.n_local)
+    h = torch.randn(rows, K, generator=gen, device=dev)
+    ms = eng.time_spmm_sum(gp, w, h, reps=reps)
+    launches = int(eng.lib.ggl_spmm_col_blocks(gp.E, K, pg.n_local))
+    del h
+    return ms, launches, gp, rows, use_halo
+
+
+def pmc_probe_gcn(args, dev, eng):
+    """`bench.py --pmc-probe` for the gcn family: rebuild this run's graph and launch the dominant kernel a few
+    times (rocprofv3 --pmc wraps this process; FETCH_SIZE / WRITE_SIZE / TCC_* go in separate passes)."""
+    spec = WORKLOADS[args.workload]
+    n_nodes, n_edges, _, _ = sizes_of(args.workload)
+    pg = build_partition(n_nodes, n_edges, args.seed, spec.get("play", 0), 1, None, dev, eng, relabel=args.relabel,
+                         order=args.order, parts=spec.get("parts"), kind=spec["gen"])
+    gen = torch.Generator(device=dev).manual_seed(1)
+    ms, launches, gp, rows, _ = dominant_spmm(pg, eng, args.hidden, gen, dev, reps=4)
+    torch.cuda.synchronize()
+    print(f"pmc-probe: E={gp.E} rows_in={rows} K={args.hidden} launches/aggregate={launches} ms/aggregate={ms:.3f}", flush=True)
+
+
+def run_gcn(args, dev, rank, world, eng=None):
+    """bench.py body for the gcn family, any world size (world == 1 degenerates to no exchange).  Top-level
+    `value` / `ms_per_step` belong to the step with every layer associated as GammaGL's GCNConv writes it,
+    A (X W) (gcn_conv.py:79): 2 aggregations per layer."""
+    eng = eng if eng is not None else _default_engine()
+    spec = WORKLOADS[args.workload]
+    n_nodes, n_edges, f_in, n_cls = sizes_of(args.workload)
+    parts, play = spec.get("parts"), spec.get("play", 0)
+    if parts and world != 1:
+        raise SystemExit(f"bench.py: --workload {args.workload} plays rank {play} of a {parts}-way partition on ONE GPU "
+                         f"(dry partition); run it with --gpus 1")
+    emul = dev.type != "cuda"
+
+    def build(relabel):
+        t0 = time.perf_counter()
+        stats = {}
+        pg = build_partition(n_nodes, n_edges, args.seed, play if parts else rank, world, None, dev, eng, relabel=relabel,
+                             order=args.order, parts=parts, stats=stats, kind=spec["gen"])
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+        return pg, stats, time.perf_counter() - t0
+
+    pg, stats, t_gen = build(args.relabel)
+    E = pg.e_global
+    # edges this process aggregates per aggregation: the whole graph over all ranks — or, for a dry share, its own
+    e_unit = pg.e_local if parts else E
+    data = _gcn_data(pg, f_in, n_cls, args.seed, rank, dev, world)
+    gen = data[4]
+    af_main = bool(getattr(args, "aggregate_first", False))
+
+    def trainer(aggregate_first):
+        return DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev,
+                              aggregate_first=aggregate_first)
+
+    tr = trainer(af_main)
+    dt, lsum = _time_steps(tr, data, args, dev, world)
+    n_agg = tr.net.agg_per_step     # aggregations the step actually executed (counted by the model's forward)
+    value = n_agg * e_unit * args.steps / dt
+    exchange = None
+    if pg.comm and not getattr(args, "no_exchange_report", False):
+        kc = n_cls + (-n_cls) % 4
+        widths = [(args.hidden, 2 * (args.layers - 2)), (kc, 2)] if args.layers >= 2 else [(kc, 2)]
+        if not tr.net.const_input_halo:
+            widths[0] = (args.hidden, widths[0][1] + 2)
+        exchange = _exchange_report(pg, tr, data, args, dev, world, [w for w in widths if w[1] > 0])
+    side = None
+    if not getattr(args, "no_comparison", False):
+        tr2 = trainer(not af_main)
+        dt2, _ = _time_steps(tr2, data, args, dev, world)
+        if tr2.net.agg_per_step != n_agg:
+            side = {"ms_per_step": dt2 / args.steps * 1e3, "aggregations_per_step": tr2.net.agg_per_step,
+                    "value": tr2.net.agg_per_step * e_unit * args.steps / dt2, "unit": "edges/s",
+                    "note": ("the same model with a layer whose input is narrower than its output computing (A X) W "
+                             "(layer 1 aggregates its 100-wide input: one aggregate forward, none backward) — NOT the "
+                             "reference's association, reported beside the headline only") if not af_main else
+                            "every layer A (X W) as gcn_conv.py:79 writes it"}
+        del tr2
+    del tr
+
+    # dominant kernel (K = hidden), hipEvents on the launch stream
+    K = args.hidden
+    ms_op, launches, gp_t, rows_t, use_halo = dominant_spmm(pg, eng, K, gen, dev)
+    alg = gp_t.E * (4 * K + 8) + pg.n_local * (4 * K + 8)             # SURVEY §8d, per aggregate
+    b_min = 4 * K * (rows_t + pg.n_local) + 8 * gp_t.E + 8 * pg.n_local   # every row once + ids + rowptr
+    rf = roofline_block(
+        f"row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, rank 0's {'halo-source' if use_halo else 'local-source'} "
+        f"edge block: {gp_t.E} edges into {pg.n_local} rows from {rows_t} source rows; the K={K} aggregate runs as "
+        f"{launches} launch(es) over {K // max(launches, 1)}-column blocks)",
+        launches, ms_op, alg, b_min, gp_t.E)
+
+    kc = n_cls + (-n_cls) % 4
+    per_row = 2 * (args.hidden * max(args.layers - 2, 0) + kc)
+    cfg = {
+        "workload": f"{args.workload}: {spec['dataset'] or 'tiny'}-sized {'R-MAT' if spec['gen'] == 'rmat' else 'hierarchical planted-community graph'}"
+                    f", N={n_nodes}, E={E} directed incl. self-loops, features {f_in}->{args.hidden}x{args.layers - 1}->{n_cls}, "
+                    f"edge order={args.order}, relabel={args.relabel}, full-graph GCN train step (fwd+bwd+Adam), "
+                    f"{n_agg} aggregations/step ({'A (X W) in every layer, as gcn_conv.py:79' if not af_main else '(A X) W where the input is narrower'}), "
+                    f"symmetric-norm edge weights precomputed (GCNConv norm='none' + calc_gcn_norm edge_weight)"
+                    + (f"; DRY partition: this GPU plays rank {play} of {parts} (its {pg.n_local} rows, {pg.e_local} in-edges, "
+                       f"{pg.n_halo} halo rows; send lists and buffers as in the {parts}-rank run, nothing on the wire); value "
+                       f"counts the edges THIS rank aggregates" if parts else ""),
+        "association": "A (X W)" if not af_main else "(A X) W where narrower",
+        "aggregations_per_step": n_agg,
+        "aggregate_first" if not af_main else "transform_first": side,
+        "parallelism": (f"node-partition x{world}, 1-hop halo all-to-all-v, per-rank graph construction" if world > 1 else
+                        (f"1 GPU playing rank {play} of {parts}" if parts else "1 GPU")),
+        "rank0_local_edges": pg.e_local, "rank0_local_source_edges": pg.gp_loc.E, "rank0_halo_rows": pg.n_halo,
+        "rank0_send_rows": pg.n_send, "rank0_owned_rows": pg.n_local,
+        "rank0_peak_edges_during_build": stats.get("peak_edges"),
+        # floats a halo row costs per step: layers 2.. exchange their K-wide rows forward and backward; layer 1
+        # exchanges nothing (the input features' halo rows were fetched once at setup)
+        "halo_floats_per_row_per_step": per_row,
+        "rank0_halo_GB_per_step": round((pg.n_halo + pg.n_send) * 4 * per_row / 1e9, 3),
+        "exchange": exchange, "setup_s": round(t_gen, 2), "loss": lsum}
+    if parts:
+        cfg["if_links_were_free_edges_per_s_all_ranks"] = n_agg * E * args.steps / dt
+    out = {
+        "metric": ("edges aggregated/sec, 3-layer GCN hidden=256 training step, ogbn-products-sized graph"
+                   if args.workload == "products" else
+                   f"edges aggregated/sec, {args.layers}-layer GCN hidden={args.hidden} training step, {args.workload}"),
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+        "config": cfg, "roofline": None if emul else rf}
+
+    # the second node order ("report both"), same association, same step count
+    also = getattr(args, "also_relabel", None)
+    also = spec.get("also") if also in (None, "auto") else (None if also == "none" else also)
+    ctx = {"pg": pg, "data": data}
+    if also and also != args.relabel and world == 1 and not parts:
+        host_graph = None
+        if getattr(args, "keep_host_graph", False):   # bench.py's cpu_baseline leg wants the main graph on the host
+            host_graph = (torch.stack([pg.ei_loc[0] + pg.lo, pg.ei_loc[1] + pg.lo]).cpu().contiguous(), pg.w_loc.cpu())
+        main_order = {"relabel": args.relabel, "ms_per_step": out["ms_per_step"], "value": value,
+                      "ms_per_aggregate_K%d" % K: ms_op}
+        del pg, data, gp_t
+        ctx = {"host_graph": host_graph}
+        eng.clear_caches()
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+        pg, stats2, t2 = build(also)
+        data = _gcn_data(pg, f_in, n_cls, args.seed, rank, dev, world)
+        tr = trainer(af_main)
+        dt_b, _ = _time_steps(tr, data, args, dev, world)
+        ms_b, _, gp_b, _, _ = dominant_spmm(pg, eng, K, data[4], dev)
+        second = {"relabel": also, "ms_per_step": dt_b / args.steps * 1e3, "value": tr.net.agg_per_step * pg.e_global * args.steps / dt_b,
+                  "ms_per_aggregate_K%d" % K: ms_b, "setup_s": round(t2, 2), "E": pg.e_global}
+        if "clusters" in stats2:
+            second["clusters"] = stats2["clusters"]
+        out["config"]["orderings"] = [main_order, second]
+        del tr, gp_b
+        ctx.update(pg=pg, data=data)
+    return out, ctx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gat: config 3
+# ---------------------------------------------------------------------------------------------------------------
+def _event_ms(fn, reps=9, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+
+
+def pmc_probe_gat(args, dev, eng):
+    from .synth import rmat_graph
+
+    n, e, _, _ = DATASETS["reddit"]
+    ei = rmat_graph(n, e, seed=args.seed, device=dev)
+    H, C = 8, 8
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(n, H, C, generator=g, device=dev)
+    el, er = torch.randn(n, H, generator=g, device=dev), torch.randn(n, H, generator=g, device=dev)
+    with torch.no_grad():
+        for _ in range(4):
+            eng.gat_fused(ei, el, er, x, 0.2)
+    torch.cuda.synchronize()
+    print("pmc-probe: gat forward 8x8 on the Reddit-sized graph", flush=True)
+
+
+def run_gat(args, dev, rank, world, eng=None):
+    """Config 3: 2-layer, 8-head GAT (602 -> 8 x 8 -> 41 classes, the last layer averages its heads; feature and
+    attention dropout 0.6 — examples/gat/gat_trainer.py defaults) on the Reddit-sized graph, one full-graph
+    training step (fwd + bwd + Adam) through FusedGATConv = the fused edge-softmax + aggregate kernels."""
+    from .layers import GATModel
+    from .synth import rmat_graph
+
+    if world != 1:
+        raise SystemExit("bench.py: --workload reddit-gat is BASELINE config 3, a single-GPU configuration (--gpus 1)")
+    eng = eng if eng is not None else _default_engine()
+    n, e, f_in, n_cls = DATASETS["reddit"]
+    t0 = time.perf_counter()
+    ei = rmat_graph(n, e, seed=args.seed, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    E = int(ei.shape[1])
+    g = torch.Generator(device=dev).manual_seed(args.seed)
+    x = torch.randn(n, f_in, generator=g, device=dev)
+    y = torch.randint(0, n_cls, (n,), generator=g, device=dev)
+    tidx = torch.arange(0, n, 3, device=dev)
+    torch.manual_seed(args.seed)
+    H, C = 8, 8
+    net = GATModel(f_in, C, n_cls, H, 0.6, 2, fused=True).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=0.005, weight_decay=5e-4)
+
+    def step():
+        net.train()
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(net(x, ei, n)[tidx], y[tidx])
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    walks = 4     # 2 layers x (forward + backward) walks over every edge (the backward of a layer is two walks — by
+    #               destination and by source — counted as one aggregation like a GCN layer's transposed SpMM)
+    # dominant kernel: the forward walk of the 8 x 8 layer
+    xg = torch.randn(n, H, C, generator=g, device=dev)
+    el, er = torch.randn(n, H, generator=g, device=dev), torch.randn(n, H, generator=g, device=dev)
+    with torch.no_grad():
+        ms_k = _event_ms(lambda: eng.gat_fused(ei, el, er, xg, 0.2))
+    alg = E * (4 * H * C + 4 * H + 4) + n * (4 * H * C + 8 * H + 8)
+    b_min = n * (4 * H * C + 4 * H) + n * (4 * H * C + 4 * H) + 4 * E + 8 * n
+    rf = roofline_block("gat_fwd2_kernel (fused edge-softmax + weighted aggregate, forward walk of the 8 x 8 layer; "
+                        "one launch + the hub-chunk combine)", 1, ms_k, alg, b_min, E)
+    out = {"metric": "edges aggregated/sec, 2-layer 8-head GAT training step, Reddit-sized graph (fused edge-softmax + aggregate)",
+           "value": walks * E * args.steps / dt, "unit": "edges/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "rccl_ranks": 1,
+           "config": {"workload": f"reddit-gat: Reddit-sized R-MAT N={n}, E={E} directed incl. self-loops, GATModel({f_in} -> "
+                                  f"{H}x{C} -> {n_cls}, heads averaged in the output layer), feature + attention dropout 0.6, "
+                                  f"full-graph train step (fwd+bwd+Adam), {walks} edge walks/step",
+                      "walks_per_step": walks, "fused_gat_forward_ms": ms_k, "setup_s": round(t_gen, 2),
+                      "loss": float(loss), "parallelism": "1 GPU"},
+           "roofline": rf}
+    return out, {"ei": ei, "n": n}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sage: config 4
+# ---------------------------------------------------------------------------------------------------------------
+def run_sage(args, dev, rank, world, eng=None):
+    """Config 4: GraphSAGE mini-batches (2048 seeds, fan-out [25, 10], hidden 256) on the products-sized graph:
+    static-shape device sampler + SAGEConv(mean) with the fused epilogue, the whole step replayed as one hipGraph
+    (world == 1); with world > 1 every rank is a replica sampling its own seeds, gradients averaged by one flat
+    all-reduce per step ("replicas only") — scaling = weak."""
+    from .sampler import BlockSampler
+    from .synth import rmat_graph
+    from .trainer import SAGEBlockTrainer
+
+    eng = eng if eng is not None else _default_engine()
+    n, e, f_in, n_cls = DATASETS["products"]
+    t0 = time.perf_counter()
+    ei = rmat_graph(n, e, seed=args.seed, device=dev)
+    g = torch.Generator(device=dev).manual_seed(args.seed + 31 * rank)
+    x = torch.randn(n, f_in, generator=g, device=dev)
+    y = torch.randint(0, n_cls, (n,), generator=g, device=dev)
+    B = 2048
+    bs = BlockSampler(ei, [25, 10], num_nodes=n, eng=eng)
+    caps = bs.calibrate(B, trials=8, slack=1.25)
+    tr = SAGEBlockTrainer(bs, f_in, args.hidden, n_cls, device=dev, caps=caps, world=world)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    batches = [torch.randperm(n, generator=g, device=dev)[:B].contiguous() for _ in range(max(args.steps, 1))]
+    seeds = batches[0].clone()
+    if world == 1:
+        tr.capture(x, y, seeds)
+
+        def run(b):
+            seeds.copy_(b)
+            return tr.replay()
+    else:
+        def run(b):
+            return tr.step(x, y, b)
+    for i in range(args.warmup):
+        run(batches[i % len(batches)])
+    _sync(dev, world)
+    t0 = time.perf_counter()
+    for b in batches[: args.steps]:
+        loss = run(b)
+    _sync(dev, world)
+    dtt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
+    dt = float(dtt)
+    # what one batch aggregates: valid edges of its two blocks (outermost first)
+    _, blocks, _ = bs.sample(batches[0], caps=caps)
+    valid = [(int(b.counts[0]), int(b.counts[1])) for b in blocks]   # (source rows, edges) per block
+    e_batch = sum(v[1] for v in valid)
+    # dominant aggregate: the outer block's mean over 100-wide input rows (layer 1 aggregates before it transforms)
+    blk = blocks[0]
+    xin = torch.randn(blk.n_src_cap, f_in, generator=g, device=dev)
+    yout = torch.empty(blk.n_dst_cap, f_in, device=dev)
+    ms_k = _event_ms(lambda: eng.spmm_epi_into(blk.plan, blk.col, None, xin, yout, mean=True), reps=21)
+    alg = valid[0][1] * (4 * f_in + 4) + blk.n_dst_cap * (4 * f_in + 8)
+    b_min = 4 * f_in * (valid[0][0] + blk.n_dst_cap) + 4 * valid[0][1] + 8 * blk.n_dst_cap
+    rf = roofline_block(f"row_reduce_kernel<float,4,MEAN,SPMM_EPI> (the outer block's mean aggregate: {valid[0][1]} sampled edges, "
+                        f"{f_in}-wide rows; a {ms_k * 1e3:.0f} us kernel — the replayed step is bound by its ~110 small kernels, "
+                        f"not by HBM)", 1, ms_k, alg, b_min, valid[0][1])
+    out = {"metric": "sampled-block edges aggregated/sec, GraphSAGE mini-batch training (2048 seeds, fan-out [25,10]), "
+                     "products-sized graph",
+           "value": world * e_batch * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+           "config": {"workload": f"sage-minibatch: products-sized R-MAT N={n}, E={int(ei.shape[1])}, GraphSAGE {f_in}->"
+                                  f"{args.hidden}->{n_cls}, SAGEConv(mean), {B} seeds/batch/GPU, fan-out [25,10]; a step = "
+                                  f"sample 2 hops on the device + gather + fwd + bwd + Adam"
+                                  + (" as ONE replayed hipGraph" if world == 1 else ", eager replicas + gradient all-reduce"),
+                      "seeds_per_s": world * B * args.steps / dt, "block_valid_src_rows_edges": valid,
+                      "block_capacities": [list(c) for c in caps], "overflowed_hops": bs.overflow_count(),
+                      "parallelism": f"{world} replica(s)", "setup_s": round(t_gen, 2), "loss": float(loss)},
+           "roofline": rf}
+    return out, {"blocks": blocks, "valid": valid}
+
+
+RUNNERS = {"gcn": run_gcn, "gat": run_gat, "sage": run_sage}
+PROBES = {"gcn": pmc_probe_gcn, "gat": pmc_probe_gat}

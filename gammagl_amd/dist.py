@@ -13,7 +13,14 @@ node of 8 MI355X, one process per GPU over ``torch.distributed`` (backend "nccl"
   backward: transposed halo SpMM -> reverse all-to-all-v, overlapped with the transposed local SpMM,
   then a deterministic segment-sum of the returned rows into the local gradient (no atomics);
   the exchange is cut into feature-column chunks so that chunk c+1 travels while chunk c is multiplied;
-* weight gradients: one flat all-reduce per step (3 small matrices).
+* weight gradients: one flat all-reduce per step (3 small matrices);
+* rows that never change — the INPUT features — are exchanged once (`PartitionedGraph.with_halo`): the first
+  layer then aggregates over `[x_local ; x_halo]` (or transforms those rows itself, A (X W) = A_loc (X_loc W) +
+  A_halo (X_halo W)) and needs no exchange in either direction, forward or backward: the gradient of a halo row of
+  X W is consumed where it is produced, by the rank's own share of dW = X^T dH, which is all-reduced anyway;
+* send / receive buffers are persistent per (direction, chunk, shape) (`PartitionedGraph._buf`), and
+  `PartitionedGraph.profile` (a dict, off when None) collects per-step exchange volumes and the time the compute
+  stream spent waiting for each all-to-all (events around `work.wait()`), which bench.py reports for N > 1.
 
 Every output row is still reduced on exactly one GPU by the same kernels as the single-GPU path;
 only the association (local edges first, then halo edges) differs, so results agree with the
@@ -133,22 +140,96 @@ class PartitionedGraph:
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
         self.n_send = int(self.send_idx.shape[0])
         self.send_plan = self.eng.seg_plan(self.send_idx, self.n_local) if self.n_send > 0 else None
+        self._bufs = {}        # persistent exchange buffers, see _buf
+        self._const = {}       # [x_local ; x_halo] of tensors that never change, see with_halo
+        self.profile = None    # set to {} to collect exchange statistics (bench.py, N > 1)
+
+    # ---- persistent buffers / constants / instrumentation ----------------------------------------
+    def _buf(self, tag, rows, cols, dtype, device):
+        """One buffer per (direction, chunk, shape), allocated on first use and reused by every later step:
+        the exchange then runs on fixed addresses (no allocator traffic per chunk per call; a precondition for
+        recording the step into a hipGraph).  Reuse is safe in stream order: a buffer's consumer (the halo
+        SpMM / the segment-sum of returned rows) is enqueued before the next collective that overwrites it is
+        issued, and the process group makes its stream wait for the issuing stream."""
+        key = (tag, int(rows), int(cols), dtype)
+        b = self._bufs.get(key)
+        if b is None or b.device != device:
+            b = torch.empty((int(rows), int(cols)), dtype=dtype, device=device)
+            self._bufs[key] = b
+        return b
+
+    def with_halo(self, x):
+        """[x_local ; x_halo] for a tensor of local rows that NEVER changes (the input features): the halo rows are
+        fetched from their owners once and kept, keyed on the identity + version of `x`.  An aggregate over the
+        result (`aggregate(..., halo_included=True)`) exchanges nothing, in either direction."""
+        if not self.comm or self.n_halo == 0:
+            return x
+        key = (x.untyped_storage()._cdata, x.storage_offset(), tuple(x.shape), x._version, str(x.device))
+        hit = self._const.get(key)
+        if hit is None:
+            with torch.no_grad():
+                xc = x.detach().contiguous()
+                send = xc.index_select(0, self.send_idx) if self.n_send > 0 else xc.new_empty((0,) + tuple(xc.shape[1:]))
+                recv = torch.empty((self.n_halo,) + tuple(xc.shape[1:]), dtype=xc.dtype, device=xc.device)
+                if self.dry:
+                    recv.zero_()
+                else:
+                    dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits, group=self.group)
+                hit = torch.cat([xc, recv], 0)
+            self._const.clear()      # one constant at a time: a new input tensor replaces the old copy
+            self._const[key] = hit
+            self._const_ref = x      # keeps the storage alive so its identity cannot be recycled
+        return hit
+
+    def _note(self, **kw):
+        if self.profile is not None:
+            for k, v in kw.items():
+                self.profile[k] = self.profile.get(k, 0) + v
+
+    def _timed_wait(self, work, dev):
+        """work.wait() with the stall it causes recorded when profiling: on the GPU the compute stream's wait is
+        bracketed by two events (read back by `profile_summary`), on the host (gloo) by the wall clock."""
+        if self.profile is None:
+            work.wait()
+            return
+        if dev.type == "cuda":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work.wait()
+            e1.record()
+            self.profile.setdefault("_events", []).append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            work.wait()
+            self.profile["exposed_ms"] = self.profile.get("exposed_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+
+    def profile_summary(self, steps):
+        """Per-step averages of what `profile` collected over `steps` steps (call after a device sync)."""
+        p = dict(self.profile or {})
+        ev = p.pop("_events", [])
+        ms = p.pop("exposed_ms", 0.0) + sum(a.elapsed_time(b) for a, b in ev)
+        s = max(int(steps), 1)
+        return {"halo_exposed_ms": ms / s, "a2a_calls": p.get("a2a_calls", 0) / s,
+                "a2a_GB_in": p.get("bytes_in", 0) / s / 1e9, "a2a_GB_out": p.get("bytes_out", 0) / s / 1e9}
 
     # ---- raw building blocks -------------------------------------------------------------------
-    def _a2a(self, out_rows, inp, out_splits, in_splits):
-        out = torch.empty((out_rows,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+    def _a2a(self, out_rows, inp, out_splits, in_splits, tag="a2a"):
+        out = self._buf(tag, out_rows, inp.shape[1], inp.dtype, inp.device)
+        self._note(a2a_calls=1, bytes_in=out.numel() * out.element_size(), bytes_out=inp.numel() * inp.element_size())
         if self.dry:  # nothing travels: the receive buffer keeps whatever it holds (finite values for timing)
             out.zero_()
             return out, _Done()
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
         return out, work
 
-    def aggregate(self, h, bias=None, relu=False, p_drop=0.0, training=True):
+    def aggregate(self, h, bias=None, relu=False, p_drop=0.0, training=True, halo_included=False):
         """out[i] = dropout(relu(sum_{j->i} w_ij h[j] + bias)) for the local rows i (autograd-aware).  The
         epilogue (gcn_conv.py:105-106, models/gcn.py:55-59) rides on the store of the LAST edge block added:
-        the local SpMM when this rank has no halo, the halo-source SpMM otherwise."""
+        the local SpMM when this rank has no halo, the halo-source SpMM otherwise.  `halo_included`: `h` holds
+        n_local + n_halo rows, the halo rows already in place behind the local ones (`with_halo`, or rows this rank
+        computed from them): nothing is exchanged, and the gradient comes back with the same n_local + n_halo rows."""
         p = float(p_drop) if training else 0.0
-        return _HaloAggregate.apply(h, self, bias, bool(relu), p)
+        return _HaloAggregate.apply(h, self, bias, bool(relu), p, bool(halo_included))
 
 
 class _HaloAggregate(torch.autograd.Function):
@@ -171,25 +252,31 @@ class _HaloAggregate(torch.autograd.Function):
         return [(i * w, (i + 1) * w) for i in range(n)]
 
     @staticmethod
-    def forward(ctx, h, pg, bias, relu, p_drop):
+    def forward(ctx, h, pg, bias, relu, p_drop, pre=False):
         eng = pg.eng
+        pre = bool(pre and pg.comm and pg.n_halo > 0)
+        if h.shape[0] != pg.n_local + (pg.n_halo if pre else 0):
+            raise RuntimeError(f"aggregate: expected {pg.n_local + (pg.n_halo if pre else 0)} rows, got {h.shape[0]}")
         ctx.k_orig = h.shape[1]
         epi = bias is not None or relu or p_drop > 0
         fused = epi and h.shape[1] % 4 == 0   # (odd widths: aggregate on padded rows, epilogue as its own pass)
         h = _HaloAggregate._pad4(h.contiguous())
         K = h.shape[1]
-        rng = eng._rng_state(h.device) if (fused and p_drop > 0) else None
+        dev = h.device
+        rng = eng._rng_state(dev) if (fused and p_drop > 0) else None
         ctx.rng_used = rng.clone() if rng is not None else None
         b = bias.contiguous().reshape(-1) if (fused and bias is not None) else None
         works = []
-        if pg.comm:
-            for (c0, c1) in _HaloAggregate._chunks(K):
-                send = torch.empty((pg.n_send, c1 - c0), dtype=h.dtype, device=h.device)
+        if pre:      # the halo rows sit behind the local ones already: one "chunk", nothing on the wire
+            works.append((0, K, h[pg.n_local:], _Done()))
+        elif pg.comm:
+            for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
+                send = pg._buf(("fs", ci), pg.n_send, c1 - c0, h.dtype, dev)
                 if pg.n_send > 0:  # one kernel: rows of the column block straight into the send buffer
                     eng.gather_rows_into(h[:, c0:c1], pg.send_idx, send)
-                recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits)
+                recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits, tag=("fr", ci))
                 works.append((c0, c1, recv, work))
-        out = torch.empty((pg.n_local, K), dtype=torch.float32, device=h.device)
+        out = torch.empty((pg.n_local, K), dtype=torch.float32, device=dev)
         last_is_local = fused and (not pg.comm or pg.n_halo == 0)
         # local-source edges: overlaps the exchange
         if last_is_local:
@@ -198,7 +285,7 @@ class _HaloAggregate(torch.autograd.Function):
         else:
             eng.spmm_sum_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out)
         for i, (c0, c1, recv, work) in enumerate(works):
-            work.wait()
+            pg._timed_wait(work, dev)
             if pg.n_halo > 0:  # halo-source edges added onto the column block in place
                 if fused:
                     eng.spmm_epi_into(pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, recv, out[:, c0:c1], accumulate=True,
@@ -209,14 +296,14 @@ class _HaloAggregate(torch.autograd.Function):
         if out.shape[1] != ctx.k_orig:
             out = out[:, :ctx.k_orig].contiguous()
         if epi and not fused:
-            rng = eng._rng_state(h.device) if p_drop > 0 else None
+            rng = eng._rng_state(dev) if p_drop > 0 else None
             ctx.rng_used = rng.clone() if rng is not None else None
             y = torch.empty_like(out)
             bb = bias.contiguous().reshape(-1) if bias is not None else None
             eng._check(eng.lib.ggl_bias_act_fwd(_ptr(out), _ptr(bb), out.shape[0], out.shape[1], int(relu),
                                                 float(p_drop), _ptr(rng), _ptr(y), eng._stream(out.device)))
             out = y
-        ctx.pg, ctx.epi = pg, (epi, relu, p_drop, None if bias is None else bias.shape)
+        ctx.pg, ctx.pre, ctx.epi = pg, pre, (epi, relu, p_drop, None if bias is None else bias.shape)
         if epi:
             ctx.save_for_backward(out)
         return out
@@ -226,38 +313,47 @@ class _HaloAggregate(torch.autograd.Function):
         pg = ctx.pg
         eng = pg.eng
         g = g.contiguous()
+        dev = g.device
         epi, relu, p_drop, bshape = ctx.epi
         gb = None
         if epi:  # through dropout / ReLU / + bias in one pass (mask redrawn from the saved rng state)
             (y,) = ctx.saved_tensors
             N, K0 = int(g.shape[0]), int(g.shape[1])
             ga = torch.empty_like(g)
-            gb = torch.empty(K0, dtype=torch.float32, device=g.device) if bshape is not None else None
+            gb = torch.empty(K0, dtype=torch.float32, device=dev) if bshape is not None else None
             wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K0)
-            ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=g.device)
+            ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
             eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K0, int(relu), float(p_drop),
                                                 _ptr(ctx.rng_used), _ptr(ga), _ptr(gb), _ptr(ws), wsb,
-                                                eng._stream(g.device)))
+                                                eng._stream(dev)))
             g = ga
             if gb is not None:
                 gb = gb.reshape(bshape)
         if not ctx.needs_input_grad[0]:
-            return None, None, gb, None, None
+            return None, None, gb, None, None, None
         g = _HaloAggregate._pad4(g)
+        K = g.shape[1]
+        if ctx.pre:
+            # the gradient of a halo row stays here (its consumer is this rank's share of a weight gradient): both
+            # transposed walks write into one [n_local + n_halo, K] result, nothing travels back
+            gh = torch.empty((pg.n_local + pg.n_halo, K), dtype=g.dtype, device=dev)
+            eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g, gh[pg.n_local:])
+            eng.spmm_sum_into(pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, gh[:pg.n_local])
+            return (gh if K == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None, gb, None, None, None
         works = []
         if pg.comm:
-            for (c0, c1) in _HaloAggregate._chunks(g.shape[1]):
-                ghalo = torch.empty((pg.n_halo, c1 - c0), dtype=g.dtype, device=g.device)
+            for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
+                ghalo = pg._buf(("bs", ci), pg.n_halo, c1 - c0, g.dtype, dev)
                 if pg.n_halo > 0:  # reads the column block of g in place (row stride passed down)
                     eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g[:, c0:c1], ghalo)
-                gsend, work = pg._a2a(pg.n_send, ghalo, pg.send_splits, pg.recv_splits)  # chunk c travels while c+1 computes
+                gsend, work = pg._a2a(pg.n_send, ghalo, pg.send_splits, pg.recv_splits, tag=("br", ci))  # chunk c travels while c+1 computes
                 works.append((c0, c1, gsend, work))
         gh, _ = eng._spmm_fwd("sum", pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, pg.n_local)  # overlaps
         for (c0, c1, gsend, work) in works:
-            work.wait()
+            pg._timed_wait(work, dev)
             if pg.n_send > 0:  # deterministic scatter-add of the returned rows, onto the column block in place
                 eng.segment_sum_into(gsend, pg.send_plan, gh[:, c0:c1], accumulate=True)
-        return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None, gb, None, None
+        return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None, gb, None, None, None
 
 
 class _LinearSideWgrad(torch.autograd.Function):
@@ -311,14 +407,16 @@ class DistGCN(torch.nn.Module):
     gcn_conv.py:78-108 with norm='none'), each GCNConv's propagate replaced by the halo aggregate."""
 
     def __init__(self, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, overlap_wgrad=True,
-                 aggregate_first=True):
-        """`aggregate_first`: a layer whose input is NARROWER than its output computes (A X) W instead of
-        A (X W) — the same product, associated the cheap way round (the rule DGL's GraphConv applies; GammaGL's
-        GCNConv always transforms first, gcn_conv.py:79).  For the first layer of the products model (100 -> 256)
+                 aggregate_first=False, const_input_halo=True):
+        """Default: every layer computes A (X W), the association GammaGL's GCNConv writes (gcn_conv.py:79).
+        `aggregate_first` (an option, NOT the reference's association: results then agree with it to rounding
+        only): a layer whose input is NARROWER than its output computes (A X) W instead — the same product,
+        associated the cheap way round (the rule DGL's GraphConv applies).  For the first layer of the products model (100 -> 256)
         the aggregate then moves 400-byte rows instead of 1 KiB ones, and its BACKWARD needs no aggregation at all:
         the input features carry no gradient, and dW = (A X)^T dH is a GEMM on the saved aggregate."""
         super().__init__()
         self.overlap_wgrad, self.aggregate_first = overlap_wgrad, aggregate_first
+        self.const_input_halo = const_input_halo   # exchange the halo rows of the (constant) input features once
         self.agg_per_step = 2 * num_layers   # aggregations one training step executes (set by forward)
         dims = [feature_dim] + [hidden_dim] * (num_layers - 1) + [num_class]
         self.lin = torch.nn.ModuleList([torch.nn.Linear(a, b, bias=False) for a, b in zip(dims[:-1], dims[1:])])
@@ -346,6 +444,11 @@ class DistGCN(torch.nn.Module):
         if x.is_cuda and self.side is None and self.overlap_wgrad:
             self.side = torch.cuda.Stream(device=x.device)
         n_agg = 0
+        # input features never change: their halo rows are fetched once (PartitionedGraph.with_halo) and the first
+        # layer runs over [x_local ; x_halo] without any exchange, forward or backward
+        pre = bool(self.const_input_halo and pg.comm and pg.n_halo > 0 and not x.requires_grad)
+        if pre:
+            x = pg.with_halo(x)
         for i in range(n):
             hidden = i < n - 1
             n_out = self.lin[i].weight.shape[0]
@@ -355,15 +458,18 @@ class DistGCN(torch.nn.Module):
             if self.aggregate_first and x.shape[1] < n_out and x.shape[1] % 4 == 0:
                 # (A X) W: aggregate the narrower side; the epilogue follows the GEMM as its own pass
                 n_agg += 2 if x.requires_grad else 1
-                z = pg.aggregate(x)
+                z = pg.aggregate(x, halo_included=pre)
                 h = _LinearSideWgrad.apply(z, self.lin[i].weight, self.side, self._sink, pad)
                 x = pg.eng.bias_act(h, bias, relu=hidden, p_drop=p, training=self.training)
             else:
+                # A (X W), GammaGL's association (gcn_conv.py:79).  With the halo rows of a constant input in place
+                # the transform runs on them too: A (X W) = A_loc (X_loc W) + A_halo (X_halo W)
                 n_agg += 2
                 h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink, pad)
                 # + bias, ReLU and dropout ride on the store of the last edge block added to a row: the local SpMM
                 # on one GPU, the halo-source SpMM behind the exchange otherwise (reduce.hip MODE_SPMM_EPI)
-                x = pg.aggregate(h, bias, relu=hidden, p_drop=p, training=self.training)
+                x = pg.aggregate(h, bias, relu=hidden, p_drop=p, training=self.training, halo_included=pre)
+            pre = False
             if pad:
                 x = x[:, :n_out]
         self.agg_per_step = n_agg
@@ -372,13 +478,13 @@ class DistGCN(torch.nn.Module):
 
 class DistGCNTrainer:
     def __init__(self, pg, feature_dim, hidden_dim, num_class, num_layers=3, drop_rate=0.5, lr=0.01,
-                 l2_coef=5e-4, seed=0, device="cuda", aggregate_first=True, capturable=False):
+                 l2_coef=5e-4, seed=0, device="cuda", aggregate_first=False, capturable=False, const_input_halo=True):
         """`capturable`: Adam keeps its step counter on the device so that `capture()` can record the whole step
         into one hipGraph (launch-bound graphs: an arxiv-sized step is ~90 launches of 5-300 us)."""
         self.pg = pg
         torch.manual_seed(seed)  # identical initial weights on every rank
         self.net = DistGCN(feature_dim, hidden_dim, num_class, num_layers, drop_rate,
-                           aggregate_first=aggregate_first).to(device)
+                           aggregate_first=aggregate_first, const_input_halo=const_input_halo).to(device)
         on_gpu = torch.device(device).type == "cuda"
         try:    # one fused optimizer kernel for all parameters on the GPU
             self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, weight_decay=l2_coef, fused=on_gpu,
@@ -424,141 +530,24 @@ class DistGCNTrainer:
 
 
 def build_partition(n_nodes, n_edges, seed, rank, world, group, dev, eng, relabel="random", order="src",
-                    parts=None, stats=None):
+                    parts=None, stats=None, kind="rmat"):
     """This rank's PartitionedGraph of the synthetic benchmark graph, built WITHOUT a global edge list:
     `synth.rmat_partitioned` hands every rank only the edges whose destination it owns (same graph for
     every world size), the halo bookkeeping exchanges node ids only.  `parts` > world == 1: a dry
-    partition — this process plays rank `rank` of `parts` (one GPU measuring one rank's share)."""
-    from .synth import rmat_partitioned
+    partition — this process plays rank `rank` of `parts` (one GPU measuring one rank's share).
+    `kind` = "planted" (a graph with community structure) or `relabel` = "cluster" (the locality-aware order of
+    `partition.cluster_order`) need the whole graph in one place: every rank builds it itself
+    (`synth.full_graph_partitioned` — graphs that fit one GPU, i.e. everything up to the products size)."""
+    from .synth import full_graph_partitioned, rmat_partitioned
 
-    g = rmat_partitioned(n_nodes, n_edges, seed=seed, rank=rank, world=world, group=group, device=dev,
-                         relabel=relabel, order=order, parts=parts, stats=stats)
+    if kind != "rmat" or relabel == "cluster":
+        g = full_graph_partitioned(kind, n_nodes, n_edges, seed=seed, rank=rank, world=world, device=dev,
+                                   relabel=relabel, order=order, parts=parts, stats=stats, eng=eng)
+    else:
+        g = rmat_partitioned(n_nodes, n_edges, seed=seed, rank=rank, world=world, group=group, device=dev,
+                             relabel=relabel, order=order, parts=parts, stats=stats)
     dry = world == 1 and (parts or 1) > 1
     pg = PartitionedGraph.from_local(g["src"], g["dst"], g["w"], g["bounds"], n_nodes, g["e_global"],
                                      rank=g["rank"], world=world, group=group, eng=eng,
                                      send_rows=g.get("send_rows") if dry else None)
     return pg
-
-
-def run_distributed_bench(args, dev, rank, world, n_nodes, n_edges, f_in, n_cls, eng=None):
-    """bench.py body for any world size (world == 1 degenerates to no exchange)."""
-    eng = eng if eng is not None else _default_engine()
-    t_gen = time.perf_counter()
-    stats = {}
-    pg = build_partition(n_nodes, n_edges, args.seed, rank, world, None, dev, eng, relabel=args.relabel,
-                         order=args.order, stats=stats)
-    E = pg.e_global
-    if dev.type == "cuda":
-        torch.cuda.empty_cache()
-        torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
-    # features / labels / train mask of the local rows only (no [N, F] tensor on any rank)
-    gen = torch.Generator(device=dev).manual_seed(args.seed + 7919 * (rank + 1))
-    x = torch.randn(pg.n_local, f_in, generator=gen, device=dev)
-    y = torch.randint(0, n_cls, (pg.n_local,), generator=gen, device=dev)
-    train_local = torch.nonzero(torch.rand(pg.n_local, generator=gen, device=dev) < 0.08).reshape(-1)
-    nt = torch.tensor([train_local.numel()], device=dev, dtype=torch.int64)
-    if world > 1:
-        dist.all_reduce(nt)  # the global train-set size every rank normalises its loss by
-    n_train = max(int(nt), 1)
-    tr = DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev,
-                        aggregate_first=not getattr(args, "transform_first", False))
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        if dev.type == "cuda":
-            torch.cuda.synchronize()
-
-    def timed(trainer):
-        for _ in range(args.warmup):
-            trainer.step(x, y, train_local, n_train)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = trainer.step(x, y, train_local, n_train)
-        sync()
-        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        lsum = loss.detach().double().reshape(1).clone()
-        if world > 1:
-            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-            dist.all_reduce(lsum)
-        return float(dt), float(lsum)
-
-    dt, lsum = timed(tr)
-    like = None
-    if tr.net.agg_per_step < 2 * args.layers and not getattr(args, "no_comparison", False):
-        # the like-for-like figure beside it: A (X W) in every layer, exactly as GammaGL's GCNConv associates it
-        tr2 = DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev,
-                             aggregate_first=False)
-        dt2, _ = timed(tr2)
-        like = {"ms_per_step": dt2 / args.steps * 1e3, "aggregations_per_step": tr2.net.agg_per_step,
-                "value": tr2.net.agg_per_step * E * args.steps / dt2, "unit": "edges/s",
-                "note": "same model and step with every layer computing A (X W) as gcn_conv.py:79 writes it (--transform-first)"}
-        del tr2
-    n_agg = tr.net.agg_per_step     # aggregations the step actually executed (counted by the model's forward)
-    value = n_agg * E * args.steps / dt
-
-    # dominant kernel on this rank's local CSR (K = hidden), hipEvents on the launch stream
-    K = args.hidden
-    # (with a partition the bulk of a rank's edges has a remote source: time the halo-source block then)
-    use_halo = pg.gp_halo is not None and pg.gp_halo.E > pg.gp_loc.E
-    gp_t, w_t, rows_t = (pg.gp_halo, pg.w_halo, pg.n_halo) if use_halo else (pg.gp_loc, pg.w_loc, pg.n_local)
-    h = torch.randn(rows_t, K, generator=gen, device=dev)
-    ms_op = eng.time_spmm_sum(gp_t, w_t, h, reps=10)     # one K-wide aggregate = `launches` kernel launches
-    e_loc = gp_t.E
-    launches = int(eng.lib.ggl_spmm_col_blocks(e_loc, K, pg.n_local))   # 64-column blocks (reduce.hip launch_f32_cols)
-    Kl = K // launches
-    ms = max(ms_op / launches, 1e-9)  # (the host-emulated test build reports 0)
-    alg = e_loc * (4 * Kl + 8) + pg.n_local * (4 * Kl + 8)   # SURVEY §8d per launch: its Kl columns, ids and weights
-    achieved = alg / (ms * 1e-3) / 1e9
-    # HBM bytes per launch of this kernel: from the committed rocprofv3 --pmc passes of THIS workload
-    # (separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_probe.py on the same graph; gfx950 read-side x2
-    # correction applied by tools/pmc_summary.py) — reported with its source, never for another workload
-    traffic, traffic_source = None, None
-    if world == 1 and args.workload == "products" and K == 256 and args.order == "src" and args.relabel == "random" \
-            and args.seed == 0:
-        try:
-            import json
-
-            name = "r2_pmc_products_k256.json"
-            prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
-            rec = json.load(open(prof))
-            if int(rec.get("graph_edges", -1)) == E and int(rec.get("launches_per_aggregate", 1)) == launches:
-                traffic = rec["spmm_sum_k256"]["hbm_bytes_per_launch"]
-                traffic_source = "profiles/" + name + " (rocprofv3 --pmc passes of tools/pmc_probe.py on this graph, not collected in this run)"
-        except Exception:  # noqa: BLE001
-            traffic = None
-    widths = [args.hidden] * (args.layers - 1) + [n_cls + (-n_cls) % 4]
-    if n_agg < 2 * args.layers:     # layer 1 exchanges its input rows (forward only) instead of its output rows
-        widths = [f_in / 2.0] + widths[1:]
-    out = {
-        "metric": "edges aggregated/sec, 3-layer GCN hidden=256 training step, ogbn-products-sized graph",
-        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
-        "config": {
-            "workload": f"{args.workload}-sized R-MAT: N={n_nodes}, E={E} directed incl. self-loops, features "
-                        f"{f_in}->{args.hidden}x{args.layers - 1}->{n_cls}, edge order={args.order}, relabel={args.relabel}, "
-                        f"full-graph GCN train step (fwd+bwd+Adam), {n_agg} aggregations/step"
-                        + (f" (layer 1 computes (A X) W on its {f_in}-wide input: one aggregate forward, none backward — "
-                           f"the input features carry no gradient)" if n_agg < 2 * args.layers else "")
-                        + ", symmetric-norm edge weights precomputed (GCNConv norm='none' + calc_gcn_norm edge_weight)",
-            "aggregations_per_step": n_agg, "transform_first": like,
-            "parallelism": f"node-partition x{world}, 1-hop halo all-to-all-v, per-rank graph construction" if world > 1 else "1 GPU",
-            "rank0_local_edges": pg.e_local, "rank0_halo_rows": pg.n_halo, "rank0_send_rows": pg.n_send,
-            "rank0_peak_edges_during_build": stats.get("peak_edges"),
-            # rows received + sent by rank 0 per step: each aggregate moves the halo rows in (forward) or their
-            # gradients out (backward) and the mirror image for the rows other ranks need, at the layer's width
-            "rank0_halo_GB_per_step": round(2 * (pg.n_halo + pg.n_send) * 4 * sum(widths) / 1e9, 3),
-            "setup_s": round(t_gen, 2), "loss": lsum},
-        "roofline": {"bound": "hbm", "kernel": f"row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, rank 0 local rows"
-                               f"{', halo-source edges' if use_halo else ''}; the K={K} aggregate runs as {launches} "
-                               f"launch(es) over {Kl}-column blocks — the figures below are per launch)",
-                     "launches_per_aggregate": launches, "K_per_launch": Kl, "ms_per_aggregate": ms_op,
-                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": traffic, "traffic_source": traffic_source, "ms_per_launch": ms,
-                     "alg_bytes_per_launch": alg, "edges_per_s_aggregate": e_loc / (max(ms_op, 1e-9) * 1e-3)},
-    }
-    return out, pg

@@ -402,3 +402,122 @@ def rmat_partitioned(num_nodes, num_directed_edges, seed=0, rank=0, world=1, gro
     if stats is not None:
         stats.update(peak_edges=peak, rounds=rounds, local_edges=int(src.numel()), buckets=nb)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Graphs every rank can hold (products-sized and below): planted communities, locality-aware orders
+# ---------------------------------------------------------------------------------------------------
+def cut_share(src, dst, num_nodes, parts=1, rank=0, order="src", dry=False):
+    """This rank's share (same dict as `rmat_partitioned`) of a graph whose FULL directed edge list
+    (`src`, `dst`: global ids in their final labelling, no self-loops) the caller holds — the route for
+    graphs that fit one GPU (2 GB of ids at the products size), where every rank can build the whole list
+    itself and no construction-time collective is needed.  Bounds, loops, symmetric GCN norm and edge order
+    exactly as `rmat_partitioned` produces them; `dry`: also the send lists the other parts would request."""
+    dev = src.device
+    N, parts, me = int(num_nodes), int(parts), int(rank)
+    deg = torch.bincount(dst, minlength=N) + 1              # + the self-loop (add_self_loops)
+    bounds = bounds_from_degree(deg, parts)
+    lo, hi = bounds[me], bounds[me + 1]
+    mine = (dst >= lo) & (dst < hi)
+    s, d = src[mine], dst[mine]
+    key = (s * N + d) if order == "src" else (d * N + s)
+    o = torch.argsort(key)
+    s, d = s[o], d[o]
+    del key, o
+    loops = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+    s, d = torch.cat([s, loops]), torch.cat([d, loops])
+    dis = deg.to(torch.float32).pow(-0.5)
+    out = {"src": s.contiguous(), "dst": (d - lo).contiguous(), "w": (dis[s] * dis[d]).contiguous(),
+           "bounds": bounds, "deg": deg.to(torch.float32), "num_nodes": N, "rank": me, "parts": parts,
+           "e_global": int(src.numel()) + N}
+    if dry:
+        bt = torch.tensor(bounds[1:-1], device=dev, dtype=torch.int64)
+        outward = (src >= lo) & (src < hi) & ~mine
+        own = torch.searchsorted(bt, dst[outward], right=True)
+        so = src[outward]
+        out["send_rows"] = [(torch.unique(so[own == q]) - lo) if q != me else torch.empty(0, dtype=torch.int64, device=dev)
+                            for q in range(parts)]
+    return out
+
+
+def planted_pairs(num_nodes, out_deg=25, classes=64, supers=8, p_class=0.85, p_super=0.10, seed=0, device="cpu",
+                  slab=1 << 26):
+    """Directed edge list (no loops, symmetrised, de-duplicated) of a HIERARCHICAL planted-community graph in its
+    natural labelling (class c = the contiguous id range [c N / classes, (c + 1) N / classes), `classes / supers`
+    consecutive classes form a super-class): node i draws `out_deg` neighbours, each inside its class with
+    probability `p_class`, elsewhere inside its super-class with `p_super`, anywhere otherwise.  Counter-based
+    (edge j of node i is a pure function of (seed, i, j)): every rank builds the same list.  Stands in for the
+    locality a co-purchase / citation graph has and R-MAT lacks ("locality-aware partition")."""
+    dev = torch.device(device)
+    N, C, S = int(num_nodes), int(classes), int(supers)
+    t_c, t_s = int(p_class * 2**32), int((p_class + p_super) * 2**32)
+    salt1 = _s64(_mix64_int(seed * 0x9E3779B97F4A7C15 + 0xA1))
+    salt2 = _s64(_mix64_int(seed * 0x9E3779B97F4A7C15 + 0xB2))
+    keys = []
+    total = N * int(out_deg)
+    for s0 in range(0, total, slab):
+        idx = torch.arange(s0, min(s0 + slab, total), dtype=torch.int64, device=dev)
+        u = idx // int(out_deg)
+        h1, h2 = mix64(idx ^ salt1), mix64(idx ^ salt2)
+        t = _lsr(h1, 32)
+        cls = (u * C) // N
+        sup = cls // (C // S)
+        c_lo, c_hi = (cls * N + C - 1) // C, ((cls + 1) * N + C - 1) // C
+        s_lo = (sup * (C // S) * N + C - 1) // C
+        s_hi = ((sup + 1) * (C // S) * N + C - 1) // C
+        lo = torch.where(t < t_c, c_lo, torch.where(t < t_s, s_lo, torch.zeros_like(u)))
+        hi = torch.where(t < t_c, c_hi, torch.where(t < t_s, s_hi, torch.full_like(u, N)))
+        v = lo + _lsr(h2, 1) % (hi - lo).clamp(min=1)
+        ok = u != v
+        u, v = u[ok], v[ok]
+        keys.append(torch.unique(torch.minimum(u, v) * N + torch.maximum(u, v)))
+        del idx, u, v, h1, h2, t, cls, sup, lo, hi, ok
+    k = torch.unique(torch.cat(keys)) if len(keys) > 1 else keys[0]
+    a, b = k // N, k % N
+    return torch.cat([a, b]), torch.cat([b, a])
+
+
+def full_graph_partitioned(kind, num_nodes, num_directed_edges, seed=0, rank=0, world=1, device="cpu",
+                           relabel="random", order="src", parts=None, stats=None, eng=None, clusters=256):
+    """`rmat_partitioned`'s result for graphs every rank can build whole: `kind` = "rmat" (the same graph
+    `rmat_partitioned` makes — used when the requested order needs the whole graph) or "planted"
+    (`planted_pairs`, ~`num_directed_edges` edges).  `relabel`: "random" | "none" | "degree" |
+    "cluster" (`partition.cluster_order` on the randomly relabelled graph: what a user would run on a graph
+    whose ids carry no locality).  No collectives: every rank computes the same labelling."""
+    dev = torch.device(device)
+    N = int(num_nodes)
+    parts = int(parts or world)
+    me = int(rank)
+    if kind == "rmat":
+        g = rmat_partitioned(N, num_directed_edges, seed=seed, device=dev, relabel="random" if relabel == "cluster" else relabel,
+                             order="src")
+        src, dst = g["src"][:-N], g["dst"][:-N]              # (world = 1: dst is global; the loops come last)
+        del g
+    elif kind == "planted":
+        out_deg = max(2, int(num_directed_edges) // (2 * N))
+        src, dst = planted_pairs(N, out_deg=out_deg, seed=seed, device=dev)
+        if relabel != "none":
+            pi = torch.randperm(N, generator=torch.Generator().manual_seed(seed + 1)).to(dev)
+            src, dst = pi[src], pi[dst]
+    else:
+        raise ValueError(kind)
+    if relabel == "degree" and kind != "rmat":
+        deg = torch.bincount(dst, minlength=N)
+        rk = torch.empty(N, dtype=torch.int64, device=dev)
+        rk[torch.argsort(deg, descending=True, stable=True)] = torch.arange(N, device=dev)
+        src, dst = rk[src], rk[dst]
+    if relabel == "cluster":
+        from .partition import cluster_order
+
+        ei = torch.stack([src, dst]).contiguous()
+        rk, lab = cluster_order(ei, N, clusters=clusters, sweeps=20, seed=seed, eng=eng)
+        if eng is not None:
+            eng.clear_caches()
+        del ei
+        src, dst = rk[src], rk[dst]
+        if stats is not None:
+            stats["clusters"] = int(lab.max()) + 1
+    out = cut_share(src, dst, N, parts=parts, rank=me, order=order, dry=(world == 1 and parts > 1))
+    if stats is not None:
+        stats.update(peak_edges=int(src.numel()), local_edges=int(out["src"].numel()), rounds=1, buckets=1)
+    return out

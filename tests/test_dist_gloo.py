@@ -92,6 +92,35 @@ def _worker(rank, world, port, tmp):
         for p, p1 in zip(tr.net.parameters(), tr1.net.parameters()):
             torch.testing.assert_close(p.grad, p1.grad, rtol=2e-4, atol=1e-6)
             torch.testing.assert_close(p.detach(), p1.detach(), rtol=1e-4, atol=1e-6)
+        # (a) the input features' halo rows travel ONCE: [x_local ; x_halo] is cached on the identity of x, the first
+        # layer (either association) then exchanges nothing — same loss and gradients as the step that exchanges its
+        # layer-1 rows every time, and per step exactly the all-to-alls of layers 2 and 3 (forward + backward each)
+        xl, yl = x[pg.lo:pg.hi].contiguous(), y[pg.lo:pg.hi].contiguous()
+        xc = pg.with_halo(xl)
+        assert pg.with_halo(xl) is xc and tuple(xc.shape) == (pg.n_local + pg.n_halo, F)
+        torch.testing.assert_close(xc[pg.n_local:], x[pg.halo_ids])
+        agg_pre = pg.aggregate(xc, halo_included=True)
+        torch.testing.assert_close(agg_pre, pg.aggregate(xl), rtol=1e-6, atol=1e-6)
+        for af in (False, True):
+            res = {}
+            for const in (True, False):
+                t = DistGCNTrainer(pg, F, Hd, C, num_layers=3, drop_rate=0.0, seed=9, device="cpu", aggregate_first=af,
+                                   const_input_halo=const)
+                pg.profile = {}
+                ls = t.step(xl, yl, loc, n_train)
+                calls = pg.profile_summary(1)["a2a_calls"]
+                pg.profile = None
+                res[const] = (ls, [p.grad.clone() for p in t.net.parameters()], calls)
+            assert res[True][2] == 4 and res[False][2] == (5 if af else 6), (af, res[True][2], res[False][2])
+            torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-6, atol=1e-7)
+            for ga, gb in zip(res[True][1], res[False][1]):
+                torch.testing.assert_close(ga, gb, rtol=1e-4, atol=1e-6)
+        # (c) persistent exchange buffers: the second step runs on the very buffers of the first
+        t = DistGCNTrainer(pg, F, Hd, C, num_layers=3, drop_rate=0.0, seed=9, device="cpu")
+        t.step(xl, yl, loc, n_train)
+        ptrs = {k: b.data_ptr() for k, b in pg._bufs.items()}
+        t.step(xl, yl, loc, n_train)
+        assert ptrs and ptrs == {k: b.data_ptr() for k, b in pg._bufs.items()}
         open(os.path.join(tmp, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
@@ -176,14 +205,26 @@ def _bench_worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gammagl_amd.dist import run_distributed_bench
+        from gammagl_amd import benchmarks
 
+        benchmarks.WORKLOADS["t400"] = dict(kind="gcn", dataset="t400", gen="rmat", also=None)
+        benchmarks.DATASETS["t400"] = (400, 6000, 12, 5)
         args = types.SimpleNamespace(seed=0, relabel="random", order="src", hidden=16, layers=3, warmup=1,
-                                     steps=2, workload="tiny")
-        out, pg = run_distributed_bench(args, torch.device("cpu"), rank, world, 400, 6000, 10, 5, eng=_emul_engine())
+                                     steps=2, workload="t400")
+        out, ctx = benchmarks.run_gcn(args, torch.device("cpu"), rank, world, eng=_emul_engine())
+        pg = ctx["pg"]
         assert out["n_gpus"] == world and out["value"] > 0 and out["scaling"] == "strong"
         assert out["rccl_ranks"] == world and pg.e_global == 6400
-        assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+        # the headline is the reference's association: 2 aggregations per layer; the cheaper one is the side figure
+        assert out["config"]["aggregations_per_step"] == 6 and out["config"]["aggregate_first"]["aggregations_per_step"] == 5
+        # what the step puts on the wire, per step: layers 2 and 3 only (the input features' halo rows travel once)
+        ex = out["config"]["exchange"]
+        assert ex["a2a_calls"] == 4 and ex["halo_exposed_ms"] >= 0 and len(ex["a2a_isolated"]) == 2
+        assert abs(ex["a2a_GB_in"] * 1e9 - (pg.n_halo + pg.n_send) * 4 * (16 + 8)) < 1e-3
+        assert out["config"]["halo_floats_per_row_per_step"] == 2 * (16 + 8)
+        rf = benchmarks.roofline_block("k", 4, 2.0, 10e9, 1e9, 1000, traffic_per_launch=1.5e9, traffic_source="t")
+        assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "eff_GBps", "compulsory_bytes"}
+        assert rf["frac"] <= 1.0 and abs(rf["achieved"] - 3000.0) < 1e-6 and rf["traffic_over_compulsory"] == 6.0
         json.dumps(out)
         open(os.path.join(tmp, f"ok{rank}"), "w").close()
     finally:
@@ -358,6 +399,18 @@ def test_per_rank_graph_construction_and_fused_halo_epilogue(world, tmp_path):
              for r in range(world)]
     assert [p.wait(timeout=600) for p in procs] == [0] * world
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_rank_share_checks_at_toy_size():
+    """The body of the -m gpu config-5 test (tests/share_checks.py) on a toy graph with the host-emulated kernels:
+    rank 3 of an 8-way dry partition built piecewise (3 hash buckets), halo / send-list identities, the aggregate
+    against f64 checksums and row evaluations, the adjoint identity through the reverse exchange."""
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    sys.path.insert(0, HERE)
+    from share_checks import check_rank_share
+
+    check_rank_share(_emul_engine(), torch.device("cpu"), 3000, 60000, P=8, r=3, min_buckets=3, buckets=3)
+    check_rank_share(_emul_engine(), torch.device("cpu"), 2000, 30000, P=4, r=0)
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
