@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SegPlanC(ctypes.Structure):
@@ -69,6 +69,8 @@ SIGNATURES = {
     "ggl_spmm_max_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
     "ggl_bspmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, _V]),
     "ggl_bspmm_grad_w": (c_int, [_V, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
+    "ggl_bspmm_grad_w_sorted_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),
+    "ggl_bspmm_grad_w_sorted": (c_int, [_P, _V, _V, _V, _V, c_int64, c_int64, _V, _V, _V]),
     "ggl_colsum_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_colsum_f32": (c_int, [_V, c_int64, c_int64, _V, _V, c_size_t, _V]),
     "ggl_bias_act_fwd": (c_int, [_V, _V, c_int64, c_int64, c_int, c_float, _V, _V, _V]),

@@ -150,7 +150,7 @@ def _exchange_report(pg, trainer, data, args, dev, world, widths):
              "GBps_per_link_fwd": gb_in / max(ms["fwd"], 1e-9) * 1e3 / max(P - 1, 1)}
         iso.append(e)
         iso_total += per_step * (ms["fwd"] + ms["bwd"]) / 2
-    for key in [k_ for k_ in pg._bufs if isinstance(k_[0], tuple) and k_[0][0] == "probe"]:
+    for key in [k_ for k_ in pg._bufs if k_[0] == "probe"]:
         del pg._bufs[key]
     rep["a2a_isolated"] = iso
     rep["a2a_isolated_ms_per_step"] = iso_total

@@ -1,0 +1,180 @@
+// gammagl_amd/csrc/edgedot.hip — bspmm's weight gradient on the destination-sorted plan:
+//   ggl_bspmm_grad_w_sorted : gw[e,h] = sum_c x[src_e,h,c] * g[dst_e,h,c]   (cpu/bspmm_sum_cpu.cpp:95-107)
+//
+// The reference sums over c serially (rounded multiply, rounded add, c ascending) and the golden weight gradients pin
+// that order bit for bit, so the dot of an (edge, head) item is one dependent chain: it has to live in ONE lane.  The
+// thread-per-item kernel of backward.hip does exactly that and reads its two strips 16 bytes at a time — a wavefront
+// then touches 64 different rows per load, C/4 times over, which thrashes the 32 KiB L1 of a CU for C > 16 (every
+// 128-byte line is fetched up to 8 times from L2): products-sized graph, H = 1, C = 256: 69 ms where the forward
+// SpMM — the same gather volume — takes 16.4 ms.
+//
+// Here the loads are coalesced and the transposition happens in LDS: a workgroup owns 256 consecutive items of the
+// DESTINATION-SORTED order (so the g strips of a batch are a handful of rows, L1/L2 hits; only x[src] is a random
+// gather, exactly as in the forward walk), stages 32-column slabs of the items' x and g strips into two LDS tiles with
+// 16-byte loads in which 8 consecutive lanes cover 128 contiguous bytes, and then every lane folds ITS item's 32
+// products in order from LDS (row stride 36 floats: the 16-byte reads of a 16-lane pass fall into distinct banks).
+// Results go to gw[perm[p], h], the caller's edge order.  A launch may cover a column range [c_lo, c_hi) only,
+// taking the chain so far from `carry_in` and leaving it in `carry_out` (both in SORTED order: coalesced): the host
+// runs wide heads as launches over 64-column blocks like the forward (launch_f32_cols, reduce.hip) — same serial
+// order, and the 256-byte slices keep 4x as many hub rows in L2; only the last block scatters through perm.
+#include "common.hpp"
+
+namespace ggl {
+
+constexpr int kDotQ = 8;                 // float4s per strip per slab: 32 columns
+constexpr int kDotLd = kDotQ * 4 + 4;    // tile row stride in floats (36: conflict-free 16-byte reads)
+
+#ifndef GGL_EMULATE
+__global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
+    const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const int32_t *__restrict__ perm,
+    const float *__restrict__ x, const float *__restrict__ g, int64_t total, int64_t H, int64_t C, int64_t c_lo,
+    int64_t c_hi, const float *__restrict__ carry_in, float *__restrict__ carry_out, float *__restrict__ gw) {
+  __shared__ __attribute__((aligned(16))) float tx[kBlock][kDotLd];
+  __shared__ __attribute__((aligned(16))) float tg[kBlock][kDotLd];
+  __shared__ int64_t sx[kBlock], sg[kBlock];
+  const int tid = threadIdx.x;
+  const int64_t base = block_id() * (int64_t)kBlock;
+  if (base >= total) return;
+  const int64_t i = base + tid;
+  const bool valid = i < total;
+  int64_t p = 0, h = 0;
+  if (valid) {
+    p = i / H;
+    h = i - p * H;
+  }
+  sx[tid] = valid ? ((int64_t)col[p] * H + h) * C : (int64_t)-1;
+  sg[tid] = valid ? ((int64_t)rowidx[p] * H + h) * C : (int64_t)-1;
+  float acc = (valid && carry_in) ? carry_in[i] : 0.0f;   // the chain so far (sorted order: coalesced)
+  __syncthreads();
+  for (int64_t c0 = c_lo; c0 < c_hi; c0 += kDotQ * 4) {
+    const int nq = (int)((c_hi - c0) >= kDotQ * 4 ? kDotQ : (c_hi - c0) >> 2);
+    float4 vx[kDotQ], vg[kDotQ];
+    const float4 zero{0.f, 0.f, 0.f, 0.f};
+    if (nq == kDotQ) {
+#pragma unroll
+      for (int j = 0; j < kDotQ; ++j) {
+        const int f = tid + kBlock * j, item = f >> 3, part = f & 7;
+        const int64_t ox = sx[item], og = sg[item];
+        vx[j] = ox >= 0 ? *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4) : zero;
+        vg[j] = og >= 0 ? *reinterpret_cast<const float4 *>(g + og + c0 + part * 4) : zero;
+      }
+#pragma unroll
+      for (int j = 0; j < kDotQ; ++j) {
+        const int f = tid + kBlock * j, item = f >> 3, part = f & 7;
+        *reinterpret_cast<float4 *>(&tx[item][part * 4]) = vx[j];
+        *reinterpret_cast<float4 *>(&tg[item][part * 4]) = vg[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kDotQ; ++j) {
+        if (j < nq) {
+          const int f = tid + kBlock * j, item = f / nq, part = f - item * nq;
+          const int64_t ox = sx[item], og = sg[item];
+          vx[j] = ox >= 0 ? *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4) : zero;
+          vg[j] = og >= 0 ? *reinterpret_cast<const float4 *>(g + og + c0 + part * 4) : zero;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kDotQ; ++j) {
+        if (j < nq) {
+          const int f = tid + kBlock * j, item = f / nq, part = f - item * nq;
+          *reinterpret_cast<float4 *>(&tx[item][part * 4]) = vx[j];
+          *reinterpret_cast<float4 *>(&tg[item][part * 4]) = vg[j];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kDotQ; ++k) {
+      if (k < nq) {
+        const float4 a = *reinterpret_cast<const float4 *>(&tx[tid][k * 4]);
+        const float4 b = *reinterpret_cast<const float4 *>(&tg[tid][k * 4]);
+        acc = __fadd_rn(acc, __fmul_rn(a.x, b.x));
+        acc = __fadd_rn(acc, __fmul_rn(a.y, b.y));
+        acc = __fadd_rn(acc, __fmul_rn(a.z, b.z));
+        acc = __fadd_rn(acc, __fmul_rn(a.w, b.w));
+      }
+    }
+    __syncthreads();
+  }
+  if (!valid) return;
+  if (carry_out) carry_out[i] = acc;
+  else gw[(perm ? (int64_t)perm[p] : p) * H + h] = acc;
+}
+#endif
+
+// the same walk one item per thread, strips read in place: the host-emulation build's stand-in (its "threads" run one
+// after another: no LDS, no barriers) and the route for strips that are not made of aligned float4s
+__global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_plain_kernel(
+    const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const int32_t *__restrict__ perm,
+    const float *__restrict__ x, const float *__restrict__ g, int64_t total, int64_t H, int64_t C,
+    float *__restrict__ gw) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < total; i += stride) {
+    const int64_t p = i / H, h = i - p * H;
+    const float *xr = x + ((int64_t)col[p] * H + h) * C;
+    const float *gr = g + ((int64_t)rowidx[p] * H + h) * C;
+    const int64_t oi = (perm ? (int64_t)perm[p] : p) * H + h;
+    float acc = 0.0f;
+    for (int64_t c = 0; c < C; ++c) acc = __fadd_rn(acc, __fmul_rn(xr[c], gr[c]));
+    gw[oi] = acc;
+  }
+}
+
+}  // namespace ggl
+
+using namespace ggl;
+
+// gw[e, h] for the edges of `plan` (destination-sorted; plan->perm maps sorted positions back to the caller's edge
+// order, NULL = already sorted), `col` / `rowidx` = source / destination node of every sorted position.
+static int64_t dot_block_width(int64_t E, int64_t N, int64_t C) {   // C = one launch
+#ifdef GGL_EMULATE
+  (void)E; (void)N;
+  return C;
+#else
+  if (options().col_block > 0 && C % 4 == 0 && C >= 2 * options().col_block && N > 0 &&
+      E >= options().col_block_min_degree * N && E >= options().col_block_min_edges)
+    return options().col_block;
+  return C;
+#endif
+}
+
+// bytes of `scratch` the call below wants (0: it runs as one launch and needs none)
+extern "C" size_t ggl_bspmm_grad_w_sorted_scratch_bytes(int64_t E, int64_t N, int64_t H, int64_t C) {
+  return dot_block_width(E, N, C) < C ? (size_t)E * (size_t)H * sizeof(float) : 0;
+}
+
+extern "C" int ggl_bspmm_grad_w_sorted(const ggl_segplan_t *plan, const int32_t *col, const int32_t *rowidx,
+                                       const float *x, const float *g, int64_t H, int64_t C, float *gw,
+                                       float *scratch, void *stream) {
+  GGL_REQUIRE(plan != nullptr && H > 0 && C > 0 && plan->E >= 0, GGL_EINVAL, "bad sizes");
+  const int64_t E = plan->E;
+  if (E == 0) return GGL_OK;
+  GGL_REQUIRE(col && rowidx && x && g && gw, GGL_EINVAL, "NULL pointer");
+  const int64_t total = E * H;
+  hipStream_t s = as_stream(stream);
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15u) == 0 &&
+                   !options().force_generic;
+#ifndef GGL_EMULATE
+  if (vec) {
+    // wide strips in 64-column blocks (see the header): only where there are hub rows to keep in L2
+    const int64_t bw = scratch ? dot_block_width(E, plan->N, C) : C;
+    for (int64_t c0 = 0; c0 < C; c0 += bw) {
+      const int64_t c1 = (c0 + bw < C) ? c0 + bw : C;
+      const float *cin = c0 > 0 ? scratch : nullptr;
+      float *cout = c1 < C ? scratch : nullptr;
+      GGL_LAUNCH((bspmm_grad_w_sorted_kernel), ceil_div(total, (int64_t)kBlock), kBlock, s, col, rowidx, plan->perm, x,
+                 g, total, H, C, c0, c1, cin, cout, gw);
+      GGL_LAUNCH_CHECK();
+    }
+    return GGL_OK;
+  }
+#endif
+  (void)vec;
+  int64_t grid = ceil_div(total, (int64_t)kBlock);
+  if (grid > 4096) grid = 4096;
+  (void)scratch;
+  GGL_LAUNCH((bspmm_grad_w_sorted_plain_kernel), grid, kBlock, s, col, rowidx, plan->perm, x, g, total, H, C, gw);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}

@@ -146,17 +146,21 @@ class PartitionedGraph:
 
     # ---- persistent buffers / constants / instrumentation ----------------------------------------
     def _buf(self, tag, rows, cols, dtype, device):
-        """One buffer per (direction, chunk, shape), allocated on first use and reused by every later step:
-        the exchange then runs on fixed addresses (no allocator traffic per chunk per call; a precondition for
-        recording the step into a hipGraph).  Reuse is safe in stream order: a buffer's consumer (the halo
-        SpMM / the segment-sum of returned rows) is enqueued before the next collective that overwrites it is
-        issued, and the process group makes its stream wait for the issuing stream."""
-        key = (tag, int(rows), int(cols), dtype)
-        b = self._bufs.get(key)
-        if b is None or b.device != device:
-            b = torch.empty((int(rows), int(cols)), dtype=dtype, device=device)
-            self._bufs[key] = b
-        return b
+        """One flat buffer per `tag`, grown to the largest request and handed out as a [rows, cols] view: allocated on
+        first use and reused by every later step, so the exchange runs on fixed addresses (no allocator traffic per
+        chunk per call; a precondition for recording the step into a hipGraph).  Tags are shared where lifetimes
+        cannot overlap — ("halo", chunk) serves the forward receive buffer and the backward's outgoing halo
+        gradients, ("send", chunk) the forward send rows and the returned gradients, layers of every width — which
+        keeps the pool at 2 x (halo + send rows) x the widest layer (a papers100M-sized share: 2 x 24 GB).
+        Reuse is safe in stream order: a buffer's consumer (the halo SpMM / the segment-sum of returned rows) is
+        enqueued before the next collective that overwrites it is issued, and the process group makes its stream
+        wait for the issuing stream."""
+        need = int(rows) * int(cols)
+        b = self._bufs.get(tag)
+        if b is None or b.device != device or b.dtype != dtype or b.numel() < need:
+            b = torch.empty(max(need, 1), dtype=dtype, device=device)
+            self._bufs[tag] = b
+        return b[:need].view(int(rows), int(cols))
 
     def with_halo(self, x):
         """[x_local ; x_halo] for a tensor of local rows that NEVER changes (the input features): the halo rows are
@@ -271,10 +275,10 @@ class _HaloAggregate(torch.autograd.Function):
             works.append((0, K, h[pg.n_local:], _Done()))
         elif pg.comm:
             for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
-                send = pg._buf(("fs", ci), pg.n_send, c1 - c0, h.dtype, dev)
+                send = pg._buf(("send", ci), pg.n_send, c1 - c0, h.dtype, dev)
                 if pg.n_send > 0:  # one kernel: rows of the column block straight into the send buffer
                     eng.gather_rows_into(h[:, c0:c1], pg.send_idx, send)
-                recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits, tag=("fr", ci))
+                recv, work = pg._a2a(pg.n_halo, send, pg.recv_splits, pg.send_splits, tag=("halo", ci))
                 works.append((c0, c1, recv, work))
         out = torch.empty((pg.n_local, K), dtype=torch.float32, device=dev)
         last_is_local = fused and (not pg.comm or pg.n_halo == 0)
@@ -343,10 +347,10 @@ class _HaloAggregate(torch.autograd.Function):
         works = []
         if pg.comm:
             for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
-                ghalo = pg._buf(("bs", ci), pg.n_halo, c1 - c0, g.dtype, dev)
+                ghalo = pg._buf(("halo", ci), pg.n_halo, c1 - c0, g.dtype, dev)
                 if pg.n_halo > 0:  # reads the column block of g in place (row stride passed down)
                     eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g[:, c0:c1], ghalo)
-                gsend, work = pg._a2a(pg.n_send, ghalo, pg.send_splits, pg.recv_splits, tag=("br", ci))  # chunk c travels while c+1 computes
+                gsend, work = pg._a2a(pg.n_send, ghalo, pg.send_splits, pg.recv_splits, tag=("send", ci))  # chunk c travels while c+1 computes
                 works.append((c0, c1, gsend, work))
         gh, _ = eng._spmm_fwd("sum", pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, pg.n_local)  # overlaps
         for (c0, c1, gsend, work) in works:

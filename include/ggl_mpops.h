@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define GGL_ABI_VERSION 4
+/* 5 (round 3): + ggl_bspmm_grad_w_sorted[_scratch_bytes]; v4's number had not been raised for the symbols added
+ * late in round 2 (ggl_sample_hop, ggl_block_transpose, ggl_gat_sh_*, ggl_segment_hub16*, ggl_spmm_col_blocks) */
+#define GGL_ABI_VERSION 5
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
 enum {
@@ -234,6 +236,14 @@ int ggl_bspmm_sum(const ggl_segplan_t *plan, const int32_t *col, const float *w,
                   const float *x, int64_t H, int64_t C, float *out, void *stream);
 int ggl_bspmm_grad_w(const int64_t *index /* [2,E] int64 */, const float *x, const float *g,
                      int64_t E, int64_t H, int64_t C, float *gw, void *stream);
+/* The same weight gradient (bspmm_sum_cpu.cpp:95-107: serial over c, rounded multiply then rounded add — bit for
+ * bit) computed along the destination-sorted FORWARD plan: col[p] / rowidx[p] = source / destination node of sorted
+ * position p, the result goes to gw[perm[p], h] (the caller's edge order).  Strips are staged through LDS with
+ * coalesced 16-byte loads (csrc/edgedot.hip); `scratch` = ggl_bspmm_grad_w_sorted_scratch_bytes(...) bytes (0 -> may be
+ * NULL): wide heads then run as launches over 64-column blocks that carry the running dot in it. */
+size_t ggl_bspmm_grad_w_sorted_scratch_bytes(int64_t E, int64_t N, int64_t H, int64_t C);
+int ggl_bspmm_grad_w_sorted(const ggl_segplan_t *plan, const int32_t *col, const int32_t *rowidx, const float *x,
+                            const float *g, int64_t H, int64_t C, float *gw, float *scratch, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Column sums of a row-major [N,K] f32 matrix: out[k] = sum_r g[r,k] — the gradient of the

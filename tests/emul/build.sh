@@ -9,4 +9,4 @@ SRC=../../gammagl_amd/csrc
 OUT=libggl_emul.so
 if [ -f $OUT ] && [ -z "$(find $SRC emul_shim.hpp gat_fast_stub.cpp ../../include -newer $OUT -type f)" ]; then exit 0; fi
 $CXX -DGGL_EMULATE -x c++ -std=c++17 -O1 -fPIC -shared -ffp-contract=off -Wno-unused-function \
-  $SRC/plan.hip $SRC/reduce.hip $SRC/backward.hip $SRC/gat.hip $SRC/epilogue.hip $SRC/sample.hip gat_fast_stub.cpp -o $OUT
+  $SRC/plan.hip $SRC/reduce.hip $SRC/backward.hip $SRC/edgedot.hip $SRC/gat.hip $SRC/epilogue.hip $SRC/sample.hip gat_fast_stub.cpp -o $OUT

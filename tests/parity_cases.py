@@ -936,6 +936,56 @@ def check_bspmm_wide(eng, dev):
         torch.testing.assert_close(w.grad, wr.grad, rtol=1e-5, atol=1e-5)
 
 
+def check_bspmm_gradw_sorted(eng, dev, oracle):
+    """bspmm's weight gradient along the destination-sorted plan (edgedot.hip: strips staged through LDS on the GPU;
+    the plain walk in the host-emulation build): bit for bit the oracle's serial-over-c sums, for heads of 20 ... 300
+    channels, with and without the 64-column-block launches that carry the running dot in a scratch buffer, and equal
+    to the thread-per-item kernel it replaces.  Graphs with empty rows, duplicate edges and a hub."""
+    import numpy as np
+
+    rng = np.random.default_rng(21)
+    names = (b"col_block_min_edges", b"col_block_min_degree")
+    old = [eng.lib.ggl_get_option(n) for n in names]
+    try:
+        for blocks in (False, True):
+            if blocks:        # force the column-block launches on these toy graphs
+                eng.set_option("col_block_min_edges", 0)
+                eng.set_option("col_block_min_degree", 0)
+            for (N, E, H, C) in ((50, 3000, 1, 256), (40, 900, 8, 44), (33, 700, 2, 136), (21, 500, 3, 20),
+                                 (64, 1500, 1, 300), (30, 257, 4, 32), (9, 1, 1, 64)):
+                src = rng.integers(0, N, E)
+                dst = rng.integers(0, max(N - 5, 1), E)              # the last rows stay empty
+                dst[: E // 3] = 2                                      # a hub row
+                index = np.stack([src, dst]).astype(np.int64)
+                w = rng.standard_normal((E, H)).astype(np.float32)
+                x = rng.standard_normal((N, H, C)).astype(np.float32)
+                go = rng.standard_normal((N, H, C)).astype(np.float32)
+                ogx, ogw = oracle.bspmm_sum_bwd(index, w, x, go)
+                got = {}
+                for sorted_walk in (True, False):
+                    eng.gradw_sorted = sorted_walk
+                    wt = to_t(w, dev).requires_grad_(True)
+                    xt = to_t(x, dev).requires_grad_(True)
+                    eng.c_bspmm_sum(to_t(index, dev), wt, xt).backward(to_t(go, dev))
+                    got[sorted_walk] = to_np(wt.grad)
+                    assert_same(to_np(xt.grad), ogx, f"bspmm gx H{H} C{C}")
+                assert_same(got[True], ogw, f"bspmm gw (sorted walk, blocks={blocks}) H{H} C{C}")
+                assert_same(got[False], ogw, f"bspmm gw (edge order) H{H} C{C}")
+    finally:
+        eng.gradw_sorted = True
+        for n, v in zip(names, old):
+            eng.set_option(n.decode(), v)
+    # a plan built from CSR + CSC (no edge_index): rowidx comes from the row pointer
+    N, H, C = 12, 2, 24
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, N, (2, 90), generator=g)
+    o = torch.argsort(ei[1] * N + ei[0], stable=True)
+    ei = ei[:, o].contiguous().to(dev)
+    gp = eng.graph_plan(ei, N)
+    gp2 = eng.graph_plan_from_csr(gp.fwd.rowptr.clone(), gp.col.clone(), gp.bwd.rowptr.clone(), gp.colT.clone(), gp.posT.clone())
+    assert torch.equal(gp2.rowidx.long(), ei[1])
+
+
 def check_plan_cache(eng, dev):
     eng.seg_cache.clear()
     ids = torch.tensor([2, 0, 1, 0, 2, 2], device=dev)

@@ -215,7 +215,7 @@ def test_one_rank_share_of_an_8_way_partition(eng, dev):
         def wait(self):
             return True
 
-    def fill(out_rows, inp, out_splits, in_splits):                     # what the 7 peers would have sent
+    def fill(out_rows, inp, out_splits, in_splits, tag=None):           # what the 7 peers would have sent
         assert out_rows == pg.n_halo and inp.shape[0] == pg.n_send
         return h[pg.halo_ids].contiguous(), _Filled()
 

@@ -110,6 +110,10 @@ def test_bspmm_wide_heads(eng, dev):
     pc.check_bspmm_wide(eng, dev)
 
 
+def test_bspmm_weight_gradient_on_the_sorted_plan(eng, dev, oracle):
+    pc.check_bspmm_gradw_sorted(eng, dev, oracle)
+
+
 def test_strided_and_accumulating_forms(eng, dev, oracle):
     pc.check_strided_accumulate(eng, dev, oracle)
 
