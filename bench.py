@@ -192,7 +192,7 @@ def cpu_baseline_gat(ctx, seed):
     layer (gather, LeakyReLU, c_segment_max, exp, c_segment_sum, divide, gather * alpha, c_segment_sum) for the 8 x 8
     head shape, on every 32nd edge of the benchmark graph (its own node set), 1 core."""
     ref, kind, orc = _ref_or_port()
-    ei, n = ctx["ei"].cpu(), ctx["n"]
+    ei, n = ctx["ei"], ctx["n"]
     cores = os.cpu_count() or 1
     torch.set_num_threads(1)
     stride = 32
@@ -422,6 +422,35 @@ def main():
         assert dist.get_world_size() == args.gpus
     if rank == 0:
         rf = out.get("roofline")
+        # what the CPU leg needs goes to the host first, then the GPU is emptied: the --pmc child processes rebuild the
+        # graph on the same device (a papers100M-sized share peaks at 93 GB while it is built)
+        cpu_args = None
+        if want_cpu:
+            if kind == "gcn":
+                full = None
+                if args.workload != "tiny":
+                    if ctx.get("host_graph") is not None:
+                        ei, w = ctx["host_graph"]
+                    else:
+                        pg = ctx["pg"]    # N = 1: rank 0 holds the whole graph (a dry share: its local-source block)
+                        ei, w = torch.stack([pg.ei_loc[0], pg.ei_loc[1]]).cpu().contiguous(), pg.w_loc.cpu()
+                        del pg
+                    full = (ei, w, int(out["config"].get("rank0_owned_rows", 0)))
+                cpu_args = (args.hidden, sizes_of(args.workload)[3], args.seed, full)
+            elif kind == "gat":
+                cpu_args = ({"ei": ctx["ei"].cpu(), "n": ctx["n"]}, args.seed)
+            else:
+                cpu_args = ({"blocks": [type("B", (), {"n_dst_cap": int(b.n_dst_cap)})() for b in ctx["blocks"]],
+                             "valid": ctx["valid"]}, args.hidden, args.seed)
+        ctx.clear()
+        if not emul:
+            from gammagl_amd import engine as _eng
+
+            _eng().clear_caches()
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
         if rf and world == 1 and not emul and kind in KERNEL_OF:
             t = src = None
             extra = {}
@@ -442,24 +471,8 @@ def main():
                 also[0]["traffic_per_aggregate"] = None if t2 is None else t2 * int(rf["launches_per_aggregate"])
                 also[0]["traffic_source"] = src2
                 also[0].update(extra2)
-        if want_cpu:
-            if kind == "gcn":
-                n_nodes = int(out["config"].get("rank0_owned_rows", 0))
-                full = None
-                if args.workload != "tiny":
-                    if ctx.get("host_graph") is not None:
-                        ei, w = ctx["host_graph"]
-                    else:
-                        pg = ctx["pg"]    # N = 1: rank 0 holds the whole graph (a dry share: its local-source block)
-                        ei, w = torch.stack([pg.ei_loc[0], pg.ei_loc[1]]).cpu().contiguous(), pg.w_loc.cpu()
-                    full = (ei, w, n_nodes)
-                n_cls = sizes_of(args.workload)[3]
-                ctx.clear()
-                out["cpu_baseline"] = cpu_baseline_gcn(args.hidden, n_cls, args.seed, full)
-            elif kind == "gat":
-                out["cpu_baseline"] = cpu_baseline_gat(ctx, args.seed)
-            else:
-                out["cpu_baseline"] = cpu_baseline_sage(ctx, args.hidden, args.seed)
+        if cpu_args is not None:
+            out["cpu_baseline"] = {"gcn": cpu_baseline_gcn, "gat": cpu_baseline_gat, "sage": cpu_baseline_sage}[kind](*cpu_args)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

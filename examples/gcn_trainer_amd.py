@@ -8,6 +8,10 @@ without --data it trains on a seeded Cora-sized homophilous synthetic graph (lab
 features + neighbourhood); --data points at an .npz with x, y, edge_index, train_idx, val_idx, test_idx.
 
     python examples/gcn_trainer_amd.py --n_epoch 50 --hidden_dim 16
+    python examples/gcn_trainer_amd.py --gpu -1 --n_epoch 20       # BASELINE config 1: TL_BACKEND=torch on the CPU
+
+With --gpu -1 (gcn_trainer.py's own flag for "no GPU") every tensor stays on the host and the same ops dispatch to the
+host build of the kernel sources (CPU dispatch key, libggl_mpops_host.so) — the plumbing configuration of BASELINE.json.
 """
 import argparse
 import os
@@ -47,7 +51,7 @@ def main():
     p.add_argument("--data", type=str, default="")
     p.add_argument("--gpu", type=int, default=0)
     args = p.parse_args()
-    dev = torch.device("cuda", args.gpu)
+    dev = torch.device("cuda", args.gpu) if args.gpu >= 0 else torch.device("cpu")
     x, y, edge_index, train_idx, val_idx, test_idx = load(args, dev)
     n = x.shape[0]
     edge_index = add_self_loops(edge_index, n)                       # gcn_trainer.py:58

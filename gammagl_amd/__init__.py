@@ -7,20 +7,39 @@ hand-written HIP for gfx950 behind the reference's own Python op surface.
     from gammagl_amd import mpops          # drop-in for gammagl/mpops/torch.py
     from gammagl_amd import engine         # plans, explicit-plan ops, fused GAT
 
-There is no CPU path: the HIP library must be built (``make -C gammagl_amd/csrc``) and tensors must
-live on the GPU.
+GPU tensors run on ``lib/libggl_mpops_hip.so`` and on nothing else: if it is missing the import of the ops
+fails loudly.  CPU tensors — the reference's ops dispatch on ``x.is_cpu()`` too (src/segment_sum.cpp:19-33;
+BASELINE config 1 is ``--gpu -1``) — run on ``lib/libggl_mpops_host.so``, the host build of the same kernel
+sources (csrc/host/host_shim.hpp).  A tensor is never moved between devices behind the caller's back.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
-_engine = None
+_engine = None        # the MI355X engine (tests may inject an Engine built on another library here)
+_host_engine = None   # the CPU backend (host build of the kernel sources), created on first CPU call
 
 
-def engine():
-    """Process-wide Engine bound to libggl_mpops_hip.so (raises ImportError if it is not built)."""
+def engine(like=None):
+    """The Engine for `like` (a tensor, a device, or None = the MI355X engine): GPU tensors -> the engine bound to
+    libggl_mpops_hip.so (ImportError if it is not built), CPU tensors -> the host build."""
     global _engine
+    if like is not None:
+        dev = getattr(like, "device", like)
+        if str(dev).startswith("cpu") and not (_engine is not None and not _engine.require_cuda):
+            return host_engine()
     if _engine is None:
         from . import _lib
         from .ops import Engine
 
         _engine = Engine(_lib.hip_lib(), require_cuda=True)
     return _engine
+
+
+def host_engine():
+    """Process-wide Engine bound to libggl_mpops_host.so: CPU tensors only."""
+    global _host_engine
+    if _host_engine is None:
+        from . import _lib
+        from .ops import Engine
+
+        _host_engine = Engine(_lib.host_lib(), require_cuda=False, cpu_only=True)
+    return _host_engine

@@ -1,8 +1,10 @@
 """ctypes binding of include/ggl_mpops.h.
 
-The product loads exactly one library: ``gammagl_amd/lib/libggl_mpops_hip.so`` (hand-written HIP for
+GPU tensors are served by exactly one library: ``gammagl_amd/lib/libggl_mpops_hip.so`` (hand-written HIP for
 gfx950, built in-tree by ``gammagl_amd/csrc/Makefile``).  If it is missing or does not load, importing
-the ops fails loudly — there is no CPU or pure-PyTorch fallback anywhere in this package.
+the ops fails loudly — nothing in this package computes a GPU tensor's result anywhere else.  CPU tensors (the
+reference dispatches on ``x.is_cpu()`` as well) are served by ``libggl_mpops_host.so``, the host build of the
+same kernel sources; it is loaded on the first CPU call only.
 """
 import ctypes
 import os
@@ -10,6 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_host.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
 ABI_VERSION = 5
@@ -133,3 +136,16 @@ def hip_lib():
                 "CPU / PyTorch fallback.")
         _hip = bind(HIP_LIB_PATH)
     return _hip
+
+
+_host = None
+
+
+def host_lib():
+    """The host build of the kernel sources (singleton): the CPU dispatch key's library."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} not found: build it with `make -C gammagl_amd/csrc host`")
+        _host = bind(HOST_LIB_PATH)
+    return _host

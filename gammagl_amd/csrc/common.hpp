@@ -1,9 +1,9 @@
 // gammagl_amd/csrc/common.hpp — shared host/device helpers for libggl_mpops_hip.so (gfx950 only).
 #pragma once
 #ifdef GGL_EMULATE
-// Host build of the SAME kernel sources, one "thread" at a time (tests/emul/).  Test
-// infrastructure for the GPU-less container: never built into, nor loaded by, the product.
-#include "../../tests/emul/emul_shim.hpp"
+// Host build of the SAME kernel sources, one "thread" at a time (csrc/host/host_shim.hpp): the CPU backend of the
+// ops (libggl_mpops_host.so, CPU dispatch key) and the engine of the GPU-less container's kernel-logic tests.
+#include "host/host_shim.hpp"
 #else
 #include <hip/hip_runtime.h>
 #endif

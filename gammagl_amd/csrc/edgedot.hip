@@ -25,6 +25,45 @@ constexpr int kDotQ = 8;                 // float4s per strip per slab: 32 colum
 constexpr int kDotLd = kDotQ * 4 + 4;    // tile row stride in floats (36: conflict-free 16-byte reads)
 
 #ifndef GGL_EMULATE
+// one slab of NQ float4s per strip: stage the 256 items' x and g pieces (all 2 * NQ loads of a thread in flight
+// together, registers only: NQ is a compile-time constant so nothing is indexed at run time), then fold this lane's own
+// item in channel order
+template <int NQ>
+__device__ __forceinline__ float dot_slab(int tid, const int64_t *sx, const int64_t *sg, const float *__restrict__ x,
+                                          const float *__restrict__ g, int64_t c0, float (*tx)[kDotLd],
+                                          float (*tg)[kDotLd], float acc) {
+  float4 vx[NQ], vg[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;
+    const int64_t ox = sx[item], og = sg[item];
+    vx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    vg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ox >= 0) {   // (an item past the end of the list: only in the last workgroup)
+      vx[j] = *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4);
+      vg[j] = *reinterpret_cast<const float4 *>(g + og + c0 + part * 4);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;
+    *reinterpret_cast<float4 *>(&tx[item][part * 4]) = vx[j];
+    *reinterpret_cast<float4 *>(&tg[item][part * 4]) = vg[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const float4 a = *reinterpret_cast<const float4 *>(&tx[tid][k * 4]);
+    const float4 b = *reinterpret_cast<const float4 *>(&tg[tid][k * 4]);
+    acc = __fadd_rn(acc, __fmul_rn(a.x, b.x));
+    acc = __fadd_rn(acc, __fmul_rn(a.y, b.y));
+    acc = __fadd_rn(acc, __fmul_rn(a.z, b.z));
+    acc = __fadd_rn(acc, __fmul_rn(a.w, b.w));
+  }
+  __syncthreads();
+  return acc;
+}
+
 __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
     const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const int32_t *__restrict__ perm,
     const float *__restrict__ x, const float *__restrict__ g, int64_t total, int64_t H, int64_t C, int64_t c_lo,
@@ -46,56 +85,17 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
   sg[tid] = valid ? ((int64_t)rowidx[p] * H + h) * C : (int64_t)-1;
   float acc = (valid && carry_in) ? carry_in[i] : 0.0f;   // the chain so far (sorted order: coalesced)
   __syncthreads();
-  for (int64_t c0 = c_lo; c0 < c_hi; c0 += kDotQ * 4) {
-    const int nq = (int)((c_hi - c0) >= kDotQ * 4 ? kDotQ : (c_hi - c0) >> 2);
-    float4 vx[kDotQ], vg[kDotQ];
-    const float4 zero{0.f, 0.f, 0.f, 0.f};
-    if (nq == kDotQ) {
-#pragma unroll
-      for (int j = 0; j < kDotQ; ++j) {
-        const int f = tid + kBlock * j, item = f >> 3, part = f & 7;
-        const int64_t ox = sx[item], og = sg[item];
-        vx[j] = ox >= 0 ? *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4) : zero;
-        vg[j] = og >= 0 ? *reinterpret_cast<const float4 *>(g + og + c0 + part * 4) : zero;
-      }
-#pragma unroll
-      for (int j = 0; j < kDotQ; ++j) {
-        const int f = tid + kBlock * j, item = f >> 3, part = f & 7;
-        *reinterpret_cast<float4 *>(&tx[item][part * 4]) = vx[j];
-        *reinterpret_cast<float4 *>(&tg[item][part * 4]) = vg[j];
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < kDotQ; ++j) {
-        if (j < nq) {
-          const int f = tid + kBlock * j, item = f / nq, part = f - item * nq;
-          const int64_t ox = sx[item], og = sg[item];
-          vx[j] = ox >= 0 ? *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4) : zero;
-          vg[j] = og >= 0 ? *reinterpret_cast<const float4 *>(g + og + c0 + part * 4) : zero;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < kDotQ; ++j) {
-        if (j < nq) {
-          const int f = tid + kBlock * j, item = f / nq, part = f - item * nq;
-          *reinterpret_cast<float4 *>(&tx[item][part * 4]) = vx[j];
-          *reinterpret_cast<float4 *>(&tg[item][part * 4]) = vg[j];
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kDotQ; ++k) {
-      if (k < nq) {
-        const float4 a = *reinterpret_cast<const float4 *>(&tx[tid][k * 4]);
-        const float4 b = *reinterpret_cast<const float4 *>(&tg[tid][k * 4]);
-        acc = __fadd_rn(acc, __fmul_rn(a.x, b.x));
-        acc = __fadd_rn(acc, __fmul_rn(a.y, b.y));
-        acc = __fadd_rn(acc, __fmul_rn(a.z, b.z));
-        acc = __fadd_rn(acc, __fmul_rn(a.w, b.w));
-      }
-    }
-    __syncthreads();
+  int64_t c0 = c_lo;
+  for (; c0 + kDotQ * 4 <= c_hi; c0 += kDotQ * 4) acc = dot_slab<kDotQ>(tid, sx, sg, x, g, c0, tx, tg, acc);
+  switch ((int)((c_hi - c0) >> 2)) {   // the last, narrower slab (block-uniform)
+    case 7: acc = dot_slab<7>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    case 6: acc = dot_slab<6>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    case 5: acc = dot_slab<5>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    case 4: acc = dot_slab<4>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    case 3: acc = dot_slab<3>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    case 2: acc = dot_slab<2>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    case 1: acc = dot_slab<1>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    default: break;
   }
   if (!valid) return;
   if (carry_out) carry_out[i] = acc;

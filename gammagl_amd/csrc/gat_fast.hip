@@ -1,7 +1,7 @@
 // gammagl_amd/csrc/gat_fast.hip — the GPU-only paths of the fused GAT op: kernels that exchange values between
 // lanes (DPP moves, ds_bpermute) and therefore have no host-emulated build; the -m gpu suite is their checker
 // (against the oracle through Engine.gat_fused, against the kernels of gat.hip, and at full size).  The
-// host-emulated test library links tests/emul/gat_fast_stub.cpp in place of this file.
+// host build links host/gpu_only_stubs.cpp in place of this file.
 #include "gat_common.hpp"
 
 namespace ggl {

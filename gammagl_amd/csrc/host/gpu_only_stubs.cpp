@@ -1,10 +1,10 @@
-// tests/emul/gat_fast_stub.cpp — TEST INFRASTRUCTURE.  The host-emulated library cannot run the kernels of
+// gammagl_amd/csrc/host/gpu_only_stubs.cpp — the host build (host_shim.hpp) cannot run the kernels of
 // gammagl_amd/csrc/gat_fast.hip (they exchange values between lanes); it exports the same symbols so that the ctypes
 // binding loads, answers "not supported" to the capability queries and fails loudly if a path is called anyway.
 #include <stddef.h>
 #include <stdint.h>
 
-#include "../../include/ggl_mpops.h"
+#include "../../../include/ggl_mpops.h"
 
 namespace ggl { void set_error(const char *fmt, ...); }
 

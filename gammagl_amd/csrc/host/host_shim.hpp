@@ -1,14 +1,20 @@
-// tests/emul/emul_shim.hpp — minimal host stand-in for the HIP device environment.
+// gammagl_amd/csrc/host/host_shim.hpp — minimal host stand-in for the HIP device environment: the HOST BUILD of the
+// kernel sources (-DGGL_EMULATE), i.e. the CPU backend of the ops.
 //
-// TEST INFRASTRUCTURE ONLY.  The kernels compiled here use no LDS, no cross-lane shuffles, no barriers
-// and no order-dependent atomics (the sampler's first-occurrence atomicMin is order-independent), so running
-// their bodies one thread at a time on the host executes exactly the same arithmetic in the same order.
-// Kernels that DO shuffle (the fast GAT path, the wide-head GAT backward) are GPU-build only and are checked
-// by the -m gpu suite alone.  tests/emul/build.sh compiles gammagl_amd/csrc/*.hip with
-// -DGGL_EMULATE into tests/emul/libggl_emul.so so the `-m "not gpu"` suite can check kernel LOGIC
-// (indexing, row splitting, tie-breaking, dtype semantics) in a container that has no GPU.  The
-// product package never loads this library (gammagl_amd/_lib.py loads libggl_mpops_hip.so only
-// and raises if it is missing).
+// The reference's ops dispatch on x.is_cuda() / x.is_cpu() (gammagl/mpops/torch_ext/src/segment_sum.cpp:19-33): CPU
+// tensors run its serial C++ loops, and BASELINE config 1 (Cora, `--gpu -1`) is exactly that path.  The row kernels of
+// reduce.hip / plan.hip / backward.hip / gat.hip / epilogue.hip / sample.hip use no LDS, no cross-lane shuffles, no
+// barriers and no order-dependent atomics (the sampler's first-occurrence atomicMin is order-independent), so running
+// their bodies one thread at a time on the host executes the same arithmetic in the same order — on rows reduced in
+// one piece bit for bit what the GPU computes and what the reference's serial loops compute.  Kernels that DO use LDS
+// or shuffles (gat_fast.hip, hub16.hip, the wide-head GAT backward, the LDS path of edgedot.hip) are GPU-build only;
+// gpu_only_stubs.cpp answers their capability queries with "no" and the generic kernels serve those shapes.
+//
+// Two consumers: `make -C gammagl_amd/csrc host` -> gammagl_amd/lib/libggl_mpops_host.so, bound to the `CPU` dispatch
+// key (gammagl_amd/torch_ops.py; CPU tensors ONLY — a GPU tensor never reaches it, and a missing HIP library still
+// fails loudly), and tests/emul/build.sh -> the same sources at -O1 / under AddressSanitizer for the `-m "not gpu"`
+// suite's kernel-logic tests.  Single-threaded on purpose: the reference's shipped CPU extension is serial too
+// (its OpenMP macro is never defined, setup.py:50).  Never the oracle: oracle/ is a separate restatement.
 #pragma once
 #include <cmath>
 #include <cstdint>

@@ -171,6 +171,35 @@ template <> struct RowIO<float, 4, true> {
     }
   }
 };
+// ... and the same for the 16-bit float storage types: rows of K % 8 != 0 elements (47 classes: 94-byte rows) used to take
+// the VEC = 1 kernels, one 2-byte load per lane — a wave-load that moves 94 bytes; here lanes 0 .. K/8 - 1 move 16 bytes
+// from a 2-byte aligned address (the backend emits global_load_dwordx4 for the packed struct: unaligned access mode)
+// and the last lane of the row the K % 8 elements left over.  Same elements, same order of the same rounded adds.
+struct __attribute__((packed, aligned(2))) H8U { uint16_t v[8]; };
+template <> struct RowIO<uint16_t, 8, true> {
+  static __device__ __forceinline__ void load(const uint16_t *__restrict__ p, uint16_t (&v)[8], int nv) {
+    if (nv == 8) {
+      const H8U t = *reinterpret_cast<const H8U *>(p);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = t.v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = i < nv ? p[i] : (uint16_t)0;
+    }
+  }
+  static __device__ __forceinline__ void store(uint16_t *__restrict__ p, const uint16_t (&v)[8], int nv) {
+    if (nv == 8) {
+      H8U t;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t.v[i] = v[i];
+      *reinterpret_cast<H8U *>(p) = t;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < nv) p[i] = v[i];
+    }
+  }
+};
 template <int VEC, bool RAG> __device__ __forceinline__ int valid_lanes(int64_t K, int64_t kk) {
   return RAG ? (int)((K - kk) < VEC ? (K - kk) : VEC) : VEC;
 }
@@ -721,6 +750,13 @@ static bool wide_ok(const ReduceArgs &a, int vec) {
          (!a.partial || aligned16(a.partial)) && a.x_ld % vec == 0 && a.out_ld % vec == 0;
 }
 
+// 16-bit rows that are not made of aligned 16-byte pieces: eight elements per lane all the same (RowIO<uint16_t, 8, true>);
+// sum / mean only (max carries eight int64 argmax registers per lane: the f32 ragged path measured slower there), and
+// from 12 columns up (below that one lane per element with 16 loads in flight wins)
+template <int OP> static bool ragged16_ok(const ReduceArgs &a) {
+  return OP != OP_MAX && !options().force_generic && options().ragged4 && a.K >= 12;
+}
+
 template <int OP>
 static int launch_seg(int dtype, const ReduceArgs &a, hipStream_t stream) {
   switch (dtype) {
@@ -730,9 +766,11 @@ static int launch_seg(int dtype, const ReduceArgs &a, hipStream_t stream) {
       return launch_typed<double, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_F16:
       if (wide_ok(a, 8)) return launch_typed<f16_t, 8, OP, MODE_SEG, false>(a, stream);
+      if (ragged16_ok<OP>(a)) return launch_typed<f16_t, 8, OP, MODE_SEG, false, true>(a, stream);
       return launch_typed<f16_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_BF16:
       if (wide_ok(a, 8)) return launch_typed<bf16_t, 8, OP, MODE_SEG, false>(a, stream);
+      if (ragged16_ok<OP>(a)) return launch_typed<bf16_t, 8, OP, MODE_SEG, false, true>(a, stream);
       return launch_typed<bf16_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_U8: return launch_typed<uint8_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_I8: return launch_typed<int8_t, 1, OP, MODE_SEG, false>(a, stream);

@@ -360,6 +360,81 @@ class _HaloAggregate(torch.autograd.Function):
         return (gh if gh.shape[1] == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None, gb, None, None, None
 
 
+class _ConstInputLayer(torch.autograd.Function):
+    """The FIRST GCN layer in GammaGL's association, A (X W) (gcn_conv.py:79), on input features that never change
+    and whose halo rows this rank holds (`PartitionedGraph.with_halo`): A (X W) = A_loc (X_loc W) + A_halo (X_halo W).
+    The halo buffer the other layers receive over the wire is here FILLED BY A GEMM, one column chunk at a time, into
+    the very same persistent buffers — no exchange in either direction, no [n_halo, K] tensor of its own:
+
+      forward   h_loc = X_loc W^T; out = A_loc h_loc; per chunk c: buf_c = X_halo W_c^T, out[:, c] += A_halo buf_c
+                (bias / ReLU / dropout ride on the store of the last block added, as everywhere);
+      backward  ga = epilogue'(g); dW = (A_loc^T ga)^T X_loc; per chunk c: buf_c = A_halo^T ga[:, c],
+                dW[c] += buf_c^T X_halo.  The gradient of a halo row of X W is consumed where it is produced — this
+                rank's share of dW, which the step all-reduces anyway.  X carries no gradient.
+
+    Costs (n_halo x f_in x K) extra multiply-adds each way instead of 2 x n_halo x K floats on the links
+    (products-sized graph, 8 ranks: 0.6 ms of GEMM instead of 1.7 GB over xGMI per step)."""
+
+    @staticmethod
+    def forward(ctx, x_cat, w, pg, bias, relu, p_drop, pad_out):
+        eng, nl = pg.eng, pg.n_local
+        dev = x_cat.device
+        wp = w if not pad_out else F.pad(w, (0, 0, 0, int(pad_out)))       # [K, f_in]
+        K = int(wp.shape[0])
+        x_loc, x_halo = x_cat[:nl], x_cat[nl:]
+        h = x_loc @ wp.t()
+        out = torch.empty((nl, K), dtype=torch.float32, device=dev)
+        epi = bias is not None or relu or p_drop > 0
+        rng = eng._rng_state(dev) if p_drop > 0 else None
+        ctx.rng_used = rng.clone() if rng is not None else None
+        b = bias.contiguous().reshape(-1) if bias is not None else None
+        eng.spmm_sum_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out)
+        chunks = _HaloAggregate._chunks(K)
+        for i, (c0, c1) in enumerate(chunks):
+            hh = pg._buf(("halo", i), pg.n_halo, c1 - c0, torch.float32, dev)
+            torch.mm(x_halo, wp[c0:c1].t(), out=hh)
+            eng.spmm_epi_into(pg.gp_halo.fwd, pg.gp_halo.col, pg.w_halo, hh, out[:, c0:c1], accumulate=True, bias=b,
+                              relu=relu, p_drop=p_drop, rng=rng, epi_K=K, col0=c0, advance_rng=(i == len(chunks) - 1))
+        ctx.pg, ctx.n_out = pg, int(w.shape[0])
+        ctx.epi = (epi, bool(relu), float(p_drop), None if bias is None else bias.shape)
+        ctx.save_for_backward(x_cat, out if epi else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pg = ctx.pg
+        eng, nl = pg.eng, pg.n_local
+        x_cat, y = ctx.saved_tensors
+        g = g.contiguous()
+        dev = g.device
+        epi, relu, p_drop, bshape = ctx.epi
+        gb = None
+        if epi:
+            N, K0 = int(g.shape[0]), int(g.shape[1])
+            ga = torch.empty_like(g)
+            gb = torch.empty(K0, dtype=torch.float32, device=dev) if bshape is not None else None
+            wsb = eng.lib.ggl_bias_act_bwd_workspace_bytes(N, K0)
+            ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dev)
+            eng._check(eng.lib.ggl_bias_act_bwd(_ptr(g), _ptr(y), N, K0, int(relu), float(p_drop), _ptr(ctx.rng_used),
+                                                _ptr(ga), _ptr(gb), _ptr(ws), wsb, eng._stream(dev)))
+            g = ga
+            if gb is not None:
+                gb = gb.reshape(bshape)
+        gw = None
+        if ctx.needs_input_grad[1]:
+            K = int(g.shape[1])
+            x_loc, x_halo = x_cat[:nl], x_cat[nl:]
+            gl, _ = eng._spmm_fwd("sum", pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, nl)
+            gw = wgrad(gl, x_loc)                                            # [K, f_in]
+            del gl
+            for i, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
+                gh = pg._buf(("halo", i), pg.n_halo, c1 - c0, torch.float32, dev)
+                eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g[:, c0:c1], gh)
+                gw[c0:c1] += wgrad(gh, x_halo)
+            gw = gw[:ctx.n_out]
+        return None, gw, None, gb, None, None, None
+
+
 class _LinearSideWgrad(torch.autograd.Function):
     """y = x @ W^T whose WEIGHT gradient (a compute-bound [out, N] x [N, in] GEMM that nothing needs before
     the optimizer step) is issued on a side HIP stream, so it runs under the next layer's HBM-bound
@@ -469,10 +544,15 @@ class DistGCN(torch.nn.Module):
                 # A (X W), GammaGL's association (gcn_conv.py:79).  With the halo rows of a constant input in place
                 # the transform runs on them too: A (X W) = A_loc (X_loc W) + A_halo (X_halo W)
                 n_agg += 2
-                h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink, pad)
-                # + bias, ReLU and dropout ride on the store of the last edge block added to a row: the local SpMM
-                # on one GPU, the halo-source SpMM behind the exchange otherwise (reduce.hip MODE_SPMM_EPI)
-                x = pg.aggregate(h, bias, relu=hidden, p_drop=p, training=self.training, halo_included=pre)
+                if pre and (n_out + pad) % 4 == 0:
+                    # constant input, halo rows held here: the halo buffer is filled by a GEMM instead of the wire
+                    x = _ConstInputLayer.apply(x, self.lin[i].weight, pg, bias, hidden,
+                                               p if self.training else 0.0, pad)
+                else:
+                    h = _LinearSideWgrad.apply(x, self.lin[i].weight, self.side, self._sink, pad)
+                    # + bias, ReLU and dropout ride on the store of the last edge block added to a row: the local SpMM
+                    # on one GPU, the halo-source SpMM behind the exchange otherwise (reduce.hip MODE_SPMM_EPI)
+                    x = pg.aggregate(h, bias, relu=hidden, p_drop=p, training=self.training, halo_included=pre)
             pre = False
             if pad:
                 x = x[:, :n_out]

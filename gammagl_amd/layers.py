@@ -35,7 +35,7 @@ def degree(index, num_nodes, dtype=torch.float32):
     if not index.is_cuda or index.dim() != 1 or index.dtype != torch.int64:
         one = torch.ones((index.shape[0],), dtype=dtype, device=index.device)
         return unsorted_segment_sum(one, index, num_nodes)
-    cnt = _engine().seg_plan(index, num_nodes).counts()
+    cnt = _engine(index).seg_plan(index, num_nodes).counts()
     sat = {torch.float32: 1 << 24, torch.float16: 2048, torch.bfloat16: 256}.get(dtype)
     if sat is not None:
         cnt = cnt.clamp(max=sat)
@@ -117,7 +117,7 @@ class MessagePassing(nn.Module):
             # 155 -> 14.7 ms forward+backward, 59 GB less HBM), same sums in the same order.  Sampled blocks stay
             # below the threshold on purpose: they are NEW edge lists every batch and the fused backward would
             # need a transposed plan (a sort + host syncs) each time — measured 4.5 vs 3.1 ms per batch.
-            eng = _engine()
+            eng = _engine(x)
             gp = eng.graph_plan(edge_index, int(kwargs['num_nodes']), int(x.shape[0]))
             ew = kwargs.get('edge_weight')
             x = eng.spmm(gp, None if ew is None else ew.reshape(-1).contiguous(), x, aggr)
@@ -154,7 +154,7 @@ class GCNConv(MessagePassing):
         cached GraphPlan (the same tensor every call also lets the SpMM stream its sorted copy)."""
         gp = None
         if edge_weight is None:
-            gp = _engine().graph_plan(edge_index, num_nodes)
+            gp = _engine(edge_index).graph_plan(edge_index, num_nodes)
             hit = gp.aux.get(("gcn_norm", self._norm))
             if hit is not None:
                 return hit
@@ -200,16 +200,16 @@ class GCNConv(MessagePassing):
                 out = torch.relu(out) if relu else out
                 out = torch.nn.functional.dropout(out, p_drop, training) if p_drop > 0 else out
             elif bias is not None or relu or p_drop > 0:
-                out = _engine().bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
+                out = _engine(out).bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
         elif (x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0
               and weights.dtype == torch.float32 and weights.numel() == edge_index.shape[1]):
-            eng = _engine()
+            eng = _engine(x)
             out = eng.spmm_bias_act(eng.graph_plan(edge_index, num_nodes), weights, x, bias, relu=relu,
                                     p_drop=p_drop, training=training)
         else:
             out = self.propagate(x, edge_index, edge_weight=weights, num_nodes=num_nodes)
             if bias is not None or relu or p_drop > 0:
-                out = _engine().bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
+                out = _engine(out).bias_act(out, bias, relu=relu, p_drop=p_drop, training=training)
         return out[:, :n_out] if pad else out
 
     def message_aggregate(self, x, edge_index, edge_weight=None, aggr="sum"):  # gcn_conv.py:110-115
@@ -261,7 +261,7 @@ class SAGEConv(MessagePassing):
                     and src_feat.dtype == torch.float32 and fused_act):
                 # input narrower than output: aggregate first, transform the (fewer, in a sampled block) destination
                 # rows afterwards — see the Block branch above
-                eng = _engine()
+                eng = _engine(src_feat)
                 if edge.shape[1] >= FUSED_MIN_EDGES:
                     gp = eng.graph_plan(edge, num_nodes, int(src_feat.shape[0]))
                     agg = eng.spmm(gp, None, src_feat, "mean")
@@ -275,7 +275,7 @@ class SAGEConv(MessagePassing):
             if SAGE_FUSE_EPILOGUE and src_feat.dim() == 2 and src_feat.dtype == torch.float32 and fused_act:
                 # "mean + fc_self(x_dst) + bias -> act" (sage_conv.py:100-108) rides on the aggregate's store:
                 # the fused rectangular SpMM-mean for big edge lists, the segment route for sampled blocks
-                eng = _engine()
+                eng = _engine(src_feat)
                 self_term = self.fc_self(dst_feat)
                 if edge.shape[1] >= FUSED_MIN_EDGES:
                     gp = eng.graph_plan(edge, num_nodes, int(src_feat.shape[0]))
@@ -359,7 +359,7 @@ class FusedGATConv(GATConv):
 
     def forward(self, x, edge_index, num_nodes=None, **kwargs):
         H, C = self.heads, self.out_channels
-        eng = _engine()
+        eng = _engine(x)
         if 'row_ptr' in kwargs:
             # fusedgat_conv.py:95-100: the caller's own CSR (rows = the aggregating nodes, col_ind = the nodes they
             # gather from), its transpose and the CSC -> CSR position map: taken as they are, no sort, no host trip
@@ -379,7 +379,7 @@ class FusedGATConv(GATConv):
         x = (x @ w).reshape(-1, H, C + pad)
         el = (x[:, :, :C] * self.att[:, :, :C]).sum(dim=-1)   # source term  a_src . x_j
         er = (x[:, :, :C] * self.att[:, :, C:]).sum(dim=-1)   # destination term a_dst . x_i
-        x = _engine().gat_fused(edge_index, el, er, x, self.negative_slope, num_nodes=num_nodes,
+        x = _engine(x).gat_fused(edge_index, el, er, x, self.negative_slope, num_nodes=num_nodes,
                                 dropout_rate=self.dropout_rate, training=self.training)
         return self._finish(x[:, :, :C] if pad else x)
 

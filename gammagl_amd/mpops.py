@@ -6,7 +6,8 @@ Same names, argument meaning and return types as the reference module
 leaks through the star-import and is used at message_passing.py:101).  Differences, on purpose:
 
 * the work runs in hand-written HIP kernels on MI355X, reached through the dispatcher ops
-  ``torch.ops.gammagl_amd.*`` (gammagl_amd/torch_ops.py; no CPU path; CPU tensors raise);
+  ``torch.ops.gammagl_amd.*`` (gammagl_amd/torch_ops.py); CPU tensors dispatch to the host build of the same
+  kernel sources, as the reference dispatches on ``x.is_cpu()`` (BASELINE config 1: ``--gpu -1``);
 * native errors are NOT swallowed: the reference's segment wrappers catch every exception and
   silently re-run a pure-torch fallback (torch.py:83-86,139-142,199-202) that disagrees with the
   C++ extension on empty max segments and integer dtypes (SURVEY.md §8c); here an error is an error;
@@ -17,7 +18,7 @@ leaks through the star-import and is used at message_passing.py:101).  Differenc
 import torch  # noqa: F401  (re-exported on purpose, see above)
 
 from . import engine as _engine
-from . import torch_ops as _torch_ops  # registers torch.ops.gammagl_amd.* (CUDA/HIP kernels only)
+from . import torch_ops as _torch_ops  # registers torch.ops.gammagl_amd.* (CUDA = HIP kernels, CPU = host build)
 
 _ops = _torch_ops.ops
 use_ext = True
@@ -46,7 +47,7 @@ def unsorted_segment_sum(x, segment_ids, num_segments=None):
     """out[s] = sum of x[e] over e with segment_ids[e] == s (torch.py:43-86)."""
     assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
     n = _num_segments(segment_ids, num_segments)
-    _engine()._dev(x)
+    _engine(x)._dev(x)
     return _ops.segment_sum(x, _ids(segment_ids, x), n)
 
 
@@ -54,7 +55,7 @@ def unsorted_segment_mean(x, segment_ids, num_segments=None):
     """Mean along segments; empty segments give 0 (torch.py:99-142)."""
     assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
     n = _num_segments(segment_ids, num_segments)
-    _engine()._dev(x)
+    _engine(x)._dev(x)
     return _ops.segment_mean(x, _ids(segment_ids, x), n)
 
 
@@ -62,7 +63,7 @@ def unsorted_segment_max(x, segment_ids, num_segments=None):
     """Max along segments (torch.py:159-202); empty segments hold lowest() as in the C++ extension."""
     n = _num_segments(segment_ids, num_segments)
     assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
-    _engine()._dev(x)
+    _engine(x)._dev(x)
     return _ops.segment_max(x, _ids(segment_ids, x), n)[0]
 
 
@@ -80,7 +81,7 @@ def segment_sum(x, segment_ids, num_segments=None):
 
 def gspmm(index, weight=None, x=None, reduce='sum'):
     """Generalized SpMM: out[dst] = reduce_e weight[e] * x[src] (torch.py:302-351)."""
-    _engine()._dev(index, weight, x)
+    _engine(x)._dev(index, weight, x)
     # weight=None: torch.py:332-333 builds ones([E]) f32; w * x == x exactly, so the kernels simply skip
     # the multiply when no weight pointer is passed
     if reduce == 'sum':
@@ -100,7 +101,7 @@ def bspmm(index, weight=None, x=None, reduce='sum'):
         # out-of-bounds read for H > 1); the only meaningful reading is "all heads weigh 1"
         weight = torch.ones((index.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
     if reduce == 'sum':
-        _engine()._dev(index, weight, x)
+        _engine(x)._dev(index, weight, x)
         return _ops.bspmm_sum(index, weight, x)
     else:
         raise Exception("Unsupported reduce type, please choose from ['sum'].")

@@ -237,9 +237,10 @@ class _PlanCache:
 
 
 class Engine:
-    def __init__(self, lib, require_cuda=True):
+    def __init__(self, lib, require_cuda=True, cpu_only=False):
         self.lib = lib
         self.require_cuda = require_cuda
+        self.cpu_only = cpu_only      # the host build: its kernels dereference host pointers
         self.seg_cache = _PlanCache()
         self.graph_cache = _PlanCache()
         self.w_cache = _PlanCache(cap=8)
@@ -248,6 +249,8 @@ class Engine:
         self.chunk = DEFAULT_CHUNK  # long-row threshold == elements per chunk; 0 = auto_chunk(E)
         self.gat_fast = True        # fused GAT: the low-VALU kernels where the head shape allows (GPU build only)
         self.hub16 = True           # f16 / bf16 sums: LDS-pipelined hub rows (GPU build only; A/B switch)
+        self.hub16_overlap = True   # ... launched on a side stream beside the walk over the other rows (A/B switch)
+        self._side = {}
         self.mean_bwd_prescale = True  # spmm mean backward = rows pre-divided by their count + plain SpMM-sum (A/B switch)
         self.row_order_window = int(os.environ.get("GGL_ROW_ORDER_WINDOW", "2048"))   # see _row_order (0 = global sort)
         self.row_order_heavy = 1024
@@ -279,13 +282,23 @@ class Engine:
                 continue
             if self.require_cuda and not t.is_cuda:
                 raise RuntimeError(
-                    "gammagl_amd runs on MI355X only: got a tensor on %s (there is no CPU path; "
-                    "move the tensors to 'cuda')" % t.device)
+                    "this is the MI355X engine (libggl_mpops_hip.so): got a tensor on %s; CPU tensors go through "
+                    "gammagl_amd.engine(tensor) / gammagl_amd.mpops, which route them to the host build" % t.device)
+            if self.cpu_only and t.is_cuda:
+                raise RuntimeError("this is the host build of the kernels (CPU tensors only): got a tensor on %s"
+                                   % t.device)
             if dev is None:
                 dev = t.device
             elif t.device != dev:
                 raise RuntimeError("Tensor device inconsistent error.")  # segment_sum.cpp:31
         return dev
+
+    def _side_stream(self, dev):
+        s = self._side.get(str(dev))
+        if s is None:
+            s = torch.cuda.Stream(device=dev)
+            self._side[str(dev)] = s
+        return s
 
     @staticmethod
     def _stream(dev):
@@ -493,11 +506,23 @@ class Engine:
         cs = plan.c_struct(part, unsplit=unsplit and not hubs, skip_long=hubs)
         if op in ("sum", "mean"):
             fn = self.lib.ggl_segment_sum if op == "sum" else self.lib.ggl_segment_mean
-            self._check(fn(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
+            side = None
             if hubs:
+                # the hub rows' serial add chains (16-24 ns per element: 2.4-3.5 ms for a 147 000-element hub) run BESIDE
+                # the launch over all other rows, on a side stream — they write disjoint rows of `out`
                 full = plan.c_struct(None)
+                if dev.type == "cuda" and self.hub16_overlap:
+                    cur = torch.cuda.current_stream(dev)
+                    side = self._side_stream(dev)
+                    side.wait_stream(cur)
+                    self._check(self.lib.ggl_segment_hub16(code, 0 if op == "sum" else 1, _ptr(x), ctypes.byref(full), K,
+                                                           _ptr(out), ctypes.c_void_p(side.cuda_stream)))
+            self._check(fn(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), st))
+            if hubs and side is None:
                 self._check(self.lib.ggl_segment_hub16(code, 0 if op == "sum" else 1, _ptr(x), ctypes.byref(full), K,
                                                        _ptr(out), st))
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
             return out, None
         arg = torch.empty((plan.N,) + tuple(x.shape[1:]), dtype=torch.int64, device=dev)
         self._check(self.lib.ggl_segment_max(code, _ptr(x), ctypes.byref(cs), K, _ptr(out), _ptr(arg),

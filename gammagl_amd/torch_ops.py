@@ -14,11 +14,13 @@ points (+ the fused GAT op and the fused epilogue) are dispatcher ops:
     torch.ops.gammagl_amd.gat_fused(index, el, er, x, negative_slope, num_nodes, dropout_rate) -> Tensor
     torch.ops.gammagl_amd.bias_act(a, bias, relu, p_drop) -> Tensor
 
-Kernels are registered for the ``CUDA`` (= HIP on ROCm) and ``AutogradCUDA`` dispatch keys only: a CPU
-tensor ends in the dispatcher's "could not run ... with arguments from the 'CPU' backend" error — there
-is no CPU implementation to fall back to.  Each kernel forwards to the engine entry point of the same
-name (gammagl_amd/ops.py), i.e. ctypes -> C ABI (include/ggl_mpops.h) -> HIP kernel on the current
-stream; the autograd formulas are the ``torch.autograd.Function``s defined there.  Fake (meta) kernels
+Kernels are registered for ``CUDA`` / ``AutogradCUDA`` (= HIP on ROCm: libggl_mpops_hip.so) and for ``CPU`` /
+``AutogradCPU`` (libggl_mpops_host.so, the host build of the same kernel sources) — the reference's ops dispatch
+on ``x.is_cuda()`` / ``x.is_cpu()`` the same way (src/segment_sum.cpp:19-33).  The dispatcher routes by the
+tensors' device: a GPU tensor can only ever reach the HIP library (a missing one fails loudly at first use), a CPU
+tensor only the host build.  Each kernel forwards to the engine entry point of the same name (gammagl_amd/ops.py),
+i.e. ctypes -> C ABI (include/ggl_mpops.h) -> kernel; the autograd formulas are the ``torch.autograd.Function``s
+defined there.  Fake (meta) kernels
 give shapes/dtypes so the ops trace under ``torch.compile`` / FakeTensor without running.
 """
 import torch
@@ -43,6 +45,7 @@ _DEF = Library(NS, "DEF")
 for _name, _sig in _SCHEMAS.items():
     _DEF.define(_name + _sig)
 _IMPLS = []  # Library handles must stay alive for their registrations to stay
+_ENGINES = {}  # dispatch key -> [callable returning the engine its kernels run on]
 
 
 def _kernels(get_engine):
@@ -64,12 +67,17 @@ def _kernels(get_engine):
 def register_backend(get_engine, backend="CUDA"):
     """Bind every op to ``get_engine()`` for dispatch key ``backend`` and its autograd key.
 
-    The package registers ``CUDA`` (the MI355X engine) at import.  The CPU test-suite binds ``CPU`` to
-    the host-emulation build of the same kernel sources (tests/emul) to exercise this layer without a
-    GPU; nothing in the package does.
+    The package registers ``CUDA`` (the MI355X engine) and ``CPU`` (the host build) at import; a later
+    registration for the same key replaces the earlier one's engine (the CPU test-suite binds ``CPU`` to its own
+    -O1 / AddressSanitizer builds of the same sources).
     """
+    slot = _ENGINES.get(backend)
+    if slot is not None:        # already registered: swap the engine the registered kernels resolve to
+        slot[0] = get_engine
+        return None
+    slot = _ENGINES[backend] = [get_engine]
     lib = Library(NS, "IMPL")
-    for name, fn in _kernels(get_engine).items():
+    for name, fn in _kernels(lambda: slot[0]()).items():
         lib.impl(name, fn, backend)
         lib.impl(name, fn, "Autograd" + backend)
     _IMPLS.append(lib)
@@ -107,7 +115,16 @@ def _product_engine():
     return engine()
 
 
+def _host_engine():
+    import gammagl_amd
+
+    if gammagl_amd._engine is not None and not gammagl_amd._engine.require_cuda:
+        return gammagl_amd._engine     # an injected any-device engine (tests)
+    return gammagl_amd.host_engine()
+
+
 _register_fakes()
 register_backend(_product_engine, "CUDA")
+register_backend(_host_engine, "CPU")
 
 ops = getattr(torch.ops, NS)

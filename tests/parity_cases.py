@@ -936,6 +936,34 @@ def check_bspmm_wide(eng, dev):
         torch.testing.assert_close(w.grad, wr.grad, rtol=1e-5, atol=1e-5)
 
 
+def check_half_ragged_rows(eng, dev, oracle):
+    """f16 / bf16 segment sum / mean on rows that are not made of aligned 16-byte pieces (12, 13, 47, 100 columns, and a
+    base address that is only 2-byte aligned): eight elements per lane with a ragged last lane
+    (reduce.hip RowIO<uint16_t, 8, true>) — the oracle's serial storage-dtype sums bit for bit, incl. a hub row and
+    with the lanes switched off (A/B)."""
+    rng = np.random.default_rng(31)
+    old = eng.lib.ggl_get_option(b"ragged4")
+    try:
+        for dt in ("float16", "bfloat16"):
+            for K in (12, 13, 47, 100):
+                N, E = 70, 4000
+                ids = rng.integers(0, N - 4, E).astype(np.int64)
+                ids[: E // 4] = 3
+                xf = (rng.standard_normal((E + 1, K)) * 3 + 0.25).astype(np.float32)
+                xh = oracle.f32_to_bf16_bits(xf) if dt == "bfloat16" else xf.astype(np.float16)
+                x_all = to_t(xh, dev, dt)
+                x = x_all[1:]                       # contiguous, base = K * 2 bytes past an allocation: 2-byte aligned for odd K
+                want_s = oracle.segment_sum(xh[1:], ids, N, bf16=dt == "bfloat16")
+                want_m = oracle.segment_mean(xh[1:], ids, N, bf16=dt == "bfloat16")
+                it = to_t(ids, dev)
+                for rag in (1, 0):
+                    eng.set_option("ragged4", rag)
+                    assert_same(to_np(eng.c_segment_sum(x, it, N)), want_s, f"{dt} K{K} sum ragged={rag}")
+                    assert_same(to_np(eng.c_segment_mean(x, it, N)), want_m, f"{dt} K{K} mean ragged={rag}")
+    finally:
+        eng.set_option("ragged4", old)
+
+
 def check_bspmm_gradw_sorted(eng, dev, oracle):
     """bspmm's weight gradient along the destination-sorted plan (edgedot.hip: strips staged through LDS on the GPU;
     the plain walk in the host-emulation build): bit for bit the oracle's serial-over-c sums, for heads of 20 ... 300

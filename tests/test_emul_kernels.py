@@ -71,6 +71,10 @@ def test_bspmm_wide_heads(eng):
     pc.check_bspmm_wide(eng, DEV)
 
 
+def test_half_precision_ragged_rows(eng, oracle):
+    pc.check_half_ragged_rows(eng, DEV, oracle)
+
+
 def test_bspmm_weight_gradient_on_the_sorted_plan(eng, oracle):
     pc.check_bspmm_gradw_sorted(eng, DEV, oracle)
 

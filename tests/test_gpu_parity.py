@@ -110,6 +110,10 @@ def test_bspmm_wide_heads(eng, dev):
     pc.check_bspmm_wide(eng, dev)
 
 
+def test_half_precision_ragged_rows(eng, dev, oracle):
+    pc.check_half_ragged_rows(eng, dev, oracle)
+
+
 def test_bspmm_weight_gradient_on_the_sorted_plan(eng, dev, oracle):
     pc.check_bspmm_gradw_sorted(eng, dev, oracle)
 
@@ -444,7 +448,9 @@ def test_rccl_self_halo_exchange(eng, dev):
         l1 = float(tr1.step(x, y, idx, idx.numel()))
         assert abs(l0 - l1) <= 1e-5 * abs(l1) + 1e-6
         for p, q in zip(tr.net.parameters(), tr1.net.parameters()):
-            torch.testing.assert_close(p.grad, q.grad, rtol=1e-3, atol=1e-6)
+            # (the first layer's weight gradient sums [x_loc ; x_halo] rows in another order than the single-rank
+            # GEMM: f32 rounding of a 20 000-term sum, scaled by the largest entry)
+            torch.testing.assert_close(p.grad, q.grad, rtol=1e-3, atol=2e-4 * float(q.grad.abs().max()))
     finally:
         dist.destroy_process_group()
 

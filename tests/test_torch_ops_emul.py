@@ -1,7 +1,7 @@
-"""torch.ops.gammagl_amd.* (gammagl_amd/torch_ops.py) exercised WITHOUT a GPU: the dispatcher layer is
-bound, inside this test only, to the host-emulation build of the kernel sources for the ``CPU`` key
-(the package itself registers HIP kernels only), then checked against the oracle, for gradients, for
-the schema / fake-tensor kernels with ``torch.library.opcheck`` and for the unregistered-backend error."""
+"""torch.ops.gammagl_amd.* (gammagl_amd/torch_ops.py) exercised WITHOUT a GPU, through the ``CPU`` dispatch key:
+first as the package registers it (libggl_mpops_host.so, the host build of the kernel sources), then with the key's
+engine swapped for the tests' own -O1 build, checked against the oracle, for gradients and for the schema /
+fake-tensor kernels with ``torch.library.opcheck``."""
 import os
 import subprocess
 
@@ -19,10 +19,9 @@ def ops():
     from gammagl_amd.ops import Engine
 
     eng = Engine(_lib.bind(os.path.join(HERE, "emul", "libggl_emul.so")), require_cuda=False)
-    lib = torch_ops.register_backend(lambda: eng, "CPU")
+    torch_ops.register_backend(lambda: eng, "CPU")       # the key is registered already: swaps its engine
     yield torch_ops.ops
-    lib._destroy()
-    torch_ops._IMPLS.remove(lib)
+    torch_ops.register_backend(torch_ops._host_engine, "CPU")
 
 
 def _graph(n, e, seed):
@@ -30,13 +29,28 @@ def _graph(n, e, seed):
     return torch.randint(0, n, (2, e), generator=g), g
 
 
-def test_product_registers_hip_only():
-    from gammagl_amd import torch_ops
+def test_product_registers_cpu_and_hip_keys(golden):
+    """As shipped: CPU tensors dispatch to the host build of the kernel sources (the reference's ops dispatch on
+    x.is_cpu() too: BASELINE config 1 runs with --gpu -1), GPU tensors to the HIP library only; the engines refuse the
+    other device's tensors instead of moving them."""
+    import gammagl_amd
+    from gammagl_amd import _lib, torch_ops
 
+    assert set(torch_ops._ENGINES) == {"CUDA", "CPU"}
     x = torch.ones(3, 2)
     ids = torch.tensor([0, 1, 1])
-    with pytest.raises(NotImplementedError, match="CPU"):
-        torch_ops.ops.segment_sum(x, ids, 2)
+    assert torch_ops.ops.segment_sum(x, ids, 2).tolist() == [[1.0, 1.0], [2.0, 2.0]]
+    host = gammagl_amd.host_engine()
+    assert host.cpu_only and host.lib is _lib.host_lib() and gammagl_amd.engine(x) is host
+    assert os.path.basename(_lib.HOST_LIB_PATH) == "libggl_mpops_host.so"
+    # the reference's own known answers through the shipped CPU key, all three reductions
+    g = golden["kat"]
+    idx = torch.from_numpy(g["idx"].copy())
+    for op, fn in (("sum", torch_ops.ops.segment_sum), ("mean", torch_ops.ops.segment_mean)):
+        xk = torch.from_numpy(g[f"{op}_float32_d2_x"].copy())
+        np.testing.assert_array_equal(fn(xk, idx, 2).numpy(), g[f"{op}_float32_d2_y"])
+    xk = torch.from_numpy(g["max_float32_d2_x"].copy())
+    np.testing.assert_array_equal(torch_ops.ops.segment_max(xk, idx, 2)[0].numpy(), g["max_float32_d2_y"])
     # every op of the reference's pybind module has a dispatcher schema
     for name in ("segment_sum", "segment_mean", "segment_max", "spmm_sum", "spmm_mean", "spmm_max",
                  "bspmm_sum", "gat_fused", "bias_act"):
