@@ -236,15 +236,25 @@ static inline size_t dtype_size(int dtype) {
   }
 }
 
-// block id -> logical block id so that each XCD (block b runs on XCD b % 8, observed) owns a
-// contiguous range of row blocks: neighbouring rows of a locality-ordered graph then share one
-// private 4 MiB L2.  Pure performance: any mapping is correct.  (guide §5.5 T1)
+// block id -> logical block id so that the blocks one XCD executes (block b runs on XCD b % 8, observed) cover RUNS of
+// consecutive row blocks: neighbouring rows of a locality-ordered graph then share one private 4 MiB L2 instead of
+// being dealt round-robin to all eight.  swizzle = 1: one contiguous eighth of the launch per XCD (4x slower on a
+// degree-ordered graph: one XCD inherits every heavy row); swizzle = B >= 2: runs of B consecutive blocks, the eight
+// XCDs working on eight adjacent runs (balanced whatever the order).  Pure performance: any bijection is correct.
+// (guide §5.5 T1)
 __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb, int swizzle) {
   if (!swizzle) return b;
-  const int64_t per = nb >> 3;
-  const int64_t main_blocks = per << 3;
-  if (b >= main_blocks) return b;  // ragged tail keeps identity
-  return (b & 7) * per + (b >> 3);
+  if (swizzle == 1) {
+    const int64_t per = nb >> 3;
+    const int64_t main_blocks = per << 3;
+    if (b >= main_blocks) return b;  // ragged tail keeps identity
+    return (b & 7) * per + (b >> 3);
+  }
+  const int64_t B = swizzle;
+  const int64_t main_blocks = (nb / (8 * B)) * (8 * B);
+  if (b >= main_blocks) return b;
+  const int64_t xcd = b & 7, k = b >> 3;          // the k-th block this XCD executes
+  return ((k / B) * 8 + xcd) * B + (k % B);
 }
 
 }  // namespace ggl

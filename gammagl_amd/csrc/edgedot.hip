@@ -9,10 +9,12 @@
 // SpMM — the same gather volume — takes 16.4 ms.
 //
 // Here the loads are coalesced and the transposition happens in LDS: a workgroup owns 256 consecutive items of the
-// DESTINATION-SORTED order (so the g strips of a batch are a handful of rows, L1/L2 hits; only x[src] is a random
-// gather, exactly as in the forward walk), stages 32-column slabs of the items' x and g strips into two LDS tiles with
-// 16-byte loads in which 8 consecutive lanes cover 128 contiguous bytes, and then every lane folds ITS item's 32
-// products in order from LDS (row stride 36 floats: the 16-byte reads of a 16-lane pass fall into distinct banks).
+// DESTINATION-SORTED order (so the g strips of a batch are a handful of rows: each lane reads its own straight from
+// memory and L1 serves the lanes that share a row; only x[src] is a random gather, exactly as in the forward walk),
+// stages 32-column slabs of the items' x strips into an LDS tile with 16-byte loads in which 8 consecutive lanes cover
+// 128 contiguous bytes — the next slab's loads in flight while the current one is folded — and every lane folds ITS
+// item's 32 products in order from LDS (row stride 36 floats: the 16-byte reads of a 16-lane pass fall into distinct
+// banks).
 // Results go to gw[perm[p], h], the caller's edge order.  A launch may cover a column range [c_lo, c_hi) only,
 // taking the chain so far from `carry_in` and leaving it in `carry_out` (both in SORTED order: coalesced): the host
 // runs wide heads as launches over 64-column blocks like the forward (launch_f32_cols, reduce.hip) — same serial
@@ -25,41 +27,58 @@ constexpr int kDotQ = 8;                 // float4s per strip per slab: 32 colum
 constexpr int kDotLd = kDotQ * 4 + 4;    // tile row stride in floats (36: conflict-free 16-byte reads)
 
 #ifndef GGL_EMULATE
-// one slab of NQ float4s per strip: stage the 256 items' x and g pieces (all 2 * NQ loads of a thread in flight
-// together, registers only: NQ is a compile-time constant so nothing is indexed at run time), then fold this lane's own
-// item in channel order
+// One slab = NQ float4s (4 NQ columns) of every item's x strip.  NQ is a compile-time constant: the slab lives in
+// registers between its loads and its LDS stores, nothing is indexed at run time (the first version indexed a shared
+// register array under a run-time bound and the backend put it in scratch memory: 2x slower than the kernel it replaced).
 template <int NQ>
-__device__ __forceinline__ float dot_slab(int tid, const int64_t *sx, const int64_t *sg, const float *__restrict__ x,
-                                          const float *__restrict__ g, int64_t c0, float (*tx)[kDotLd],
-                                          float (*tg)[kDotLd], float acc) {
-  float4 vx[NQ], vg[NQ];
+__device__ __forceinline__ void slab_load(int tid, const int64_t *sx, const float *__restrict__ x, int64_t c0,
+                                          float4 (&v)[NQ]) {
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;   // 8 consecutive lanes = 128 contiguous bytes
+    const int64_t ox = sx[item];
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ox >= 0) v[j] = *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4);
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void slab_store(int tid, const float4 (&v)[NQ], float (*tx)[kDotLd]) {
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;
-    const int64_t ox = sx[item], og = sg[item];
-    vx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    vg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ox >= 0) {   // (an item past the end of the list: only in the last workgroup)
-      vx[j] = *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4);
-      vg[j] = *reinterpret_cast<const float4 *>(g + og + c0 + part * 4);
-    }
+    *reinterpret_cast<float4 *>(&tx[item][part * 4]) = v[j];
   }
+}
+// this lane's own item: its x slab from LDS, its g slab straight from memory (the g strips of a batch of sorted
+// positions are a handful of destination rows: lanes that share a row read the same addresses, L1 serves them)
+template <int NQ>
+__device__ __forceinline__ float slab_fold(int tid, float (*tx)[kDotLd], const float *__restrict__ gp, bool valid,
+                                           float acc) {
+  float4 gg[NQ];
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) {
-    const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;
-    *reinterpret_cast<float4 *>(&tx[item][part * 4]) = vx[j];
-    *reinterpret_cast<float4 *>(&tg[item][part * 4]) = vg[j];
+  for (int k = 0; k < NQ; ++k) {
+    gg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) gg[k] = *reinterpret_cast<const float4 *>(gp + k * 4);
   }
-  __syncthreads();
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     const float4 a = *reinterpret_cast<const float4 *>(&tx[tid][k * 4]);
-    const float4 b = *reinterpret_cast<const float4 *>(&tg[tid][k * 4]);
-    acc = __fadd_rn(acc, __fmul_rn(a.x, b.x));
-    acc = __fadd_rn(acc, __fmul_rn(a.y, b.y));
-    acc = __fadd_rn(acc, __fmul_rn(a.z, b.z));
-    acc = __fadd_rn(acc, __fmul_rn(a.w, b.w));
+    acc = __fadd_rn(acc, __fmul_rn(a.x, gg[k].x));
+    acc = __fadd_rn(acc, __fmul_rn(a.y, gg[k].y));
+    acc = __fadd_rn(acc, __fmul_rn(a.z, gg[k].z));
+    acc = __fadd_rn(acc, __fmul_rn(a.w, gg[k].w));
   }
+  return acc;
+}
+template <int NQ>
+__device__ __forceinline__ float slab_tail(int tid, const int64_t *sx, const float *__restrict__ x,
+                                           const float *__restrict__ gp, bool valid, int64_t c0, float (*tx)[kDotLd],
+                                           float acc) {
+  float4 v[NQ];
+  slab_load<NQ>(tid, sx, x, c0, v);
+  slab_store<NQ>(tid, v, tx);
+  __syncthreads();
+  acc = slab_fold<NQ>(tid, tx, gp + c0, valid, acc);
   __syncthreads();
   return acc;
 }
@@ -68,9 +87,8 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
     const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const int32_t *__restrict__ perm,
     const float *__restrict__ x, const float *__restrict__ g, int64_t total, int64_t H, int64_t C, int64_t c_lo,
     int64_t c_hi, const float *__restrict__ carry_in, float *__restrict__ carry_out, float *__restrict__ gw) {
-  __shared__ __attribute__((aligned(16))) float tx[kBlock][kDotLd];
-  __shared__ __attribute__((aligned(16))) float tg[kBlock][kDotLd];
-  __shared__ int64_t sx[kBlock], sg[kBlock];
+  __shared__ __attribute__((aligned(16))) float tx[kBlock][kDotLd];   // 36 KiB: four workgroups per CU
+  __shared__ int64_t sx[kBlock];
   const int tid = threadIdx.x;
   const int64_t base = block_id() * (int64_t)kBlock;
   if (base >= total) return;
@@ -82,19 +100,32 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
     h = i - p * H;
   }
   sx[tid] = valid ? ((int64_t)col[p] * H + h) * C : (int64_t)-1;
-  sg[tid] = valid ? ((int64_t)rowidx[p] * H + h) * C : (int64_t)-1;
+  const float *gp = g + (valid ? ((int64_t)rowidx[p] * H + h) * C : 0);
   float acc = (valid && carry_in) ? carry_in[i] : 0.0f;   // the chain so far (sorted order: coalesced)
   __syncthreads();
   int64_t c0 = c_lo;
-  for (; c0 + kDotQ * 4 <= c_hi; c0 += kDotQ * 4) acc = dot_slab<kDotQ>(tid, sx, sg, x, g, c0, tx, tg, acc);
+  const int64_t n_full = (c_hi - c_lo) / (kDotQ * 4);
+  if (n_full > 0) {
+    // software pipeline over the full slabs: slab s + 1 is in flight while slab s is folded
+    float4 cur[kDotQ];
+    slab_load<kDotQ>(tid, sx, x, c0, cur);
+    for (int64_t s = 0; s < n_full; ++s) {
+      slab_store<kDotQ>(tid, cur, tx);
+      __syncthreads();
+      if (s + 1 < n_full) slab_load<kDotQ>(tid, sx, x, c0 + kDotQ * 4, cur);
+      acc = slab_fold<kDotQ>(tid, tx, gp + c0, valid, acc);
+      __syncthreads();
+      c0 += kDotQ * 4;
+    }
+  }
   switch ((int)((c_hi - c0) >> 2)) {   // the last, narrower slab (block-uniform)
-    case 7: acc = dot_slab<7>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
-    case 6: acc = dot_slab<6>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
-    case 5: acc = dot_slab<5>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
-    case 4: acc = dot_slab<4>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
-    case 3: acc = dot_slab<3>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
-    case 2: acc = dot_slab<2>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
-    case 1: acc = dot_slab<1>(tid, sx, sg, x, g, c0, tx, tg, acc); break;
+    case 7: acc = slab_tail<7>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 6: acc = slab_tail<6>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 5: acc = slab_tail<5>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 4: acc = slab_tail<4>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 3: acc = slab_tail<3>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 2: acc = slab_tail<2>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 1: acc = slab_tail<1>(tid, sx, x, gp, valid, c0, tx, acc); break;
     default: break;
   }
   if (!valid) return;

@@ -27,18 +27,30 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ?
 __device__ __forceinline__ uint32_t pick_word(const U4 &u, int c) {
   return c == 0 ? u.x : (c == 1 ? u.y : (c == 2 ? u.z : u.w));
 }
-// Attention-dropout word of (sorted position p, head h): a counter-based 32-bit mix of (seed, offset, p * H + h)
-// with xxHash32's avalanche as the finaliser (~15 VALU instructions).  Round 1 drew these from Philox4x32-10
-// (one 4-word block per four positions); the backward's source walks meet forward positions in scattered order
-// and had to run the full ten rounds per edge for one word — 2.6-3.2 ms of a 5-9 ms walk on the Reddit-sized
-// graph.  Dropout masks need decorrelation, not cryptographic strength; the layer epilogue's dropout
-// (epilogue.hip, reduce.hip) stays on Philox.  The host restatement lives in tests/parity_cases.py.
+// Attention-dropout word of (sorted position p, head h): counter-based, ~15 VALU instructions per word.
+// Round 1 drew these from Philox4x32-10 (one 4-word block per four positions); the backward's source walks meet forward
+// positions in scattered order and had to run the full ten rounds per edge for one word — 2.6-3.2 ms of a 5-9 ms
+// walk on the Reddit-sized graph.  Dropout masks need decorrelation, not cryptographic strength.  The (seed, offset)
+// pair of a launch goes through splitmix64 ONCE (loop-invariant: the compiler keeps it in scalar registers) to give a
+// 64-bit launch key; the word is a two-round keyed mix of the 64-bit index: multiply-xorshift with the key's low half,
+// the index's high half and the key's high half folded in before the second multiply, xxHash32's avalanche as the
+// finaliser.  Consecutive steps (offset + 1) get unrelated keys in BOTH rounds, so their masks are not related by a
+// constant XOR of the pre-avalanche value (round 2's generator: advisor finding), and no index bit is dropped.
+// The layer epilogue's dropout (epilogue.hip, reduce.hip) stays on Philox.  Host restatement + the statistical test
+// (keep rate, step-to-step and neighbour correlation, bit balance): tests/parity_cases.py gat_drop_word /
+// check_drop_word_statistics.
+__device__ __forceinline__ uint64_t drop_key(uint64_t offset, uint64_t seed) {
+  uint64_t z = seed + offset * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
 __device__ __forceinline__ uint32_t drop_word(int64_t p, int64_t H, int64_t h, uint64_t offset, uint64_t seed) {
   const uint64_t idx = (uint64_t)(p * H + h);
-  uint32_t x = ((uint32_t)idx * 0x9E3779B1u) ^ (uint32_t)seed;
-  x ^= ((uint32_t)(idx >> 32) + (uint32_t)offset) * 0x85EBCA77u;
-  x ^= ((uint32_t)(offset >> 32) ^ (uint32_t)(seed >> 32)) * 0xC2B2AE3Du;
-  x ^= x >> 15; x *= 0x85EBCA77u;
+  const uint64_t key = drop_key(offset, seed);
+  uint32_t x = ((uint32_t)idx ^ (uint32_t)key) * 0x9E3779B1u;
+  x ^= x >> 15;
+  x = (x ^ (uint32_t)(idx >> 32) ^ (uint32_t)(key >> 32)) * 0x85EBCA77u;
   x ^= x >> 13; x *= 0xC2B2AE3Du;
   x ^= x >> 16;
   return x;

@@ -598,15 +598,21 @@ class DistGCNTrainer:
         self.opt.step()
         return loss.detach()
 
-    def capture(self, x_local, y_local, train_local, n_train_global, warmup=3):
-        """Record step(...) on these very tensors into one hipGraph (single rank, `capturable=True`); afterwards
-        `replay()` runs a training step — the kernels never sync or allocate outside the graph's pool, the side
-        stream's weight-gradient GEMMs and the dropout draws (state advanced on the device) are part of it."""
-        if self.pg.world > 1:
-            raise RuntimeError("capture() records a single-rank step (the exchange is not recorded into the graph)")
+    def capture(self, x_local, y_local, train_local, n_train_global, warmup=3, collectives=False):
+        """Record step(...) on these very tensors into one hipGraph (`capturable=True`); afterwards `replay()` runs a
+        training step — the kernels never sync or allocate outside the graph's pool, the side stream's weight-gradient
+        GEMMs and the dropout draws (state advanced on the device) are part of it.  A step that exchanges halos
+        (world > 1, or the single-GPU self-halo group) contains RCCL collectives: pass `collectives=True` to record
+        them too (RCCL >= 2.26 captures its kernels; the exchange runs on persistent buffers, a precondition).  That is
+        opt-in: it has been exercised on ONE GPU only (tests/test_gpu_parity.py, world-size-1 RCCL group) — every rank
+        must capture and replay in lockstep."""
+        if self.pg.comm and not self.pg.dry and not collectives:
+            raise RuntimeError("this step exchanges halos through RCCL: capture(..., collectives=True) records the "
+                               "collectives into the graph as well (opt-in, see the docstring)")
         from .trainer import GraphedStep
 
-        self.graph = GraphedStep(lambda: self.step(x_local, y_local, train_local, n_train_global), warmup=warmup)
+        self.graph = GraphedStep(lambda: self.step(x_local, y_local, train_local, n_train_global), warmup=warmup,
+                                 capture_error_mode="thread_local" if collectives else "global")
         return self.graph
 
     def replay(self):

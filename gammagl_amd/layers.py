@@ -219,6 +219,12 @@ class GCNConv(MessagePassing):
 
 
 class SAGEConv(MessagePassing):
+    """layers/conv/sage_conv.py.  ASSOCIATION: the reference always transforms first, mean(fc_neigh(x_src))
+    (sage_conv.py:100).  With aggr='mean', f32 features and a layer whose input is NARROWER than its output this
+    class computes fc_neigh(mean(x_src)) instead — the same product associated the cheap way round (the rule DGL's
+    SAGEConv applies): results then agree with the reference to f32 rounding (1e-5 relative), not bit for bit.
+    Set `gammagl_amd.layers.SAGE_FUSE_EPILOGUE = False` for the reference's order of operations throughout."""
+
     def __init__(self, in_channels, out_channels, activation=None, aggr="mean", add_bias=True):
         super().__init__()
         self.aggr = aggr
@@ -272,19 +278,21 @@ class SAGEConv(MessagePassing):
                     out = eng.bias_act(out, self.bias, relu=self.act is not None)
                 return out
             src_feat = self.fc_neigh(src_feat)
-            if SAGE_FUSE_EPILOGUE and src_feat.dim() == 2 and src_feat.dtype == torch.float32 and fused_act:
+            big = edge.shape[1] >= FUSED_MIN_EDGES
+            # (a small block whose width is not a multiple of 4 — e.g. the 47-class output layer — has no fused form:
+            # it goes straight to propagate() below without computing fc_self / the gather here first and again there)
+            if (SAGE_FUSE_EPILOGUE and src_feat.dim() == 2 and src_feat.dtype == torch.float32 and fused_act
+                    and (big or src_feat.shape[1] % 4 == 0)):
                 # "mean + fc_self(x_dst) + bias -> act" (sage_conv.py:100-108) rides on the aggregate's store:
                 # the fused rectangular SpMM-mean for big edge lists, the segment route for sampled blocks
                 eng = _engine(src_feat)
                 self_term = self.fc_self(dst_feat)
-                if edge.shape[1] >= FUSED_MIN_EDGES:
+                if big:
                     gp = eng.graph_plan(edge, num_nodes, int(src_feat.shape[0]))
                     return eng.spmm_epi(gp, None, src_feat, "mean", add=self_term, bias=self.bias,
                                         relu=self.act is not None)
-                msg = src_feat.index_select(0, edge[0])
-                if src_feat.shape[1] % 4 == 0:
-                    return eng.segment_epi(msg, edge[1], num_nodes, "mean", add=self_term, bias=self.bias,
-                                           relu=self.act is not None)
+                return eng.segment_epi(src_feat.index_select(0, edge[0]), edge[1], num_nodes, "mean", add=self_term,
+                                       bias=self.bias, relu=self.act is not None)
             # (propagate picks the fused SpMM-mean for big edge lists, the segment route for sampled blocks)
             out = self.propagate(src_feat, edge, edge_weight=None, num_nodes=num_nodes, aggr='mean')
         elif self.aggr == 'gcn':

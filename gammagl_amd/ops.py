@@ -104,11 +104,14 @@ class GraphPlan:
         for nm, ptr in (("row_ptr", row_ptr), ("col_ptr", col_ptr)):   # one-off (per plan) host reads
             if int(ptr[0]) != 0 or int(ptr[-1]) != gp.E or (ptr.numel() > 1 and bool((ptr[1:] < ptr[:-1]).any())):
                 raise RuntimeError(f"{nm} must rise from 0 to the number of edges ({gp.E})")
-        gp.fwd = engine.plan_from_rowptr(row_ptr, gp.E)
-        gp.col = col_ind.to(torch.int32).contiguous()
-        gp._bwd = engine.plan_from_rowptr(col_ptr, gp.E)
-        gp._colT = row_ind.to(torch.int32).contiguous()
-        gp._posT = permute.to(torch.int32).contiguous()
+        def own_i32(t):   # the plan keeps ITS OWN int32 copy: a later in-place edit of the caller's tensor cannot reach it
+            return t.to(torch.int32).contiguous() if t.dtype != torch.int32 else t.clone().contiguous()
+
+        gp.fwd = engine.plan_from_rowptr(row_ptr.clone() if row_ptr.dtype == torch.int64 else row_ptr, gp.E)
+        gp.col = own_i32(col_ind)
+        gp._bwd = engine.plan_from_rowptr(col_ptr.clone() if col_ptr.dtype == torch.int64 else col_ptr, gp.E)
+        gp._colT = own_i32(row_ind)
+        gp._posT = own_i32(permute)
         gp._rowidx = None
         gp.aux = {}
         return gp
@@ -462,8 +465,13 @@ class Engine:
         n_cols = int(col_ptr.shape[0]) - 1 if n_cols is None else int(n_cols)
         extra = ("csr", n_rows, n_cols, self.chunk) + tuple(_PlanCache.key(t, ()) for t in (col_ind, col_ptr, row_ind, permute))
         gp = self.graph_cache.get(row_ptr, extra)
+        if gp is not None and any(r.expired() for r in gp.aux.get("_csr_refs", ())):
+            # one of the four other tensors died: its storage address (part of the key) may since have been handed to
+            # a different tensor of the same shape — identity + version cannot tell, so this is a miss
+            gp = None
         if gp is None:
             gp = GraphPlan.from_csr(self, row_ptr, col_ind, col_ptr, row_ind, permute, n_rows, n_cols)
+            gp.aux["_csr_refs"] = tuple(StorageWeakRef(t.untyped_storage()) for t in (col_ind, col_ptr, row_ind, permute))
             self.graph_cache.put(row_ptr, extra, gp)
         else:
             self.stats["plan_hits"] += 1

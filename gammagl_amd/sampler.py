@@ -19,6 +19,7 @@ from .ops import _ptr
 
 
 _BIG = 1 << 62
+EXACT_HOP_MAX_SLOTS = 1 << 26   # seeds x fan-out up to which NeighborSampler.sample runs a hop at worst-case capacity (4 GB)
 
 
 def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_pos=None):
@@ -136,7 +137,10 @@ class NeighborSampler:
         n_id, adjs = batch, []
         for size in self.sizes:
             n_dst = int(n_id.shape[0])
-            if size > 0 and n_dst > 0 and n_dst * size < (1 << 30):
+            # the static-shape hop allocates WORST-CASE buffers (~60 bytes per seed x fan-out slot) before the counts are
+            # known: fine for mini-batches, not for a layer-wise inference batch of tens of millions of seeds, which
+            # keeps the count-then-pick path whose buffers are sized by the actual min(deg, fan-out)
+            if size > 0 and n_dst > 0 and n_dst * size <= EXACT_HOP_MAX_SLOTS:
                 rowptr, col, n_id, e_pos = self._hop_exact(n_id.contiguous(), size)
             else:
                 rowptr, col, n_id, e_pos = sample_adj(self.rowptr, self.col, n_id, size, replace=False, eng=self.eng,

@@ -38,7 +38,9 @@ class GraphedStep:
     few eager warm-up steps run first; the captured step reads its inputs from the tensors it was
     captured with (update them in place)."""
 
-    def __init__(self, step_fn, warmup=3):
+    def __init__(self, step_fn, warmup=3, capture_error_mode="global"):
+        """`capture_error_mode="thread_local"`: for steps that contain RCCL collectives — the process group's watchdog
+        thread polls events while the capture is open, which the default global mode treats as a capture violation."""
         self.step_fn = step_fn
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -48,7 +50,7 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.out = step_fn()
 
     def __call__(self):

@@ -438,21 +438,54 @@ def philox4x32_10(index, offset, seed):
 
 
 def gat_drop_word(index, offset, seed):
-    """numpy restatement of gat.hip drop_word: the attention-dropout word of counter index = p * H + h."""
+    """numpy restatement of gat_common.hpp drop_word: the attention-dropout word of counter index = p * H + h."""
+    m64 = (1 << 64) - 1
+    z = (int(seed) + int(offset) * 0x9E3779B97F4A7C15) & m64        # drop_key: splitmix64 of the launch's (seed, offset)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
+    z ^= z >> 31
+    k0, k1 = np.uint64(z & 0xFFFFFFFF), np.uint64(z >> 32)
     idx = np.asarray(index, dtype=np.uint64)
     m32 = np.uint64(0xFFFFFFFF)
-    lo, hi = (idx & m32).astype(np.uint64), (idx >> np.uint64(32)).astype(np.uint64)
-    off_lo, off_hi = np.uint64(offset) & m32, (np.uint64(offset) >> np.uint64(32)) & m32
-    sd_lo, sd_hi = np.uint64(seed) & m32, (np.uint64(seed) >> np.uint64(32)) & m32
-    x = ((lo * np.uint64(0x9E3779B1)) & m32) ^ sd_lo
-    x ^= (((hi + off_lo) & m32) * np.uint64(0x85EBCA77)) & m32
-    x ^= ((off_hi ^ sd_hi) * np.uint64(0xC2B2AE3D)) & m32
+    lo, hi = idx & m32, idx >> np.uint64(32)
+    x = ((lo ^ k0) * np.uint64(0x9E3779B1)) & m32
     x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x85EBCA77)) & m32
+    x = ((x ^ hi ^ k1) * np.uint64(0x85EBCA77)) & m32
     x ^= x >> np.uint64(13)
     x = (x * np.uint64(0xC2B2AE3D)) & m32
     x ^= x >> np.uint64(16)
     return x.astype(np.uint32)
+
+
+def check_drop_word_statistics():
+    """The attention-dropout generator as a random source (host restatement; the device kernels are held to it word
+    for word by check_gat_dropout): keep rate at the thresholds the layers use, no correlation between the masks of
+    consecutive steps (offset, offset + 1) or of neighbouring indices, every output bit balanced, indices that differ
+    only above bit 32 get different words."""
+    n = 1 << 20
+    idx = np.arange(n, dtype=np.uint64)
+    tol = 5.0 / np.sqrt(n)
+    for seed in (0, 1, 0x123456789ABCDEF, (1 << 62) - 3):
+        w0 = gat_drop_word(idx, 7, seed)
+        w1 = gat_drop_word(idx, 8, seed)
+        for pd in (0.1, 0.5, 0.6):
+            t = np.uint32(int(pd * 4294967296.0))
+            k0, k1 = (w0 >= t).astype(np.float64), (w1 >= t).astype(np.float64)
+            assert abs(k0.mean() - (1 - pd)) < tol and abs(k1.mean() - (1 - pd)) < tol, (seed, pd, k0.mean())
+            c_steps = np.corrcoef(k0, k1)[0, 1]                      # step n vs step n + 1, same positions
+            c_neigh = np.corrcoef(k0[:-1], k0[1:])[0, 1]              # position p vs p + 1, same step
+            c_head = np.corrcoef(k0[:-8], k0[8:])[0, 1]               # (p, h) vs (p + 1, h) with 8 heads
+            assert abs(c_steps) < tol and abs(c_neigh) < tol and abs(c_head) < tol, (seed, pd, c_steps, c_neigh, c_head)
+        bits = ((w0[:, None] >> np.arange(32, dtype=np.uint32)) & 1).mean(0)
+        assert np.abs(bits - 0.5).max() < tol, (seed, bits)
+        # the XOR of two steps' words is itself balanced (round 2's generator related them through one constant)
+        xb = (((w0 ^ w1)[:, None] >> np.arange(32, dtype=np.uint32)) & 1).mean(0)
+        assert np.abs(xb - 0.5).max() < tol
+        hi = gat_drop_word(idx[:4096] + np.uint64(1 << 32), 7, seed)
+        assert (hi != w0[:4096]).mean() > 0.99
+    # a different seed or offset changes about half of the keep decisions
+    a, b = gat_drop_word(idx, 0, 5) >= np.uint32(1 << 31), gat_drop_word(idx, 0, 6) >= np.uint32(1 << 31)
+    assert abs((a != b).mean() - 0.5) < tol
 
 
 def check_gat_dropout(eng, dev, oracle):

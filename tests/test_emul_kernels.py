@@ -71,6 +71,10 @@ def test_bspmm_wide_heads(eng):
     pc.check_bspmm_wide(eng, DEV)
 
 
+def test_attention_dropout_words_are_a_sound_random_source():
+    pc.check_drop_word_statistics()
+
+
 def test_half_precision_ragged_rows(eng, oracle):
     pc.check_half_ragged_rows(eng, DEV, oracle)
 

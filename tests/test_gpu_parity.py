@@ -130,9 +130,17 @@ def test_plan_cache(eng, dev):
     pc.check_plan_cache(eng, dev)
 
 
-def test_cpu_tensors_are_refused(eng):
-    with pytest.raises(RuntimeError, match="MI355X only"):
+def test_engines_never_take_the_other_devices_tensors(eng, dev):
+    """The MI355X engine refuses CPU tensors and the host build refuses GPU tensors: nothing is moved between devices
+    behind the caller's back, and a GPU tensor's result can only ever come from the HIP library."""
+    import gammagl_amd
+
+    with pytest.raises(RuntimeError, match="MI355X engine"):
         eng.c_segment_sum(torch.ones(3, 2), torch.tensor([0, 1, 1]), 2)
+    host = gammagl_amd.host_engine()
+    with pytest.raises(RuntimeError, match="host build"):
+        host.c_segment_sum(torch.ones(3, 2, device=dev), torch.tensor([0, 1, 1], device=dev), 2)
+    assert gammagl_amd.engine(torch.ones(1, device=dev)) is eng and gammagl_amd.engine(torch.ones(1)) is host
 
 
 def test_mpops_surface_matches_reference_names(eng, dev):
@@ -157,7 +165,8 @@ def test_mpops_surface_matches_reference_names(eng, dev):
 
 def test_torch_ops_dispatch_to_hip(eng, dev, oracle):
     """torch.ops.gammagl_amd.* (torch_ops.py): HIP kernels for CUDA tensors, autograd through the
-    dispatcher, schema / fake-tensor / autograd-registration checks, no CPU kernel."""
+    dispatcher, schema / fake-tensor / autograd-registration checks; CPU tensors dispatch to the host build of the
+    same kernel sources (same bits on rows reduced in one piece)."""
     from gammagl_amd import torch_ops
 
     ops = torch_ops.ops
@@ -181,8 +190,7 @@ def test_torch_ops_dispatch_to_hip(eng, dev, oracle):
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(xnd.grad.cpu().numpy(), refg, rtol=1e-5, atol=1e-5)
     assert torch.equal(y.detach(), eng.c_spmm_sum(eid, wd, xnd.detach()))  # same kernel either way
-    with pytest.raises(NotImplementedError, match="CPU"):
-        ops.segment_sum(x, ei[1], 300)
+    np.testing.assert_array_equal(ops.segment_sum(x, ei[1], 300).numpy(), oracle.segment_sum(x.numpy(), ei[1].numpy(), 300))
     utils = ("test_schema", "test_faketensor", "test_autograd_registration")
     torch.library.opcheck(ops.segment_sum.default, (xd.clone().requires_grad_(), eid[1], 300), test_utils=utils)
     torch.library.opcheck(ops.spmm_sum.default, (eid, wd, xnd.detach().requires_grad_()), test_utils=utils)
@@ -847,3 +855,51 @@ def test_partitioned_trainer_step_captures_into_a_hipgraph(eng, dev):
         assert all(v == v for v in seq) and seq[-1] < 0.7 * seq[0]
         assert len(set(seq)) > 30                                    # fresh masks: no two replays repeat
     assert abs(losses["graph"][-1] - losses["eager"][-1]) < 0.25 * losses["eager"][0]
+
+
+def test_halo_step_with_rccl_collectives_captures_into_a_hipgraph(eng, dev):
+    """The step WITH its halo exchange recorded: a world-size-1 RCCL group where the upper half of the rows is treated
+    as remote, so every aggregate issues real all-to-all-v collectives (forward and reverse) on the persistent
+    exchange buffers; capture(collectives=True) records them with the kernels, and the replayed steps train like the
+    eager ones (dropout off: same losses to rounding)."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from gammagl_amd.dist import DistGCNTrainer, PartitionedGraph
+    from gammagl_amd.synth import homophilous_graph
+
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x, y, ei = homophilous_graph(6000, 32, 7, deg=6, seed=3, device=dev)
+        ei = torch.cat([ei, torch.arange(x.shape[0], device=dev).repeat(2, 1)], 1)
+        n = x.shape[0]
+        deg = torch.bincount(ei[1], minlength=n).float().clamp(min=1)
+        w = deg.pow(-0.5)[ei[0]] * deg.pow(-0.5)[ei[1]]
+        pg = PartitionedGraph(ei, w, n, 0, 1, eng=eng, self_halo_from=n // 2)
+        assert pg.comm and pg.n_halo > 0 and not pg.dry
+        idx = torch.arange(0, n, 2, device=dev)
+        losses = {}
+        for mode in ("eager", "graph"):
+            tr = DistGCNTrainer(pg, 32, 64, 7, num_layers=3, drop_rate=0.0, seed=2, device=dev, capturable=(mode == "graph"))
+            if mode == "graph":
+                with pytest.raises(RuntimeError, match="collectives"):
+                    tr.capture(x, y, idx, idx.numel())
+                tr.capture(x, y, idx, idx.numel(), warmup=3, collectives=True)      # 3 eager steps + the recorded one
+                seq = [float(tr.replay()) for _ in range(20)]
+            else:
+                for _ in range(4):
+                    tr.step(x, y, idx, idx.numel())
+                seq = [float(tr.step(x, y, idx, idx.numel())) for _ in range(20)]
+            losses[mode] = seq
+        for a, b in zip(losses["eager"], losses["graph"]):
+            assert abs(a - b) <= 1e-3 * abs(a) + 1e-5, (a, b)
+        assert losses["graph"][-1] < 0.8 * losses["graph"][0]
+    finally:
+        dist.destroy_process_group()

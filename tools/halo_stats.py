@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gammagl_amd import engine  # noqa: E402
 from gammagl_amd.partition import cluster_order, halo_stats, relabel_edges  # noqa: E402
-from gammagl_amd.synth import DATASETS, homophilous_graph, rmat_graph  # noqa: E402
+from gammagl_amd.synth import DATASETS, rmat_graph  # noqa: E402
 
 dev = torch.device("cuda", 0)
 eng = engine()
@@ -48,15 +48,16 @@ del ei
 ei = rmat_graph(n, e, seed=0, device=dev, relabel="none")
 report("generator's natural order", ei, n)
 del ei
+from gammagl_amd.synth import PLANTED_LEVELS, planted_pairs  # noqa: E402
+
 deg = max(2, e // (2 * n))
-print(f"(b) planted communities: N={n}, 64 classes, {deg} out-edges per node, 85 % inside the class, random ids")
-_, y, ei = homophilous_graph(n, 64, 64, deg=deg, p_same=0.85, seed=0, device=dev)
+print(f"(b) hierarchical planted communities: N={n}, levels (groups, share of a node's edges inside) = {PLANTED_LEVELS}, "
+      f"{deg} out-edges per node, random ids")
+s_, d_ = planted_pairs(n, out_deg=deg, seed=0, device=dev)
+nat = torch.stack([s_, d_])
 pi = torch.randperm(n, device=dev)
-ei = torch.stack([pi[ei[0]], pi[ei[1]]])
+ei = torch.stack([pi[s_], pi[d_]]).contiguous()
+del s_, d_
 report("random ids", ei, n)
-report("cluster_order on random ids", clustered(ei, n, 256), n)
-inv = torch.empty_like(pi)
-inv[pi] = torch.arange(n, device=dev)
-rank_true = torch.empty(n, dtype=torch.int64, device=dev)
-rank_true[torch.argsort(y[inv] * n + torch.arange(n, device=dev))] = torch.arange(n, device=dev)
-report("oracle order (the planted classes)", relabel_edges(ei, rank_true), n)
+report("cluster_order on random ids", clustered(ei, n, max(8, min(1024, n // 2400))), n)
+report("oracle order (the generator's own labelling)", nat, n)

@@ -47,7 +47,7 @@ for kind, relabel in (("rmat", "random"), ("rmat", "degree"), ("planted", "rando
     for K in (256, 64):
         x = torch.randn(n, K, generator=g, device=dev)
         out = torch.empty(n, K, device=dev)
-        for win, swz in ((0, 0), (512, 0), (2048, 0), (8192, 0), (32768, 0), (2048, 1), (-1, 0)):
+        for win, swz in ((0, 0), (2048, 0), (2048, 8), (2048, 32), (2048, 128), (2048, 512), (8192, 128)):
             eng.clear_caches()
             eng.row_order_window = max(win, 0)
             eng.set_option("xcd_swizzle", swz)
