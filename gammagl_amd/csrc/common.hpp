@@ -226,6 +226,10 @@ template <> struct TT<bf16_t> {
   static __device__ __forceinline__ A div(A a, A c) { return bf16_to_f32(f32_to_bf16(__fdiv_rn(a, c))); }
 };
 
+// eight 16-bit elements at a 2-byte aligned address as ONE 16-byte access (the backend emits global_load_dwordx4 for the
+// packed struct: unaligned access mode) — rows of f16 / bf16 whose width is not a multiple of 8 (reduce.hip, hub16.hip)
+struct __attribute__((packed, aligned(2))) H8U { uint16_t v[8]; };
+
 static inline size_t dtype_size(int dtype) {
   switch (dtype) {
     case GGL_U8: case GGL_I8: return 1;

@@ -23,8 +23,10 @@
 
 namespace ggl {
 
-constexpr int kDotQ = 8;                 // float4s per strip per slab: 32 columns
-constexpr int kDotLd = kDotQ * 4 + 4;    // tile row stride in floats (36: conflict-free 16-byte reads)
+// float4s per strip per slab: 8 (32 columns; tile row stride 36 floats: the 16-byte reads of a 16-lane pass fall into
+// distinct banks) — or 12 for heads of 33 .. 48 channels (41 classes padded to 44), which then are ONE slab with no
+// narrower remainder slab behind it
+template <int Q> struct DotTile { static constexpr int ld = Q * 4 + 4; };
 
 #ifndef GGL_EMULATE
 // One slab = NQ float4s (4 NQ columns) of every item's x strip.  NQ is a compile-time constant: the slab lives in
@@ -41,8 +43,8 @@ __device__ __forceinline__ void slab_load(int tid, const int64_t *sx, const floa
     if (ox >= 0) v[j] = *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4);
   }
 }
-template <int NQ>
-__device__ __forceinline__ void slab_store(int tid, const float4 (&v)[NQ], float (*tx)[kDotLd]) {
+template <int NQ, int LD>
+__device__ __forceinline__ void slab_store(int tid, const float4 (&v)[NQ], float (*tx)[LD]) {
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;
@@ -51,8 +53,8 @@ __device__ __forceinline__ void slab_store(int tid, const float4 (&v)[NQ], float
 }
 // this lane's own item: its x slab from LDS, its g slab straight from memory (the g strips of a batch of sorted
 // positions are a handful of destination rows: lanes that share a row read the same addresses, L1 serves them)
-template <int NQ>
-__device__ __forceinline__ float slab_fold(int tid, float (*tx)[kDotLd], const float *__restrict__ gp, bool valid,
+template <int NQ, int LD>
+__device__ __forceinline__ float slab_fold(int tid, float (*tx)[LD], const float *__restrict__ gp, bool valid,
                                            float acc) {
   float4 gg[NQ];
 #pragma unroll
@@ -70,24 +72,26 @@ __device__ __forceinline__ float slab_fold(int tid, float (*tx)[kDotLd], const f
   }
   return acc;
 }
-template <int NQ>
+template <int NQ, int LD>
 __device__ __forceinline__ float slab_tail(int tid, const int64_t *sx, const float *__restrict__ x,
-                                           const float *__restrict__ gp, bool valid, int64_t c0, float (*tx)[kDotLd],
+                                           const float *__restrict__ gp, bool valid, int64_t c0, float (*tx)[LD],
                                            float acc) {
   float4 v[NQ];
   slab_load<NQ>(tid, sx, x, c0, v);
-  slab_store<NQ>(tid, v, tx);
+  slab_store<NQ, LD>(tid, v, tx);
   __syncthreads();
-  acc = slab_fold<NQ>(tid, tx, gp + c0, valid, acc);
+  acc = slab_fold<NQ, LD>(tid, tx, gp + c0, valid, acc);
   __syncthreads();
   return acc;
 }
 
+template <int Q>
 __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
     const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const int32_t *__restrict__ perm,
     const float *__restrict__ x, const float *__restrict__ g, int64_t total, int64_t H, int64_t C, int64_t c_lo,
     int64_t c_hi, const float *__restrict__ carry_in, float *__restrict__ carry_out, float *__restrict__ gw) {
-  __shared__ __attribute__((aligned(16))) float tx[kBlock][kDotLd];   // 36 KiB: four workgroups per CU
+  constexpr int kDotQ = Q, kDotLd = DotTile<Q>::ld;
+  __shared__ __attribute__((aligned(16))) float tx[kBlock][kDotLd];   // Q = 8: 36 KiB, four workgroups per CU
   __shared__ int64_t sx[kBlock];
   const int tid = threadIdx.x;
   const int64_t base = block_id() * (int64_t)kBlock;
@@ -110,22 +114,26 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
     float4 cur[kDotQ];
     slab_load<kDotQ>(tid, sx, x, c0, cur);
     for (int64_t s = 0; s < n_full; ++s) {
-      slab_store<kDotQ>(tid, cur, tx);
+      slab_store<kDotQ, kDotLd>(tid, cur, tx);
       __syncthreads();
       if (s + 1 < n_full) slab_load<kDotQ>(tid, sx, x, c0 + kDotQ * 4, cur);
-      acc = slab_fold<kDotQ>(tid, tx, gp + c0, valid, acc);
+      acc = slab_fold<kDotQ, kDotLd>(tid, tx, gp + c0, valid, acc);
       __syncthreads();
       c0 += kDotQ * 4;
     }
   }
   switch ((int)((c_hi - c0) >> 2)) {   // the last, narrower slab (block-uniform)
-    case 7: acc = slab_tail<7>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 6: acc = slab_tail<6>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 5: acc = slab_tail<5>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 4: acc = slab_tail<4>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 3: acc = slab_tail<3>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 2: acc = slab_tail<2>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 1: acc = slab_tail<1>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 11: if constexpr (Q > 11) acc = slab_tail<11, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 10: if constexpr (Q > 10) acc = slab_tail<10, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 9: if constexpr (Q > 9) acc = slab_tail<9, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 8: if constexpr (Q > 8) acc = slab_tail<8, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 7: acc = slab_tail<7, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 6: acc = slab_tail<6, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 5: acc = slab_tail<5, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 4: acc = slab_tail<4, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 3: acc = slab_tail<3, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 2: acc = slab_tail<2, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
+    case 1: acc = slab_tail<1, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
     default: break;
   }
   if (!valid) return;
@@ -194,8 +202,12 @@ extern "C" int ggl_bspmm_grad_w_sorted(const ggl_segplan_t *plan, const int32_t 
       const int64_t c1 = (c0 + bw < C) ? c0 + bw : C;
       const float *cin = c0 > 0 ? scratch : nullptr;
       float *cout = c1 < C ? scratch : nullptr;
-      GGL_LAUNCH((bspmm_grad_w_sorted_kernel), ceil_div(total, (int64_t)kBlock), kBlock, s, col, rowidx, plan->perm, x,
-                 g, total, H, C, c0, c1, cin, cout, gw);
+      if (C > 32 && C <= 48)
+        GGL_LAUNCH((bspmm_grad_w_sorted_kernel<12>), ceil_div(total, (int64_t)kBlock), kBlock, s, col, rowidx, plan->perm,
+                   x, g, total, H, C, c0, c1, cin, cout, gw);
+      else
+        GGL_LAUNCH((bspmm_grad_w_sorted_kernel<8>), ceil_div(total, (int64_t)kBlock), kBlock, s, col, rowidx, plan->perm,
+                   x, g, total, H, C, c0, c1, cin, cout, gw);
       GGL_LAUNCH_CHECK();
     }
     return GGL_OK;

@@ -18,6 +18,75 @@ constexpr int kHubStage = 256;              // elements per LDS half = producer 
 constexpr int kHubCols = 64;                // columns per slab = consumer lanes
 constexpr int kHubBlock = kWave + kHubStage;  // wavefront 0 consumes, wavefronts 1-4 produce
 
+// The consumer's running sum: ONE dependent chain per column, so its length per element is the kernel's floor.
+// TT<T>::add spells "add in f32, round to the storage type, widen again" with software rounding (6-7 dependent
+// VALU operations for bf16).  Same values from shorter chains:
+//   f16 : v_add_f16 on the storage values.  The sum of two f16 numbers rounded once to f16 equals the f32 sum rounded
+//         to f16 — double rounding is innocuous when the wider format has at least 2p + 2 significand bits
+//         (p = 11: 24 >= 24) — so this is c10::Half's "float add, then round" bit for bit (1 instruction per element);
+//   bf16: f32 add, v_cvt_pk_bf16_f32 (round to nearest even in hardware, gfx950), shift back: 3 instructions.  A NaN stays
+//         a NaN along the chain whatever its payload; the final store canonicalises it like c10::BFloat16 (0x7FC0).
+template <typename T> struct HubAcc;
+template <> struct HubAcc<f16_t> {
+  _Float16 a = (_Float16)0.0f;
+  __device__ __forceinline__ void add(uint16_t xb) {
+    _Float16 x;
+    __builtin_memcpy(&x, &xb, 2);
+    a = a + x;
+  }
+  __device__ __forceinline__ float value() const { return (float)a; }
+};
+template <> struct HubAcc<bf16_t> {
+  float a = 0.0f;
+  __device__ __forceinline__ void add(uint16_t xb) {
+    const __bf16 r = (__bf16)__fadd_rn(a, bf16_to_f32(xb));
+    uint16_t bits;
+    __builtin_memcpy(&bits, &r, 2);
+    a = bf16_to_f32(bits);
+  }
+  __device__ __forceinline__ float value() const { return a; }   // (TT<bf16_t>::store maps a NaN to 0x7FC0)
+};
+
+// One element's slab (ncol <= 64 columns starting at column c0 of its row) from memory into its LDS row: P whole
+// 8-element pieces as 16-byte loads — all in flight together, P a compile-time constant (a run-time bound on the piece
+// loop sent the staging array to scratch memory: 144 bytes per thread in round 2's kernel) — plus, for rows that are not
+// made of aligned 16-byte pieces (V16 = false: K = 47 -> 94-byte rows, or an unaligned base), the ncol % 8 elements left
+// over as the tail of the 16 bytes that END at the slab's end.  That path used to issue one 2-byte load per element
+// (47 per row: the K = 47 hub rows of the products-sized graph took 16 ms while the other 2.4 M rows took 8).
+template <bool V16, int P>
+__device__ __forceinline__ void hub_fill(const uint16_t *__restrict__ g, uint16_t *__restrict__ dst, int ncol, int64_t c0) {
+  uint4 v[P > 0 ? P : 1];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    if (V16) {
+      v[q] = reinterpret_cast<const uint4 *>(g)[q];
+    } else {
+      const H8U t = *reinterpret_cast<const H8U *>(g + q * 8);     // 2-byte aligned 16-byte load
+      __builtin_memcpy(&v[q], &t, 16);
+    }
+  }
+  uint64_t lo = 0, hi = 0;
+  const int rem = V16 ? 0 : (ncol & 7);
+  const bool shifted = rem > 0 && (c0 + ncol >= 8);               // (always, unless the whole row is shorter than 8)
+  if (shifted) {
+    const H8U t = *reinterpret_cast<const H8U *>(g + ncol - 8);
+    uint4 tw;
+    __builtin_memcpy(&tw, &t, 16);
+    lo = (uint64_t)tw.x | ((uint64_t)tw.y << 32);
+    hi = (uint64_t)tw.z | ((uint64_t)tw.w << 32);
+  }
+#pragma unroll
+  for (int q = 0; q < P; ++q) *reinterpret_cast<uint4 *>(dst + q * 8) = v[q];
+  if (rem > 0) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+      if (t < rem) {
+        const int j = 8 - rem + t;                                 // element j of the 8 loaded (shifts, no register indexing)
+        dst[P * 8 + t] = shifted ? (uint16_t)((j < 4 ? lo : hi) >> (16 * (j & 3))) : g[P * 8 + t];
+      }
+  }
+}
+
 // V16: K % 8 == 0 and 16-byte aligned rows — the slab of an element moves as 16-byte pieces; otherwise element by element
 template <typename T, bool V16>
 __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *__restrict__ x,
@@ -46,26 +115,18 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
     };
     auto fill = [&](int64_t src, int b) {
       if (src < 0) return;
-      if (V16) {
-        const uint4 *g = reinterpret_cast<const uint4 *>(x + src * K + c0);
-        uint4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (q < parts) v[q] = g[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (q < parts) *reinterpret_cast<uint4 *>(&buf[b][e][q * 8]) = v[q];
-      } else {
-        const uint16_t *g = x + src * K + c0;
-        for (int q0 = 0; q0 < ncol; q0 += 8) {  // 8 two-byte loads in flight
-          uint16_t v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (q0 + q < ncol) v[q] = g[q0 + q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (q0 + q < ncol) buf[b][e][q0 + q] = v[q];
-        }
+      const uint16_t *g = x + src * K + c0;
+      uint16_t *dst = &buf[b][e][0];
+      switch (parts) {   // block-uniform: the piece count is a compile-time constant inside each case (see hub_fill)
+        case 8: hub_fill<V16, 8>(g, dst, ncol, c0); break;
+        case 7: hub_fill<V16, 7>(g, dst, ncol, c0); break;
+        case 6: hub_fill<V16, 6>(g, dst, ncol, c0); break;
+        case 5: hub_fill<V16, 5>(g, dst, ncol, c0); break;
+        case 4: hub_fill<V16, 4>(g, dst, ncol, c0); break;
+        case 3: hub_fill<V16, 3>(g, dst, ncol, c0); break;
+        case 2: hub_fill<V16, 2>(g, dst, ncol, c0); break;
+        case 1: hub_fill<V16, 1>(g, dst, ncol, c0); break;
+        default: hub_fill<V16, 0>(g, dst, ncol, c0); break;
       }
     };
     int64_t src = src_of(0);
@@ -82,7 +143,7 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
   }
   // ---- consumer: one column per lane, the elements of a stage in order; the LDS reads of 8 elements are issued
   // together, the adds stay the reference's serial chain
-  typename TT<T>::A acc = TT<T>::zero();
+  HubAcc<T> run;
   __syncthreads();
   for (int64_t st = 0; st < nst; ++st) {
     const int b = (int)(st & 1);
@@ -94,12 +155,13 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = buf[b][e + q][lane];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc = TT<T>::add(acc, TT<T>::load(v[q]));
+        for (int q = 0; q < 8; ++q) run.add(v[q]);
       }
-      for (; e < cnt; ++e) acc = TT<T>::add(acc, TT<T>::load(buf[b][e][lane]));
+      for (; e < cnt; ++e) run.add(buf[b][e][lane]);
     }
     __syncthreads();
   }
+  typename TT<T>::A acc = run.value();
   if (lane < ncol) {
     if (mean) {  // segment_mean_cpu.cpp:67-76: the count lives in the storage type; divide only where count > 1
       const typename TT<T>::A c = TT<T>::count(len);

@@ -151,12 +151,16 @@ template <typename S, int VEC, bool RAG> struct RowIO {
 };
 template <> struct RowIO<float, 4, true> {
   static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[4], int nv) {
-    if (nv == 4) {
-      const F4U t = *reinterpret_cast<const F4U *>(p);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
+    // the row's last lane (nv < 4 floats left) reads the 16 bytes that END at the row's end and shifts: every lane of
+    // the wave issues exactly one load per element (a row is at least 4 floats wide on this path), where the ragged
+    // lane used to add nv dword loads to every wave-wide load of the walk
+    const int s = 4 - nv;
+    const F4U t = *reinterpret_cast<const F4U *>(p - s);
+    const float a[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = i < nv ? p[i] : 0.0f;
+    for (int i = 0; i < 4; ++i) {
+      const int j = i + s;
+      v[i] = i < nv ? (j == 0 ? a[0] : j == 1 ? a[1] : j == 2 ? a[2] : a[3]) : 0.0f;
     }
   }
   static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[4], int nv) {
@@ -175,16 +179,17 @@ template <> struct RowIO<float, 4, true> {
 // the VEC = 1 kernels, one 2-byte load per lane — a wave-load that moves 94 bytes; here lanes 0 .. K/8 - 1 move 16 bytes
 // from a 2-byte aligned address (the backend emits global_load_dwordx4 for the packed struct: unaligned access mode)
 // and the last lane of the row the K % 8 elements left over.  Same elements, same order of the same rounded adds.
-struct __attribute__((packed, aligned(2))) H8U { uint16_t v[8]; };
 template <> struct RowIO<uint16_t, 8, true> {
   static __device__ __forceinline__ void load(const uint16_t *__restrict__ p, uint16_t (&v)[8], int nv) {
-    if (nv == 8) {
-      const H8U t = *reinterpret_cast<const H8U *>(p);
+    // (the row's last lane reads the 16 bytes that end at the row's end and shifts, see RowIO<float, 4, true>)
+    const int s = 8 - nv;
+    const uint4 t = *reinterpret_cast<const uint4 *>(reinterpret_cast<const H8U *>(p - s));
+    const uint64_t lo = (uint64_t)t.x | ((uint64_t)t.y << 32), hi = (uint64_t)t.z | ((uint64_t)t.w << 32);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = t.v[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = i < nv ? p[i] : (uint16_t)0;
+    for (int i = 0; i < 8; ++i) {
+      const int j = i + s;                                   // element j of the 8 loaded
+      const uint64_t w = j < 4 ? lo : hi;
+      v[i] = i < nv ? (uint16_t)(w >> (16 * (j & 3))) : (uint16_t)0;
     }
   }
   static __device__ __forceinline__ void store(uint16_t *__restrict__ p, const uint16_t (&v)[8], int nv) {
@@ -572,6 +577,7 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   const int32_t *long_rows;
   const int64_t *chunk_ptr;
   const int32_t *row_order;
+  int64_t xcd_run_rows;
   int64_t n_long, n_chunks;
   void *partial;
   int64_t *partial_arg;
@@ -657,6 +663,10 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   const int rows_per_block = kWavesPerBlock * (kWave >> d.logL);
   d.nblocks = ceil_div(a.N, rows_per_block);
   d.swizzle = (int)options().xcd_swizzle;
+  if (a.xcd_run_rows > 0 && !d.swizzle) {   // a locality-ordered graph: runs of consecutive row blocks per XCD
+    const int64_t run_blocks = a.xcd_run_rows / rows_per_block;
+    if (run_blocks >= 2 && d.nblocks >= 16 * run_blocks) d.swizzle = (int)run_blocks;
+  }
   GGL_REQUIRE(d.nblocks < ((int64_t)1 << 30), GGL_EINVAL, "too many rows for one launch");
   if (a.N <= 0 || a.K <= 0) return GGL_OK;
   if constexpr (!STATIC_IDX || RAG) {   // (the ragged kernels resolve the index mode at run time: one variant each)
@@ -794,6 +804,7 @@ static int fill_plan(ReduceArgs &a, const ggl_segplan_t *plan, int dtype, int64_
   a.long_rows = plan->long_rows;
   a.chunk_ptr = plan->chunk_ptr;
   a.row_order = plan->row_order;
+  a.xcd_run_rows = plan->xcd_run_rows;
   a.n_long = plan->n_long;
   a.n_chunks = plan->n_chunks;
   a.partial = plan->partial;

@@ -601,18 +601,20 @@ class DistGCNTrainer:
     def capture(self, x_local, y_local, train_local, n_train_global, warmup=3, collectives=False):
         """Record step(...) on these very tensors into one hipGraph (`capturable=True`); afterwards `replay()` runs a
         training step — the kernels never sync or allocate outside the graph's pool, the side stream's weight-gradient
-        GEMMs and the dropout draws (state advanced on the device) are part of it.  A step that exchanges halos
-        (world > 1, or the single-GPU self-halo group) contains RCCL collectives: pass `collectives=True` to record
-        them too (RCCL >= 2.26 captures its kernels; the exchange runs on persistent buffers, a precondition).  That is
-        opt-in: it has been exercised on ONE GPU only (tests/test_gpu_parity.py, world-size-1 RCCL group) — every rank
-        must capture and replay in lockstep."""
-        if self.pg.comm and not self.pg.dry and not collectives:
-            raise RuntimeError("this step exchanges halos through RCCL: capture(..., collectives=True) records the "
-                               "collectives into the graph as well (opt-in, see the docstring)")
+        GEMMs and the dropout draws (state advanced on the device) are part of it.  Single-rank steps (and dry
+        partitions) only: a step that exchanges halos contains RCCL collectives, and recording those was TRIED and does
+        not work on this stack — torch 2.10 + ROCm 7.0.2 + RCCL 2.26.6 segfault inside hipStreamEndCapture when the
+        captured region holds an all-to-all-v (world-size-1 group on one MI355X, capture_error_mode="thread_local",
+        persistent exchange buffers: profiles/r3_rccl_capture_attempt.txt).  `collectives=True` (or
+        GGL_CAPTURE_COLLECTIVES=1) attempts it anyway, for a future stack; the eager N > 1 step is what bench.py times."""
+        want = collectives or os.environ.get("GGL_CAPTURE_COLLECTIVES") == "1"
+        if self.pg.comm and not self.pg.dry and not want:
+            raise RuntimeError("this step exchanges halos through RCCL; recording collectives into a hipGraph crashes on "
+                               "this stack (see the docstring) — capture() is for single-rank steps")
         from .trainer import GraphedStep
 
         self.graph = GraphedStep(lambda: self.step(x_local, y_local, train_local, n_train_global), warmup=warmup,
-                                 capture_error_mode="thread_local" if collectives else "global")
+                                 capture_error_mode="thread_local" if want else "global")
         return self.graph
 
     def replay(self):

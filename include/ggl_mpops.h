@@ -84,6 +84,9 @@ typedef struct ggl_segplan {
   int64_t E;                /* number of elements (edges) */
   const int32_t *row_order; /* [N] rows sorted by length (longest first) or NULL: the order in which
                                row slots are handed to wavefronts — scheduling only, results identical */
+  int64_t xcd_run_rows;     /* > 0: the node order carries locality — hand each XCD runs of this many consecutive row
+                               slots (its private L2 then serves one neighbourhood instead of 1/8 of every one);
+                               0: the library default (round-robin).  Scheduling only (ABI 5). */
 } ggl_segplan_t;
 
 /* bytes of workspace ggl_plan_build needs */

@@ -68,6 +68,20 @@ def test_host_emulation_build_has_the_same_surface():
     assert not missing, missing
 
 
+def test_host_library_is_a_product_artefact_with_the_same_surface():
+    """libggl_mpops_host.so (the CPU dispatch key's library: `make -C gammagl_amd/csrc host`) exports every declared
+    symbol at the header's ABI version, and binds through the same ctypes table as the HIP library."""
+    from gammagl_amd import _lib
+
+    if not os.path.exists(_lib.HOST_LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "gammagl_amd", "csrc"), "-s", "host"])
+    lib = _lib.bind(_lib.HOST_LIB_PATH)
+    assert lib.ggl_abi_version() == header_abi_version()
+    assert not [n for n in declared_functions() if not hasattr(lib, n)]
+    # the capability queries of the GPU-only kernels answer "no" there (gpu_only_stubs.cpp)
+    assert lib.ggl_gat_fast_supported(8, 8) == 0 and lib.ggl_gat_sh_supported(8, 64, 41) == 0
+
+
 def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
     from gammagl_amd import _lib
 

@@ -855,51 +855,3 @@ def test_partitioned_trainer_step_captures_into_a_hipgraph(eng, dev):
         assert all(v == v for v in seq) and seq[-1] < 0.7 * seq[0]
         assert len(set(seq)) > 30                                    # fresh masks: no two replays repeat
     assert abs(losses["graph"][-1] - losses["eager"][-1]) < 0.25 * losses["eager"][0]
-
-
-def test_halo_step_with_rccl_collectives_captures_into_a_hipgraph(eng, dev):
-    """The step WITH its halo exchange recorded: a world-size-1 RCCL group where the upper half of the rows is treated
-    as remote, so every aggregate issues real all-to-all-v collectives (forward and reverse) on the persistent
-    exchange buffers; capture(collectives=True) records them with the kernels, and the replayed steps train like the
-    eager ones (dropout off: same losses to rounding)."""
-    import os
-    import socket
-
-    import torch.distributed as dist
-
-    from gammagl_amd.dist import DistGCNTrainer, PartitionedGraph
-    from gammagl_amd.synth import homophilous_graph
-
-    if not dist.is_initialized():
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        x, y, ei = homophilous_graph(6000, 32, 7, deg=6, seed=3, device=dev)
-        ei = torch.cat([ei, torch.arange(x.shape[0], device=dev).repeat(2, 1)], 1)
-        n = x.shape[0]
-        deg = torch.bincount(ei[1], minlength=n).float().clamp(min=1)
-        w = deg.pow(-0.5)[ei[0]] * deg.pow(-0.5)[ei[1]]
-        pg = PartitionedGraph(ei, w, n, 0, 1, eng=eng, self_halo_from=n // 2)
-        assert pg.comm and pg.n_halo > 0 and not pg.dry
-        idx = torch.arange(0, n, 2, device=dev)
-        losses = {}
-        for mode in ("eager", "graph"):
-            tr = DistGCNTrainer(pg, 32, 64, 7, num_layers=3, drop_rate=0.0, seed=2, device=dev, capturable=(mode == "graph"))
-            if mode == "graph":
-                with pytest.raises(RuntimeError, match="collectives"):
-                    tr.capture(x, y, idx, idx.numel())
-                tr.capture(x, y, idx, idx.numel(), warmup=3, collectives=True)      # 3 eager steps + the recorded one
-                seq = [float(tr.replay()) for _ in range(20)]
-            else:
-                for _ in range(4):
-                    tr.step(x, y, idx, idx.numel())
-                seq = [float(tr.step(x, y, idx, idx.numel())) for _ in range(20)]
-            losses[mode] = seq
-        for a, b in zip(losses["eager"], losses["graph"]):
-            assert abs(a - b) <= 1e-3 * abs(a) + 1e-5, (a, b)
-        assert losses["graph"][-1] < 0.8 * losses["graph"][0]
-    finally:
-        dist.destroy_process_group()

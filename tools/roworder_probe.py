@@ -47,9 +47,10 @@ for kind, relabel in (("rmat", "random"), ("rmat", "degree"), ("planted", "rando
     for K in (256, 64):
         x = torch.randn(n, K, generator=g, device=dev)
         out = torch.empty(n, K, device=dev)
-        for win, swz in ((0, 0), (2048, 0), (2048, 8), (2048, 32), (2048, 128), (2048, 512), (8192, 128)):
+        for win, swz, run in ((0, 0, 0), (2048, 0, 0), (2048, 128, 0), (2048, 0, -1), (2048, 0, 1024), (2048, 0, 4096)):
             eng.clear_caches()
             eng.row_order_window = max(win, 0)
+            eng.xcd_run_rows = run      # 0 = off, -1 = decided per graph (GraphPlan._schedule), > 0 = forced run length in rows
             eng.set_option("xcd_swizzle", swz)
             eng.set_option("row_order", 0 if win < 0 else 1)       # -1: no row_order at all (natural id order)
             gp = eng.graph_plan(ei, n)
@@ -57,9 +58,11 @@ for kind, relabel in (("rmat", "random"), ("rmat", "degree"), ("planted", "rando
             t = ev(lambda: eng.spmm_sum_into(gp.fwd, gp.col, w, x, out))
             tt = ev(lambda: eng.spmm_sum_into(gp.bwd, gp.colT, w, x, out))
             label = "natural id order" if win < 0 else ("global sort by length" if win == 0 else f"windows of {win} ids")
-            say(f"  K={K:3d} {label:24s} xcd_swizzle={swz}: forward {t:6.2f} ms, transposed {tt:6.2f} ms")
+            say(f"  K={K:3d} {label:24s} xcd_swizzle={swz:3d} xcd_run_rows={run:5d} (plan: {gp.fwd.xcd_run:4d}, locality "
+                f"{gp.locality():.2f}): forward {t:6.2f} ms, transposed {tt:6.2f} ms")
         eng.set_option("xcd_swizzle", 0)
         eng.set_option("row_order", 1)
+        eng.xcd_run_rows = -1
         del x, out
     del pg, ei, w
     eng.clear_caches()
