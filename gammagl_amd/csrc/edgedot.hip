@@ -24,8 +24,8 @@
 namespace ggl {
 
 // float4s per strip per slab: 8 (32 columns; tile row stride 36 floats: the 16-byte reads of a 16-lane pass fall into
-// distinct banks) — or 12 for heads of 33 .. 48 channels (41 classes padded to 44), which then are ONE slab with no
-// narrower remainder slab behind it
+// distinct banks).  (12-piece slabs — a 44-channel head as ONE slab — were tried: 180 registers, two workgroups per CU,
+// 8 x 44 forward+backward 82 -> 88 ms.)
 template <int Q> struct DotTile { static constexpr int ld = Q * 4 + 4; };
 
 #ifndef GGL_EMULATE
@@ -41,6 +41,27 @@ __device__ __forceinline__ void slab_load(int tid, const int64_t *sx, const floa
     const int64_t ox = sx[item];
     v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ox >= 0) v[j] = *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4);
+  }
+}
+// the same on the first NQ entries of the pipeline's 8-entry register slab (the narrower last slab of a strip)
+template <int NQ, int Q>
+__device__ __forceinline__ void slab_load_into(int tid, const int64_t *sx, const float *__restrict__ x, int64_t c0,
+                                               float4 (&v)[Q]) {
+  static_assert(NQ <= Q, "tail slab wider than the pipeline's");
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;
+    const int64_t ox = sx[item];
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ox >= 0) v[j] = *reinterpret_cast<const float4 *>(x + ox + c0 + part * 4);
+  }
+}
+template <int NQ, int LD, int Q>
+__device__ __forceinline__ void slab_store_from(int tid, const float4 (&v)[Q], float (*tx)[LD]) {
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int f = tid + kBlock * j, item = f / NQ, part = f - item * NQ;
+    *reinterpret_cast<float4 *>(&tx[item][part * 4]) = v[j];
   }
 }
 template <int NQ, int LD>
@@ -72,20 +93,10 @@ __device__ __forceinline__ float slab_fold(int tid, float (*tx)[LD], const float
   }
   return acc;
 }
-template <int NQ, int LD>
-__device__ __forceinline__ float slab_tail(int tid, const int64_t *sx, const float *__restrict__ x,
-                                           const float *__restrict__ gp, bool valid, int64_t c0, float (*tx)[LD],
-                                           float acc) {
-  float4 v[NQ];
-  slab_load<NQ>(tid, sx, x, c0, v);
-  slab_store<NQ, LD>(tid, v, tx);
-  __syncthreads();
-  acc = slab_fold<NQ, LD>(tid, tx, gp + c0, valid, acc);
-  __syncthreads();
-  return acc;
-}
-
-template <int Q>
+// TAIL = float4s of the strip's last, narrower slab (0 = the column range is whole slabs): a template parameter, so each
+// instantiation carries one tail shape (a run-time switch over seven shapes inside one kernel cost 188 registers
+// instead of ~120, i.e. half the resident wavefronts)
+template <int Q, int TAIL>
 __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
     const int32_t *__restrict__ col, const int32_t *__restrict__ rowidx, const int32_t *__restrict__ perm,
     const float *__restrict__ x, const float *__restrict__ g, int64_t total, int64_t H, int64_t C, int64_t c_lo,
@@ -109,32 +120,23 @@ __global__ __launch_bounds__(kBlock) void bspmm_grad_w_sorted_kernel(
   __syncthreads();
   int64_t c0 = c_lo;
   const int64_t n_full = (c_hi - c_lo) / (kDotQ * 4);
-  if (n_full > 0) {
-    // software pipeline over the full slabs: slab s + 1 is in flight while slab s is folded
-    float4 cur[kDotQ];
-    slab_load<kDotQ>(tid, sx, x, c0, cur);
-    for (int64_t s = 0; s < n_full; ++s) {
-      slab_store<kDotQ, kDotLd>(tid, cur, tx);
-      __syncthreads();
-      if (s + 1 < n_full) slab_load<kDotQ>(tid, sx, x, c0 + kDotQ * 4, cur);
-      acc = slab_fold<kDotQ, kDotLd>(tid, tx, gp + c0, valid, acc);
-      __syncthreads();
-      c0 += kDotQ * 4;
-    }
+  // software pipeline: the next slab's loads (a full one, or the tail) are in flight while the current one is folded
+  float4 cur[kDotQ];
+  if (n_full > 0) slab_load<kDotQ>(tid, sx, x, c0, cur);
+  else if constexpr (TAIL > 0) slab_load_into<TAIL>(tid, sx, x, c0, cur);
+  for (int64_t s = 0; s < n_full; ++s) {
+    slab_store<kDotQ, kDotLd>(tid, cur, tx);
+    __syncthreads();
+    if (s + 1 < n_full) slab_load<kDotQ>(tid, sx, x, c0 + kDotQ * 4, cur);
+    else if constexpr (TAIL > 0) slab_load_into<TAIL>(tid, sx, x, c0 + kDotQ * 4, cur);
+    acc = slab_fold<kDotQ, kDotLd>(tid, tx, gp + c0, valid, acc);
+    __syncthreads();
+    c0 += kDotQ * 4;
   }
-  switch ((int)((c_hi - c0) >> 2)) {   // the last, narrower slab (block-uniform)
-    case 11: if constexpr (Q > 11) acc = slab_tail<11, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 10: if constexpr (Q > 10) acc = slab_tail<10, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 9: if constexpr (Q > 9) acc = slab_tail<9, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 8: if constexpr (Q > 8) acc = slab_tail<8, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 7: acc = slab_tail<7, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 6: acc = slab_tail<6, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 5: acc = slab_tail<5, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 4: acc = slab_tail<4, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 3: acc = slab_tail<3, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 2: acc = slab_tail<2, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    case 1: acc = slab_tail<1, kDotLd>(tid, sx, x, gp, valid, c0, tx, acc); break;
-    default: break;
+  if constexpr (TAIL > 0) {
+    slab_store_from<TAIL, kDotLd>(tid, cur, tx);
+    __syncthreads();
+    acc = slab_fold<TAIL, kDotLd>(tid, tx, gp + c0, valid, acc);
   }
   if (!valid) return;
   if (carry_out) carry_out[i] = acc;
@@ -202,12 +204,20 @@ extern "C" int ggl_bspmm_grad_w_sorted(const ggl_segplan_t *plan, const int32_t 
       const int64_t c1 = (c0 + bw < C) ? c0 + bw : C;
       const float *cin = c0 > 0 ? scratch : nullptr;
       float *cout = c1 < C ? scratch : nullptr;
-      if (C > 32 && C <= 48)
-        GGL_LAUNCH((bspmm_grad_w_sorted_kernel<12>), ceil_div(total, (int64_t)kBlock), kBlock, s, col, rowidx, plan->perm,
-                   x, g, total, H, C, c0, c1, cin, cout, gw);
-      else
-        GGL_LAUNCH((bspmm_grad_w_sorted_kernel<8>), ceil_div(total, (int64_t)kBlock), kBlock, s, col, rowidx, plan->perm,
-                   x, g, total, H, C, c0, c1, cin, cout, gw);
+#define GGL_DOT_LAUNCH(T)                                                                                         \
+  GGL_LAUNCH((bspmm_grad_w_sorted_kernel<8, T>), ceil_div(total, (int64_t)kBlock), kBlock, s, col, rowidx, plan->perm, x, \
+             g, total, H, C, c0, c1, cin, cout, gw)
+      switch ((int)(((c1 - c0) % 32) / 4)) {
+        case 0: GGL_DOT_LAUNCH(0); break;
+        case 1: GGL_DOT_LAUNCH(1); break;
+        case 2: GGL_DOT_LAUNCH(2); break;
+        case 3: GGL_DOT_LAUNCH(3); break;
+        case 4: GGL_DOT_LAUNCH(4); break;
+        case 5: GGL_DOT_LAUNCH(5); break;
+        case 6: GGL_DOT_LAUNCH(6); break;
+        default: GGL_DOT_LAUNCH(7); break;
+      }
+#undef GGL_DOT_LAUNCH
       GGL_LAUNCH_CHECK();
     }
     return GGL_OK;

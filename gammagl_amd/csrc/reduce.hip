@@ -151,16 +151,14 @@ template <typename S, int VEC, bool RAG> struct RowIO {
 };
 template <> struct RowIO<float, 4, true> {
   static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[4], int nv) {
-    // the row's last lane (nv < 4 floats left) reads the 16 bytes that END at the row's end and shifts: every lane of
-    // the wave issues exactly one load per element (a row is at least 4 floats wide on this path), where the ragged
-    // lane used to add nv dword loads to every wave-wide load of the walk
-    const int s = 4 - nv;
-    const F4U t = *reinterpret_cast<const F4U *>(p - s);
-    const float a[4] = {t.x, t.y, t.z, t.w};
+    if (nv == 4) {
+      const F4U t = *reinterpret_cast<const F4U *>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      // (the 16-bit rows below read a ragged tail as ONE shifted 16-byte load; tried here too and it lost: the selects
+      // run on every lane of the wave, segment_sum [E, 47] f32 7.8 -> 9.8 ms, where three dword loads cost one lane)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = i + s;
-      v[i] = i < nv ? (j == 0 ? a[0] : j == 1 ? a[1] : j == 2 ? a[2] : a[3]) : 0.0f;
+      for (int i = 0; i < 4; ++i) v[i] = i < nv ? p[i] : 0.0f;
     }
   }
   static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[4], int nv) {
@@ -181,7 +179,9 @@ template <> struct RowIO<float, 4, true> {
 // and the last lane of the row the K % 8 elements left over.  Same elements, same order of the same rounded adds.
 template <> struct RowIO<uint16_t, 8, true> {
   static __device__ __forceinline__ void load(const uint16_t *__restrict__ p, uint16_t (&v)[8], int nv) {
-    // (the row's last lane reads the 16 bytes that end at the row's end and shifts, see RowIO<float, 4, true>)
+    // the row's last lane (nv < 8 elements left) reads the 16 bytes that END at the row's end and shifts: every lane of
+    // the wave issues exactly one load per element (a row is at least 8 elements wide on this path), where the ragged lane
+    // used to add up to seven 2-byte loads to every wave-wide load of the walk ([E, 47] f16: 20.1 -> 7.2 ms)
     const int s = 8 - nv;
     const uint4 t = *reinterpret_cast<const uint4 *>(reinterpret_cast<const H8U *>(p - s));
     const uint64_t lo = (uint64_t)t.x | ((uint64_t)t.y << 32), hi = (uint64_t)t.z | ((uint64_t)t.w << 32);
