@@ -277,14 +277,20 @@ def measure_traffic(args, kernel_substr, relabel=None, with_l2=False):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode}): {r.stderr[-200:]}", {}
+            import re
+
+            m = re.search(r"dispatches=(\d+)", r.stdout)
+            last = int(m.group(1)) if m else 0          # the probe's own launches are the LAST `last` dispatches of the kernel
             acc = {c: [] for c in counters}
             with open(files[0], newline="") as f:
                 for row in csv.DictReader(f):
                     if row["Counter_Name"] in acc and kernel_substr in row["Kernel_Name"]:
-                        acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                        acc[row["Counter_Name"]].append((int(row.get("Dispatch_Id", 0) or 0), float(row["Counter_Value"])))
             for c, xs in acc.items():
                 if not xs:
                     return None, f"kernel '{kernel_substr}' not found in the {c} counter file", {}
+                xs = [v for _, v in sorted(xs)]
+                xs = xs[-last:] if 0 < last <= len(xs) else xs
                 vals[c] = sum(xs) / len(xs)
         except Exception as ex:  # noqa: BLE001
             return None, f"{type(ex).__name__}: {ex}", {}
@@ -465,12 +471,13 @@ def main():
                     src = f"unavailable: {why}"
             set_traffic(rf, t, src)
             rf.update(extra)
-            also = [o for o in out["config"].get("orderings", [])[1:]]
-            if also and args.pmc_traffic == "l2":   # the second node order's traffic too (locality workloads)
-                t2, src2, extra2 = measure_traffic(args, KERNEL_OF[kind], relabel=also[0]["relabel"], with_l2=True)
-                also[0]["traffic_per_aggregate"] = None if t2 is None else t2 * int(rf["launches_per_aggregate"])
-                also[0]["traffic_source"] = src2
-                also[0].update(extra2)
+            if args.pmc_traffic == "l2":   # the other node orders' traffic too (locality workloads)
+                for o in out["config"].get("orderings", [])[1:]:
+                    t2, src2, extra2 = measure_traffic(args, KERNEL_OF[kind], relabel=o["relabel"], with_l2=True)
+                    o["traffic_per_aggregate"] = None if t2 is None else t2 * int(rf["launches_per_aggregate"])
+                    o["traffic_over_compulsory"] = None if t2 is None else o["traffic_per_aggregate"] / max(rf["compulsory_bytes"], 1)
+                    o["traffic_source"] = src2
+                    o.update(extra2)
         if cpu_args is not None:
             out["cpu_baseline"] = {"gcn": cpu_baseline_gcn, "gat": cpu_baseline_gat, "sage": cpu_baseline_sage}[kind](*cpu_args)
         print(json.dumps(out), flush=True)

@@ -26,8 +26,8 @@ WORKLOADS = {
     "products": dict(kind="gcn", dataset="products", gen="rmat", also="degree"),
     "arxiv": dict(kind="gcn", dataset="arxiv", gen="rmat", also="degree"),
     "tiny": dict(kind="gcn", dataset=None, gen="rmat", also=None),
-    "tiny-planted": dict(kind="gcn", dataset=None, gen="planted", also="cluster"),
-    "products-planted": dict(kind="gcn", dataset="products", gen="planted", also="cluster"),
+    "tiny-planted": dict(kind="gcn", dataset=None, gen="planted", also=("cluster", "none")),
+    "products-planted": dict(kind="gcn", dataset="products", gen="planted", also=("cluster", "none")),
     "papers-share": dict(kind="gcn", dataset="papers100M", gen="rmat", parts=8, play=3, also=None),
     "reddit-gat": dict(kind="gat", dataset="reddit"),
     "sage-minibatch": dict(kind="sage", dataset="products"),
@@ -191,7 +191,10 @@ def pmc_probe_gcn(args, dev, eng):
     gen = torch.Generator(device=dev).manual_seed(1)
     ms, launches, gp, rows, _ = dominant_spmm(pg, eng, args.hidden, gen, dev, reps=4)
     torch.cuda.synchronize()
-    print(f"pmc-probe: E={gp.E} rows_in={rows} K={args.hidden} launches/aggregate={launches} ms/aggregate={ms:.3f}", flush=True)
+    # (reps + 1 warm-up) aggregates of `launches` dispatches each were the LAST dispatches of the dominant kernel: the
+    # parent averages the counters over exactly those (a clustered order runs the same kernel while it is computed)
+    print(f"pmc-probe: E={gp.E} rows_in={rows} K={args.hidden} launches/aggregate={launches} ms/aggregate={ms:.3f} "
+          f"dispatches={5 * launches}", flush=True)
 
 
 def run_gcn(args, dev, rank, world, eng=None):
@@ -301,33 +304,40 @@ def run_gcn(args, dev, rank, world, eng=None):
         "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
         "config": cfg, "roofline": None if emul else rf}
 
-    # the second node order ("report both"), same association, same step count
+    # the other node orders ("report both"), same association, same step count: degree-sorted for the R-MAT
+    # workloads; for the planted graph the order partition.cluster_order recovers from the random ids, and the
+    # generator's own ("none": a dataset whose native order already carries its locality)
     also = getattr(args, "also_relabel", None)
     also = spec.get("also") if also in (None, "auto") else (None if also == "none" else also)
+    also = [also] if isinstance(also, str) else list(also or [])
+    also = [a for a in also if a != args.relabel]
     ctx = {"pg": pg, "data": data}
-    if also and also != args.relabel and world == 1 and not parts:
+    if also and world == 1 and not parts and not getattr(args, "no_comparison", False):
         host_graph = None
         if getattr(args, "keep_host_graph", False):   # bench.py's cpu_baseline leg wants the main graph on the host
             host_graph = (torch.stack([pg.ei_loc[0] + pg.lo, pg.ei_loc[1] + pg.lo]).cpu().contiguous(), pg.w_loc.cpu())
-        main_order = {"relabel": args.relabel, "ms_per_step": out["ms_per_step"], "value": value,
-                      "ms_per_aggregate_K%d" % K: ms_op}
+        orderings = [{"relabel": args.relabel, "ms_per_step": out["ms_per_step"], "value": value,
+                      "ms_per_aggregate_K%d" % K: ms_op}]
         del pg, data, gp_t
         ctx = {"host_graph": host_graph}
-        eng.clear_caches()
-        if dev.type == "cuda":
-            torch.cuda.empty_cache()
-        pg, stats2, t2 = build(also)
-        data = _gcn_data(pg, f_in, n_cls, args.seed, rank, dev, world)
-        tr = trainer(af_main)
-        dt_b, _ = _time_steps(tr, data, args, dev, world)
-        ms_b, _, gp_b, _, _ = dominant_spmm(pg, eng, K, data[4], dev)
-        second = {"relabel": also, "ms_per_step": dt_b / args.steps * 1e3, "value": tr.net.agg_per_step * pg.e_global * args.steps / dt_b,
-                  "ms_per_aggregate_K%d" % K: ms_b, "setup_s": round(t2, 2), "E": pg.e_global}
-        if "clusters" in stats2:
-            second["clusters"] = stats2["clusters"]
-        out["config"]["orderings"] = [main_order, second]
-        del tr, gp_b
-        ctx.update(pg=pg, data=data)
+        for other in also:
+            eng.clear_caches()
+            if dev.type == "cuda":
+                torch.cuda.empty_cache()
+            pg, stats2, t2 = build(other)
+            data = _gcn_data(pg, f_in, n_cls, args.seed, rank, dev, world)
+            tr = trainer(af_main)
+            dt_b, _ = _time_steps(tr, data, args, dev, world)
+            ms_b, _, gp_b, _, _ = dominant_spmm(pg, eng, K, data[4], dev)
+            entry = {"relabel": other, "ms_per_step": dt_b / args.steps * 1e3,
+                     "value": tr.net.agg_per_step * pg.e_global * args.steps / dt_b,
+                     "ms_per_aggregate_K%d" % K: ms_b, "setup_s": round(t2, 2), "E": pg.e_global,
+                     "xcd_run_rows": int(getattr(gp_b.fwd, "xcd_run", 0) or 0)}
+            if "clusters" in stats2:
+                entry["clusters"] = stats2["clusters"]
+            orderings.append(entry)
+            del tr, gp_b, pg, data
+        out["config"]["orderings"] = orderings
     return out, ctx
 
 
@@ -361,7 +371,7 @@ def pmc_probe_gat(args, dev, eng):
         for _ in range(4):
             eng.gat_fused(ei, el, er, x, 0.2)
     torch.cuda.synchronize()
-    print("pmc-probe: gat forward 8x8 on the Reddit-sized graph", flush=True)
+    print("pmc-probe: gat forward 8x8 on the Reddit-sized graph dispatches=4", flush=True)
 
 
 def run_gat(args, dev, rank, world, eng=None):

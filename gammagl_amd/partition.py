@@ -65,7 +65,7 @@ def arrange_communities(q):
     return pos
 
 
-def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=None, balance=4.0, arrange=True):
+def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=None, balance=4.0, arrange=True, update=1.0):
     """Returns (`rank`, `label`): `rank` int64 [N] = new id of every node (communities contiguous, ids stable
     inside a community), `label` the community of every node.  Size-capped label propagation: a node adopts the
     community most of its neighbours are in unless that community already holds `balance` x the average
@@ -95,6 +95,8 @@ def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=Non
         new = score.argmax(1)
         # admit movers only up to each community's free room (lowest node id first: deterministic)
         move = new != lab
+        if update < 1.0:   # damped synchronous sweeps: a random share of the nodes may move (fewer two-cycles)
+            move &= torch.rand(N, generator=g, device=dev) < update
         room = (cap - size).clamp(min=0)
         tgt = torch.where(move, new, torch.full_like(new, C))
         order = torch.argsort(tgt * N + ar)                         # movers grouped by target community
