@@ -166,8 +166,9 @@ class PartitionedGraph:
         """[x_local ; x_halo] for a tensor of local rows that NEVER changes (the input features): the halo rows are
         fetched from their owners once and kept, keyed on the identity + version of `x`.  An aggregate over the
         result (`aggregate(..., halo_included=True)`) exchanges nothing, in either direction."""
-        if not self.comm or self.n_halo == 0:
-            return x
+        if not self.comm:
+            return x   # (a rank WITHOUT halo rows still takes part below: its peers may need its rows, and a collective
+            #            that some ranks skip is a deadlock)
         key = (x.untyped_storage()._cdata, x.storage_offset(), tuple(x.shape), x._version, str(x.device))
         hit = self._const.get(key)
         if hit is None:
@@ -258,7 +259,7 @@ class _HaloAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, pg, bias, relu, p_drop, pre=False):
         eng = pg.eng
-        pre = bool(pre and pg.comm and pg.n_halo > 0)
+        pre = bool(pre and pg.comm)      # halo rows already in place: NO collective, whether or not this rank has a halo
         if h.shape[0] != pg.n_local + (pg.n_halo if pre else 0):
             raise RuntimeError(f"aggregate: expected {pg.n_local + (pg.n_halo if pre else 0)} rows, got {h.shape[0]}")
         ctx.k_orig = h.shape[1]
@@ -272,7 +273,8 @@ class _HaloAggregate(torch.autograd.Function):
         b = bias.contiguous().reshape(-1) if (fused and bias is not None) else None
         works = []
         if pre:      # the halo rows sit behind the local ones already: one "chunk", nothing on the wire
-            works.append((0, K, h[pg.n_local:], _Done()))
+            if pg.n_halo > 0:
+                works.append((0, K, h[pg.n_local:], _Done()))
         elif pg.comm:
             for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
                 send = pg._buf(("send", ci), pg.n_send, c1 - c0, h.dtype, dev)
@@ -341,7 +343,8 @@ class _HaloAggregate(torch.autograd.Function):
             # the gradient of a halo row stays here (its consumer is this rank's share of a weight gradient): both
             # transposed walks write into one [n_local + n_halo, K] result, nothing travels back
             gh = torch.empty((pg.n_local + pg.n_halo, K), dtype=g.dtype, device=dev)
-            eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g, gh[pg.n_local:])
+            if pg.n_halo > 0:
+                eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g, gh[pg.n_local:])
             eng.spmm_sum_into(pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, gh[:pg.n_local])
             return (gh if K == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None, gb, None, None, None
         works = []
@@ -388,8 +391,12 @@ class _ConstInputLayer(torch.autograd.Function):
         rng = eng._rng_state(dev) if p_drop > 0 else None
         ctx.rng_used = rng.clone() if rng is not None else None
         b = bias.contiguous().reshape(-1) if bias is not None else None
-        eng.spmm_sum_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out)
-        chunks = _HaloAggregate._chunks(K)
+        if pg.n_halo == 0:   # a rank without halo rows: the epilogue rides on the local walk
+            eng.spmm_epi_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out, bias=b, relu=relu, p_drop=p_drop, rng=rng,
+                              epi_K=K)
+        else:
+            eng.spmm_sum_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out)
+        chunks = _HaloAggregate._chunks(K) if pg.n_halo > 0 else []
         for i, (c0, c1) in enumerate(chunks):
             hh = pg._buf(("halo", i), pg.n_halo, c1 - c0, torch.float32, dev)
             torch.mm(x_halo, wp[c0:c1].t(), out=hh)
@@ -427,7 +434,7 @@ class _ConstInputLayer(torch.autograd.Function):
             gl, _ = eng._spmm_fwd("sum", pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, nl)
             gw = wgrad(gl, x_loc)                                            # [K, f_in]
             del gl
-            for i, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
+            for i, (c0, c1) in enumerate(_HaloAggregate._chunks(K) if pg.n_halo > 0 else []):
                 gh = pg._buf(("halo", i), pg.n_halo, c1 - c0, torch.float32, dev)
                 eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g[:, c0:c1], gh)
                 gw[c0:c1] += wgrad(gh, x_halo)
@@ -525,7 +532,8 @@ class DistGCN(torch.nn.Module):
         n_agg = 0
         # input features never change: their halo rows are fetched once (PartitionedGraph.with_halo) and the first
         # layer runs over [x_local ; x_halo] without any exchange, forward or backward
-        pre = bool(self.const_input_halo and pg.comm and pg.n_halo > 0 and not x.requires_grad)
+        pre = bool(self.const_input_halo and pg.comm and not x.requires_grad)   # (the same on every rank: it decides
+        #                                                                          whether layer 1 issues collectives)
         if pre:
             x = pg.with_halo(x)
         for i in range(n):

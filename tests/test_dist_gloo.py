@@ -20,6 +20,31 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _run_ranks(world, tmp_path, mode="", timeout=300):
+    """Start `world` worker processes of this file on a free 127.0.0.1 port and wait for them; one retry on a fresh
+    port (the port is picked, released and re-bound by rank 0: another process can grab it in between)."""
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    rcs = None
+    for attempt in range(2):
+        port = _free_port()
+        for r in range(world):
+            ok = tmp_path / f"ok{r}"
+            if ok.exists():
+                ok.unlink()
+        procs = [subprocess.Popen([sys.executable, __file__, str(r), str(world), str(port), str(tmp_path)] + ([mode] if mode else []))
+                 for r in range(world)]
+        try:
+            rcs = [p.wait(timeout=timeout) for p in procs]
+        except subprocess.TimeoutExpired:
+            for p in procs:
+                p.kill()
+            rcs = [-9] * world
+        if rcs == [0] * world:
+            break
+    assert rcs == [0] * world, rcs
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 def _emul_engine():
     sys.path.insert(0, REPO)
     from gammagl_amd import _lib
@@ -128,13 +153,7 @@ def _worker(rank, world, port, tmp):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_halo_exchange_matches_single_process(world, tmp_path):
-    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
-    port = _free_port()
-    procs = [subprocess.Popen([sys.executable, __file__, str(r), str(world), str(port), str(tmp_path)])
-             for r in range(world)]
-    rcs = [p.wait(timeout=300) for p in procs]
-    assert rcs == [0] * world, rcs
-    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+    _run_ranks(world, tmp_path)
 
 
 def test_balanced_bounds_and_world1():
@@ -233,12 +252,7 @@ def _bench_worker(rank, world, port, tmp):
 
 def test_bench_body_runs_distributed(tmp_path):
     """bench.py's body (per-rank graph construction, partition, timed steps, max-over-ranks) on gloo."""
-    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
-    port = _free_port()
-    procs = [subprocess.Popen([sys.executable, __file__, str(r), "2", str(port), str(tmp_path), "bench"])
-             for r in range(2)]
-    assert [p.wait(timeout=300) for p in procs] == [0, 0]
-    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+    _run_ranks(2, tmp_path, "bench")
 
 
 def _sage_worker(rank, world, port, tmp):
@@ -289,12 +303,7 @@ def _sage_worker(rank, world, port, tmp):
 
 
 def test_sage_minibatch_replicas_with_gradient_allreduce(tmp_path):
-    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
-    port = _free_port()
-    procs = [subprocess.Popen([sys.executable, __file__, str(r), "2", str(port), str(tmp_path), "sage"])
-             for r in range(2)]
-    assert [p.wait(timeout=300) for p in procs] == [0, 0]
-    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+    _run_ranks(2, tmp_path, "sage")
 
 
 def _edge_set(src, dst):
@@ -393,12 +402,7 @@ def _shard_worker(rank, world, port, tmp):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_per_rank_graph_construction_and_fused_halo_epilogue(world, tmp_path):
-    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
-    port = _free_port()
-    procs = [subprocess.Popen([sys.executable, __file__, str(r), str(world), str(port), str(tmp_path), "shard"])
-             for r in range(world)]
-    assert [p.wait(timeout=600) for p in procs] == [0] * world
-    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+    _run_ranks(world, tmp_path, "shard", timeout=600)
 
 
 def test_rank_share_checks_at_toy_size():
