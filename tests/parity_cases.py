@@ -969,6 +969,56 @@ def check_bspmm_wide(eng, dev):
         torch.testing.assert_close(w.grad, wr.grad, rtol=1e-5, atol=1e-5)
 
 
+def check_schedule_invariance(eng, dev):
+    """Scheduling knobs never change a bit: the row hand-out order (global sort by length, id windows, none) and the XCD
+    run mapping (off, runs of 64 / 2048 rows, one contiguous eighth) give identical sums, means, maxima, argmax witnesses
+    and fused epilogues on a graph with a hub, empty rows and more row blocks than 16 runs."""
+    g = torch.Generator().manual_seed(17)
+    N, E = 6000, 90000
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N - 50, (E,), generator=g)
+    dst[:3000] = 11
+    ei = torch.stack([src, dst]).to(dev)
+    w = torch.rand(E, generator=g).to(dev)
+    bias = torch.randn(64, generator=g).to(dev)
+    xs = {K: torch.randn(N, K, generator=g).to(dev) for K in (64, 16, 256)}
+    msg = torch.randn(E, 24, generator=g).to(dev)
+    old = (eng.row_order_window, eng.xcd_run_rows, eng.lib.ggl_get_option(b"xcd_swizzle"), eng.lib.ggl_get_option(b"row_order"))
+    ref = None
+    try:
+        for win, run, swz, ro in ((0, 0, 0, 1), (512, 0, 0, 1), (2048, 64, 0, 1), (2048, 2048, 0, 1), (512, 0, 1, 1), (512, 0, 8, 1),
+                                  (512, 64, 0, 0), (2048, -1, 0, 1)):
+            eng.clear_caches()
+            eng.row_order_window, eng.xcd_run_rows = win, run
+            eng.set_option("xcd_swizzle", swz)
+            eng.set_option("row_order", ro)
+            gp = eng.graph_plan(ei, N)
+            assert gp.fwd.xcd_run == (run if run >= 0 else 0)        # (auto: 90 000 edges is below the size where it decides)
+            got = []
+            for K, x in xs.items():
+                out = torch.empty(N, K, device=dev)
+                eng.spmm_sum_into(gp.fwd, gp.col, w, x, out)
+                got.append(out.clone())
+                eng.spmm_sum_into(gp.bwd, gp.colT, w, x, out)
+                got.append(out.clone())
+            y = torch.empty(N, 64, device=dev)
+            eng.spmm_epi_into(gp.fwd, gp.col, w, xs[64], y, mean=True, bias=bias, relu=True)
+            got.append(y)
+            got.append(eng.c_spmm_max(ei, w, xs[16]))
+            mx, arg = eng.segment_max_with_arg(msg, ei[1].contiguous(), N)
+            got += [mx, arg, eng.c_segment_sum(msg, ei[1].contiguous(), N), eng.c_segment_mean(msg, ei[1].contiguous(), N)]
+            if ref is None:
+                ref = got
+            else:
+                for i, (a, b) in enumerate(zip(ref, got)):
+                    assert torch.equal(a, b), (win, run, swz, ro, i)
+    finally:
+        eng.row_order_window, eng.xcd_run_rows = old[0], old[1]
+        eng.set_option("xcd_swizzle", old[2])
+        eng.set_option("row_order", old[3])
+        eng.clear_caches()
+
+
 def check_half_ragged_rows(eng, dev, oracle):
     """f16 / bf16 segment sum / mean on rows that are not made of aligned 16-byte pieces (12, 13, 47, 100 columns, and a
     base address that is only 2-byte aligned): eight elements per lane with a ragged last lane

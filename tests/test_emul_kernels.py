@@ -75,6 +75,10 @@ def test_attention_dropout_words_are_a_sound_random_source():
     pc.check_drop_word_statistics()
 
 
+def test_scheduling_knobs_never_change_a_bit(eng):
+    pc.check_schedule_invariance(eng, DEV)
+
+
 def test_half_precision_ragged_rows(eng, oracle):
     pc.check_half_ragged_rows(eng, DEV, oracle)
 

@@ -309,3 +309,43 @@ def test_products_size_column_blocks_same_bits(eng, dev):
         assert torch.equal(a, b), nm
     kept = (res[64][3] != 0).float().mean()
     assert 0.2 < float(kept) < 0.3                    # relu x dropout(0.5) of a zero-mean aggregate
+
+
+def test_locality_ordered_graph_gets_xcd_runs_same_bits(eng, dev):
+    """Products-sized planted-community graph: in its own node order the plan detects locality and hands each XCD runs of
+    2048 consecutive rows, with shuffled ids it does not; either way the aggregate's bits are the ones of the round-robin
+    hand-out (scheduling only), forward and transposed."""
+    if not _big(dev):
+        pytest.skip("needs > 100 GB of HBM")
+    from gammagl_amd.synth import DATASETS, planted_pairs
+
+    n, e, _, _ = DATASETS["products"]
+    s_, d_ = planted_pairs(n, out_deg=max(2, e // (2 * n)), seed=0, device=dev)
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(n, 64, generator=g, device=dev)
+    old = eng.xcd_run_rows
+    try:
+        for shuffled in (False, True):
+            if shuffled:
+                pi = torch.randperm(n, generator=g, device=dev)
+                ei = torch.stack([pi[s_], pi[d_]]).contiguous()
+            else:
+                ei = torch.stack([s_, d_]).contiguous()
+            res = {}
+            for run in (-1, 0):
+                eng.clear_caches()
+                eng.xcd_run_rows = run
+                gp = eng.graph_plan(ei, n)
+                if run < 0:
+                    loc = gp.locality()
+                    assert (loc < 0.1 and gp.fwd.xcd_run == 0) if shuffled else (loc > 0.5 and gp.fwd.xcd_run == 2048), loc
+                    assert gp.bwd.xcd_run == gp.fwd.xcd_run
+                a, b = torch.empty(n, 64, device=dev), torch.empty(n, 64, device=dev)
+                eng.spmm_sum_into(gp.fwd, gp.col, None, x, a)
+                eng.spmm_sum_into(gp.bwd, gp.colT, None, x, b)
+                res[run] = (a, b)
+            assert torch.equal(res[-1][0], res[0][0]) and torch.equal(res[-1][1], res[0][1])
+            del ei
+    finally:
+        eng.xcd_run_rows = old
+        eng.clear_caches()

@@ -110,6 +110,10 @@ def test_bspmm_wide_heads(eng, dev):
     pc.check_bspmm_wide(eng, dev)
 
 
+def test_scheduling_knobs_never_change_a_bit(eng, dev):
+    pc.check_schedule_invariance(eng, dev)
+
+
 def test_half_precision_ragged_rows(eng, dev, oracle):
     pc.check_half_ragged_rows(eng, dev, oracle)
 
