@@ -250,7 +250,7 @@ def test_arxiv_size_16bit_sums_with_a_reddit_sized_hub_row(eng, dev, oracle, dt)
     ids = rmat_graph(n, e, seed=0, device=dev)[1].contiguous()
     ids[:109110] = 5
     g = torch.Generator(device=dev).manual_seed(13)
-    for K in (16, 7):
+    for K in (16, 7, 47):     # (47: ragged 8-wide lanes + the hub kernel's 16-byte producers for rows that are not 16-byte pieces)
         xf = (torch.randn(ids.shape[0], K, generator=g, device=dev) * 3 + 0.5).cpu().numpy()
         xh = oracle.f32_to_bf16_bits(xf) if dt == "bfloat16" else xf.astype(np.float16)
         xt = pc.to_t(xh, dev, dt)
@@ -349,3 +349,36 @@ def test_locality_ordered_graph_gets_xcd_runs_same_bits(eng, dev):
     finally:
         eng.xcd_run_rows = old
         eng.clear_caches()
+
+
+def test_products_size_bspmm_weight_gradient_sorted_plan_same_bits(eng, dev):
+    """bspmm's weight gradient at the products size: the walk along the sorted plan (LDS-staged strips, 64-column-block
+    launches carrying the running dot) == the thread-per-item kernel in edge order, bit for bit, for a one-head 256-channel
+    row (4 column blocks) and 8 heads x 44 channels (one 32-column slab + a 12-column tail), and both == an f64 evaluation of a
+    row sample within f32 rounding."""
+    if not _big(dev):
+        pytest.skip("needs > 100 GB of HBM")
+    from gammagl_amd.synth import DATASETS, rmat_graph
+
+    n, e, _, _ = DATASETS["products"]
+    ei = rmat_graph(n, e, seed=0, device=dev)
+    E = ei.shape[1]
+    g = torch.Generator(device=dev).manual_seed(4)
+    for H, C in ((1, 256), (8, 44)):
+        x = torch.randn(n, H, C, generator=g, device=dev).requires_grad_(True)
+        w = torch.rand(E, H, generator=g, device=dev).requires_grad_(True)
+        go = torch.randn(n, H, C, generator=g, device=dev)
+        assert (eng.lib.ggl_bspmm_grad_w_sorted_scratch_bytes(E, n, H, C) > 0) == (C >= 128)
+        got = {}
+        for mode in (True, False):
+            eng.gradw_sorted = mode
+            x.grad = w.grad = None
+            eng.c_bspmm_sum(ei, w, x).backward(go)
+            got[mode] = w.grad.clone()
+        eng.gradw_sorted = True
+        assert torch.equal(got[True], got[False])
+        pick = torch.randint(0, E, (4096,), generator=g, device=dev)
+        want = (x.detach()[ei[0, pick]].double() * go[ei[1, pick]].double()).sum(-1)
+        scale = (x.detach()[ei[0, pick]].abs().double() * go[ei[1, pick]].abs().double()).sum(-1)
+        assert bool(((got[True][pick].double() - want).abs() <= 1e-5 * scale + 1e-6).all())
+        del x, w, go, got
