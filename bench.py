@@ -85,6 +85,11 @@ def parse():
                    help="auto: after the timed region (N = 1), measure the dominant kernel's HBM-side traffic with two "
                         "rocprofv3 --pmc passes of `bench.py --pmc-probe` on the same graph (skipped when rocprofv3 is not "
                         "on PATH; falls back to the committed profile); l2: a third pass for the L2 hit rate")
+    p.add_argument("--dry-parts", type=int, default=0,
+                   help="N = 1 only: play ONE rank's share of a --dry-parts-way partition of the workload's graph as a dry "
+                        "partition (send lists and buffers as in the real run, nothing on the wire): what a rank computes per "
+                        "step, for tools/scaling_model.sh (papers-share is this with 8 parts built in)")
+    p.add_argument("--dry-rank", type=int, default=-1, help="the rank played with --dry-parts (default: parts / 2)")
     p.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--seed", type=int, default=0)
     return p.parse_args()
@@ -272,7 +277,8 @@ def measure_traffic(args, kernel_substr, relabel=None, with_l2=False):
         try:
             cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-probe", "--workload", args.workload, "--hidden", str(args.hidden),
-                   "--seed", str(args.seed), "--relabel", relabel or args.relabel, "--order", args.order]
+                   "--seed", str(args.seed), "--relabel", relabel or args.relabel, "--order", args.order,
+                   "--dry-parts", str(args.dry_parts), "--dry-rank", str(args.dry_rank)]
             r = subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR=d), capture_output=True, text=True, timeout=240)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:

@@ -181,13 +181,23 @@ def dominant_spmm(pg, eng, K, gen, dev, reps=10):
     return ms, launches, gp, rows, use_halo
 
 
+def _dry(args, spec):
+    """(parts, rank played) of a dry partition: built into the workload (papers-share) or asked for with --dry-parts."""
+    parts = int(getattr(args, "dry_parts", 0) or 0) or spec.get("parts")
+    if not parts:
+        return None, 0
+    play = int(getattr(args, "dry_rank", -1))
+    return parts, (play if play >= 0 else spec.get("play", parts // 2))
+
+
 def pmc_probe_gcn(args, dev, eng):
     """`bench.py --pmc-probe` for the gcn family: rebuild this run's graph and launch the dominant kernel a few
     times (rocprofv3 --pmc wraps this process; FETCH_SIZE / WRITE_SIZE / TCC_* go in separate passes)."""
     spec = WORKLOADS[args.workload]
     n_nodes, n_edges, _, _ = sizes_of(args.workload)
-    pg = build_partition(n_nodes, n_edges, args.seed, spec.get("play", 0), 1, None, dev, eng, relabel=args.relabel,
-                         order=args.order, parts=spec.get("parts"), kind=spec["gen"])
+    parts, play = _dry(args, spec)
+    pg = build_partition(n_nodes, n_edges, args.seed, play, 1, None, dev, eng, relabel=args.relabel,
+                         order=args.order, parts=parts, kind=spec["gen"])
     gen = torch.Generator(device=dev).manual_seed(1)
     ms, launches, gp, rows, _ = dominant_spmm(pg, eng, args.hidden, gen, dev, reps=4)
     torch.cuda.synchronize()
@@ -204,7 +214,7 @@ def run_gcn(args, dev, rank, world, eng=None):
     eng = eng if eng is not None else _default_engine()
     spec = WORKLOADS[args.workload]
     n_nodes, n_edges, f_in, n_cls = sizes_of(args.workload)
-    parts, play = spec.get("parts"), spec.get("play", 0)
+    parts, play = _dry(args, spec)
     if parts and world != 1:
         raise SystemExit(f"bench.py: --workload {args.workload} plays rank {play} of a {parts}-way partition on ONE GPU "
                          f"(dry partition); run it with --gpus 1")
