@@ -209,11 +209,17 @@ template <int VEC, bool RAG> __device__ __forceinline__ int valid_lanes(int64_t 
   return RAG ? (int)((K - kk) < VEC ? (K - kk) : VEC) : VEC;
 }
 
+// The argmax witness of a lane's element travels in a 32-bit register: it is an edge position or a source node id, both
+// of which index int32 arrays (perm / col), or the "empty" fill (E, or 0), so it always fits; it is widened to the
+// reference's int64 at the store.  Eight 64-bit witnesses per lane (the 16-byte 16-bit paths) were 16 registers and two
+// selects per element each.
+using argreg_t = int32_t;
+
 // ---- reduce sorted positions [beg, end) of `row` for the VEC features starting at kk -------------
 template <typename T, int VEC, int OP, int MODE, int IDX, int U, bool RAG = false>
 __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, const ReduceDims &d,
                                              int64_t row, int64_t beg, int64_t end, int64_t kk,
-                                             typename TT<T>::A (&acc)[VEC], int64_t (&arg)[VEC]) {
+                                             typename TT<T>::A (&acc)[VEC], argreg_t (&arg)[VEC]) {
   using S = typename TT<T>::S;
   using A = typename TT<T>::A;
   const int64_t K = d.K;
@@ -259,7 +265,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
       if (OP == OP_MAX) {
         if (TT<T>::less(acc[i], v)) {
           acc[i] = v;
-          arg[i] = who;
+          arg[i] = (argreg_t)who;
         }
       } else {
         acc[i] = TT<T>::add(acc[i], v);
@@ -315,12 +321,12 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
 }
 
 template <typename T, int VEC, int OP>
-__device__ __forceinline__ void init_acc(typename TT<T>::A (&acc)[VEC], int64_t (&arg)[VEC],
+__device__ __forceinline__ void init_acc(typename TT<T>::A (&acc)[VEC], argreg_t (&arg)[VEC],
                                          int64_t arg_fill) {
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     acc[i] = (OP == OP_MAX) ? TT<T>::lowest() : TT<T>::zero();
-    arg[i] = arg_fill;
+    arg[i] = (argreg_t)arg_fill;
   }
 }
 
@@ -375,7 +381,7 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
                                            typename TT<T>::S *__restrict__ out,
                                            int64_t *__restrict__ argout, int64_t K, int64_t row,
                                            int64_t len, int64_t kk, typename TT<T>::A (&acc)[VEC],
-                                           const int64_t (&arg)[VEC], const EpiPre<VEC> &pre) {
+                                           const argreg_t (&arg)[VEC], const EpiPre<VEC> &pre) {
   using S = typename TT<T>::S;
   const int nv = valid_lanes<VEC, RAG>(K, kk);
   if (OP == OP_MEAN) {
@@ -416,7 +422,7 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
   if (OP == OP_MAX) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i)
-      if (!RAG || i < nv) argout[row * K + kk + i] = arg[i];
+      if (!RAG || i < nv) argout[row * K + kk + i] = (int64_t)arg[i];
   }
 }
 
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
     const int64_t end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
     for (int64_t kk = (int64_t)lane * VEC; kk < d.K; kk += (int64_t)kWave * VEC) {
       A acc[VEC];
-      int64_t arg[VEC];
+      argreg_t arg[VEC];
       init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
       reduce_range<T, VEC, OP, MODE, IDX, U, RAG>(q, d, row, beg, end, kk, acc, arg);
       S o[VEC];
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
       if (OP == OP_MAX) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i)
-          if (!RAG || i < nv) partial_arg[cid * d.K + kk + i] = arg[i];
+          if (!RAG || i < nv) partial_arg[cid * d.K + kk + i] = (int64_t)arg[i];
       }
     }
     return;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
   if (len > d.chunk) return;  // long row: reduced by the chunk blocks above + long_final_kernel
   for (int64_t kk = (int64_t)li * VEC; kk < d.K; kk += (int64_t)L * VEC) {
     A acc[VEC];
-    int64_t arg[VEC];
+    argreg_t arg[VEC];
     init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
     seed_acc<T, VEC, OP, RAG>(d, out, row, kk, acc);
     EpiPre<VEC> pre;
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
   const int64_t len = rowptr[row + 1] - rowptr[row];
   for (int64_t k = threadIdx.x; k < d.K; k += kBlock) {
     A acc[1];
-    int64_t arg[1];
+    argreg_t arg[1];
     init_acc<T, 1, OP>(acc, arg, d.arg_fill);
     seed_acc<T, 1, OP>(d, out, row, k, acc);
     for (int64_t c = c0; c < c1; ++c) {
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
       if (OP == OP_MAX) {
         if (TT<T>::less(acc[0], v)) {  // strict <: the earliest chunk (smallest e) keeps ties
           acc[0] = v;
-          arg[0] = partial_arg[c * d.K + k];
+          arg[0] = (argreg_t)partial_arg[c * d.K + k];
         }
       } else {
         acc[0] = TT<T>::add(acc[0], v);
@@ -879,6 +885,9 @@ extern "C" int ggl_segment_max(int dtype, const void *x, const ggl_segplan_t *pl
   if (rc) return rc;
   GGL_REQUIRE((x || plan->E * K == 0) && ((out && arg) || plan->N * K == 0), GGL_EINVAL,
               "x/out/arg is NULL");
+  // the witnesses travel in 32-bit registers (argreg_t): element positions must fit, like perm's own entries
+  GGL_REQUIRE(plan->E < ((int64_t)1 << 31) && arg_fill >= 0 && arg_fill < ((int64_t)1 << 31), GGL_EINVAL,
+              "segment_max: 2^31 or more elements in one plan");
   a.x = x;
   a.out = out;
   a.arg = arg;
