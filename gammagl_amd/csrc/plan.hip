@@ -254,6 +254,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "xcd_swizzle")) o.xcd_swizzle = value;
   else if (!strcmp(name, "force_generic")) o.force_generic = value;
   else if (!strcmp(name, "ragged4")) o.ragged4 = value;
+  else if (!strcmp(name, "ragged_max")) o.ragged_max = value;
   else if (!strcmp(name, "col_block")) o.col_block = value;
   else if (!strcmp(name, "col_block_min_edges")) o.col_block_min_edges = value;
   else if (!strcmp(name, "col_block_min_degree")) o.col_block_min_degree = value;
@@ -270,6 +271,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "xcd_swizzle")) return o.xcd_swizzle;
   if (!strcmp(name, "force_generic")) return o.force_generic;
   if (!strcmp(name, "ragged4")) return o.ragged4;
+  if (!strcmp(name, "ragged_max")) return o.ragged_max;
   if (!strcmp(name, "col_block")) return o.col_block;
   if (!strcmp(name, "col_block_min_edges")) return o.col_block_min_edges;
   if (!strcmp(name, "col_block_min_degree")) return o.col_block_min_degree;

@@ -702,8 +702,9 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
   // K = 41 6.2 -> 5.5 ms, segment_sum [E, 47] 7.46 -> 7.22 ms; below 32 columns the VEC = 1 kernels with 16 loads in
   // flight win by 3x and wave-per-row widths (K > 128) lose 7 %, so only 32 <= K <= 128 takes it.
   // (not segment_max: its int64 argmax registers make the 4-wide lanes slower there, [E, 47] 7.9 -> 9.1 ms)
-  if constexpr ((seg_like(MODE) && OP != OP_MAX) || spmm_like(MODE)) {
-    if (!options().force_generic && options().ragged4 && a.K >= 32 && a.K <= 128)
+  if constexpr (seg_like(MODE) || spmm_like(MODE)) {
+    if (!options().force_generic && options().ragged4 && a.K >= 32 && a.K <= 128 &&
+        (OP != OP_MAX || spmm_like(MODE) || options().ragged_max))
       return launch_typed<float, 4, OP, MODE, kStatic, true>(a, stream);
   }
   return launch_typed<float, 1, OP, MODE, kStatic>(a, stream);
@@ -770,7 +771,7 @@ static bool wide_ok(const ReduceArgs &a, int vec) {
 // sum / mean only (max carries eight int64 argmax registers per lane: the f32 ragged path measured slower there), and
 // from 12 columns up (below that one lane per element with 16 loads in flight wins)
 template <int OP> static bool ragged16_ok(const ReduceArgs &a) {
-  return OP != OP_MAX && !options().force_generic && options().ragged4 && a.K >= 12;
+  return (OP != OP_MAX || options().ragged_max) && !options().force_generic && options().ragged4 && a.K >= 12;
 }
 
 template <int OP>
