@@ -767,11 +767,12 @@ static bool wide_ok(const ReduceArgs &a, int vec) {
          (!a.partial || aligned16(a.partial)) && a.x_ld % vec == 0 && a.out_ld % vec == 0;
 }
 
-// 16-bit rows that are not made of aligned 16-byte pieces: eight elements per lane all the same (RowIO<uint16_t, 8, true>);
-// sum / mean only (max carries eight int64 argmax registers per lane: the f32 ragged path measured slower there), and
+// 16-bit rows that are not made of aligned 16-byte pieces: eight elements per lane all the same (RowIO<uint16_t, 8, true>),
 // from 12 columns up (below that one lane per element with 16 loads in flight wins)
 template <int OP> static bool ragged16_ok(const ReduceArgs &a) {
-  return (OP != OP_MAX || options().ragged_max) && !options().force_generic && options().ragged4 && a.K >= 12;
+  // (max: from 72 columns up — [E, 100] f16 18.6 -> 12.9 ms, but [E, 47] 9.7 -> 10.4: eight witnesses per lane cost more than
+  //  the narrow loads there)
+  return (OP != OP_MAX || a.K >= 72 || options().ragged_max) && !options().force_generic && options().ragged4 && a.K >= 12;
 }
 
 template <int OP>
