@@ -1043,6 +1043,10 @@ def check_half_ragged_rows(eng, dev, oracle):
                     eng.set_option("ragged4", rag)
                     assert_same(to_np(eng.c_segment_sum(x, it, N)), want_s, f"{dt} K{K} sum ragged={rag}")
                     assert_same(to_np(eng.c_segment_mean(x, it, N)), want_m, f"{dt} K{K} mean ragged={rag}")
+                    mx, arg = eng.segment_max_with_arg(x, it, N)       # (ragged lanes from 72 columns up; 32-bit witnesses)
+                    omx, oarg = oracle.segment_max(xh[1:], ids, N, bf16=dt == "bfloat16")
+                    assert_same(to_np(mx), omx, f"{dt} K{K} max ragged={rag}")
+                    assert np.array_equal(to_np(arg), oarg), f"{dt} K{K} argmax ragged={rag}"
     finally:
         eng.set_option("ragged4", old)
 
