@@ -303,3 +303,54 @@ def run_fused_case(eng, DEV, prob):
     finally:
         eng.chunk = old
         eng.seg_cache.clear(); eng.graph_cache.clear(); eng.w_cache.clear()
+
+
+# ---- bspmm: forward, input gradient, weight gradient (sorted-plan walk) -----------------------------------------------
+@st.composite
+def bspmm_problems(draw):
+    N = draw(st.integers(1, 40))
+    E = draw(st.integers(0, 600))
+    H = draw(st.sampled_from([1, 2, 3, 8]))
+    C = draw(st.sampled_from([4, 8, 16, 20, 32, 36, 44, 64, 100, 128, 256, 300]))
+    kind = draw(st.sampled_from(["uniform", "sorted", "hub", "single"]))
+    blocks = draw(st.booleans())
+    seed = draw(st.integers(0, 2**31 - 1))
+    return N, E, H, C, kind, blocks, seed
+
+
+def run_bspmm_case(eng, DEV, oracle, prob):
+    """bspmm_sum forward / gx / gw against the oracle bit for bit (quarter-integer data: every partial sum is exact, so
+    neither the chunking of hub rows nor the 64-column-block launches of the weight-gradient walk can change a bit)."""
+    N, E, H, C, kind, blocks, seed = prob
+    rng = np.random.default_rng(seed)
+    dst = make_ids(rng, N, E, kind)
+    src = rng.integers(0, N, size=E).astype(np.int64)
+    index = np.stack([src, dst])
+    w = (rng.integers(-4, 5, size=(E, H)) * 0.5).astype(np.float32)
+    x = (rng.integers(-8, 9, size=(N, H, C)) * 0.25).astype(np.float32)
+    go = (rng.integers(-8, 9, size=(N, H, C)) * 0.25).astype(np.float32)
+    names = (b"col_block_min_edges", b"col_block_min_degree")
+    old = [eng.lib.ggl_get_option(n) for n in names]
+    try:
+        if blocks:
+            for n in names:
+                eng.set_option(n.decode(), 0)
+        wt = pc.to_t(w, DEV).requires_grad_(True)
+        xt = pc.to_t(x, DEV).requires_grad_(True)
+        y = eng.c_bspmm_sum(pc.to_t(index, DEV), wt, xt)
+        y.backward(pc.to_t(go, DEV))
+        ogx, ogw = oracle.bspmm_sum_bwd(index, w, x, go)
+        pc.assert_same(pc.to_np(y), oracle.bspmm_sum_fwd(index, w, x), f"bspmm y {prob}")
+        pc.assert_same(pc.to_np(xt.grad), ogx, f"bspmm gx {prob}")
+        pc.assert_same(pc.to_np(wt.grad), ogw, f"bspmm gw {prob}")
+    finally:
+        for n, v in zip(names, old):
+            eng.set_option(n.decode(), v)
+        eng.graph_cache.clear()
+        eng.seg_cache.clear()
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@given(bspmm_problems())
+def test_bspmm_fuzz(oracle, prob):
+    run_bspmm_case(engine(), DEV, oracle, prob)

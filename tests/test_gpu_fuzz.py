@@ -55,6 +55,13 @@ def test_fused_epilogue_and_strided_fuzz_gpu(target, prob):
     F.run_fused_case(target[0], target[1], prob)
 
 
+@settings(**_cfg)
+@given(F.bspmm_problems())
+def test_bspmm_fuzz_gpu(target, oracle, prob):
+    """incl. the LDS-staged weight-gradient walk (edgedot.hip), which only the GPU build has"""
+    F.run_bspmm_case(target[0], target[1], oracle, prob)
+
+
 @st.composite
 def _headmean_problems(draw):
     N = draw(st.integers(1, 40))
