@@ -15,7 +15,7 @@ import torch
 from . import engine as _engine
 
 
-def arrange_communities(q):
+def arrange_communities(q, device=None):
     """A linear arrangement of the communities of a quotient graph (`q` [C, C]: edges between communities) that puts
     strongly connected communities next to each other, by RECURSIVE SPECTRAL BISECTION: order the communities along
     the Fiedler vector of the normalised Laplacian, cut that order where the normalised cut is smallest, recurse into
@@ -23,8 +23,8 @@ def arrange_communities(q):
     inside super-classes inside ...) comes out as nested contiguous ranges, so a contiguous cut of the final order into
     P parts severs the weakest links it can.  Returns `pos` int64 [C]: position of every community (empty
     communities last).  Deterministic (eigenvector signs are fixed), so every rank computes the same arrangement."""
-    q = q.detach().double().cpu()
-    C = q.shape[0]
+    q = q.detach().double().to(device if device is not None else "cpu")   # (thousands of communities: the eigen-
+    C = q.shape[0]                                                          #  decompositions run on the GPU)
     q = q + q.t()
     q.fill_diagonal_(0.0)
     live = torch.nonzero(q.sum(1) > 0).reshape(-1).tolist()
@@ -33,7 +33,7 @@ def arrange_communities(q):
     def order(nodes):
         if len(nodes) <= 2:
             return nodes
-        idx = torch.tensor(nodes)
+        idx = torch.tensor(nodes, device=q.device)
         sub = q[idx][:, idx]
         d = sub.sum(1)
         lone = [nodes[i] for i in torch.nonzero(d <= 0).reshape(-1).tolist()]
@@ -41,7 +41,7 @@ def arrange_communities(q):
             keep = [n for n in nodes if n not in set(lone)]
             return order(keep) + lone if len(keep) < len(nodes) and keep else nodes
         dis = d.pow(-0.5)
-        lap = torch.eye(len(nodes), dtype=torch.float64) - dis.unsqueeze(1) * sub * dis.unsqueeze(0)
+        lap = torch.eye(len(nodes), dtype=torch.float64, device=q.device) - dis.unsqueeze(1) * sub * dis.unsqueeze(0)
         _, vec = torch.linalg.eigh(lap)
         f = vec[:, 1] * dis
         if float(f[torch.argmax(f.abs())]) < 0:
@@ -65,7 +65,33 @@ def arrange_communities(q):
     return pos
 
 
-def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=None, balance=4.0, arrange=True, update=1.0):
+def _sweep_by_sorting(src, dst, lab, C, N, cap, size):
+    """One propagation sweep without the [N, C] one-hot matrix: the (node, neighbour's community) pairs of all edges are
+    sorted and run-length counted, so the cost is one sort of E keys whatever the number of communities (the SpMM form
+    moves N x C floats per sweep: 20 GB at 2 000 labels on the products-sized graph).  Returns the label every node would
+    adopt (same scoring as the dense form: neighbour count, a small pull towards smaller communities, full communities
+    closed to newcomers, ties stay put)."""
+    dev = lab.device
+    ar = torch.arange(N, device=dev)
+    key = torch.cat([dst * C + lab[src], ar * C + lab])           # + every node's own label (count 0 if no neighbour has it)
+    uk, cnt = torch.unique(key, return_counts=True)
+    node, l = uk // C, uk % C
+    own = l == lab[node]
+    sc = (cnt - own.to(cnt.dtype)).float() - 1e-3 * (size[l] / cap)   # (the appended own-label entry is not a neighbour)
+    full = size[l] >= cap
+    sc = torch.where(full & ~own, torch.full_like(sc, -1.0), sc)
+    sc = sc + own.float() * (0.5 + full.float() * 2.0)
+    mx = torch.full((N,), -2.0, device=dev).scatter_reduce_(0, node, sc, "amax", include_self=True)
+    cand = torch.where(sc >= mx[node], l, torch.full_like(l, C))
+    # ties: the current label if it is among the best, else the smallest label id (deterministic)
+    best = torch.full((N,), C, dtype=torch.int64, device=dev).scatter_reduce_(0, node, cand, "amin", include_self=True)
+    keeps = torch.zeros(N, dtype=torch.bool, device=dev)
+    keeps[node[own & (sc >= mx[node])]] = True
+    return torch.where(keeps, lab, best)
+
+
+def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=None, balance=4.0, arrange=True, update=1.0,
+                  method="auto"):
     """Returns (`rank`, `label`): `rank` int64 [N] = new id of every node (communities contiguous, ids stable
     inside a community), `label` the community of every node.  Size-capped label propagation: a node adopts the
     community most of its neighbours are in unless that community already holds `balance` x the average
@@ -74,25 +100,32 @@ def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=Non
     by edge count, and a cut through the middle of a community costs just that community's split (measured on a
     planted-partition graph: 32 labels for 8 planted classes recover them, local-source share 0.13 -> 0.78 at
     P = 8; with exactly 8 tightly balanced labels the propagation stalls at 0.28).  `arrange`: the communities are
-    laid out by recursive spectral bisection of their quotient graph (`arrange_communities`) instead of by label id."""
+    laid out by recursive spectral bisection of their quotient graph (`arrange_communities`) instead of by label id.
+    `method`: "spmm" (each sweep one SpMM of this library on the one-hot label matrix), "sort" (`_sweep_by_sorting`:
+    no N x C matrix, for thousands of communities), "auto" = sort above 1024 communities."""
     eng = eng or _engine()
     dev = edge_index.device
     N, C = int(num_nodes), int(clusters)
     g = torch.Generator(device=dev).manual_seed(seed)
     lab = torch.randint(0, C, (N,), generator=g, device=dev)
-    gp = eng.graph_plan(edge_index, N)
+    by_sort = method == "sort" or (method == "auto" and C > 1024)
+    gp = None if by_sort else eng.graph_plan(edge_index, N)
+    src, dst = edge_index[0], edge_index[1]
     cap = balance * N / C
     ar = torch.arange(N, device=dev)
     for _ in range(sweeps):
-        onehot = torch.zeros((N, C), dtype=torch.float32, device=dev)
-        onehot[ar, lab] = 1.0
-        with torch.no_grad():
-            score = eng.spmm(gp, None, onehot)                     # [N, C]: neighbours per community
         size = torch.bincount(lab, minlength=C).float()
-        score = score - 1e-3 * (size / cap).unsqueeze(0)            # tie-break towards the smaller community
-        score[:, size >= cap] = -1.0                                # full communities accept nobody new ...
-        score[ar, lab] += 0.5 + (size[lab] >= cap).float() * 2.0    # ... but keep their members; ties stay put
-        new = score.argmax(1)
+        if by_sort:
+            new = _sweep_by_sorting(src, dst, lab, C, N, cap, size)
+        else:
+            onehot = torch.zeros((N, C), dtype=torch.float32, device=dev)
+            onehot[ar, lab] = 1.0
+            with torch.no_grad():
+                score = eng.spmm(gp, None, onehot)                     # [N, C]: neighbours per community
+            score = score - 1e-3 * (size / cap).unsqueeze(0)            # tie-break towards the smaller community
+            score[:, size >= cap] = -1.0                                # full communities accept nobody new ...
+            score[ar, lab] += 0.5 + (size[lab] >= cap).float() * 2.0    # ... but keep their members; ties stay put
+            new = score.argmax(1)
         # admit movers only up to each community's free room (lowest node id first: deterministic)
         move = new != lab
         if update < 1.0:   # damped synchronous sweeps: a random share of the nodes may move (fewer two-cycles)
@@ -110,13 +143,8 @@ def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=Non
     if arrange and C > 2:
         # communities in the order of the quotient graph's Fiedler vector, so that neighbouring id ranges hold
         # communities that exchange many edges (label ids themselves carry no meaning)
-        onehot = torch.zeros((N, C), dtype=torch.float32, device=dev)
-        onehot[ar, lab] = 1.0
-        with torch.no_grad():
-            score = eng.spmm(gp, None, onehot)
-        q = torch.zeros((C, C), dtype=torch.float64, device=dev).index_add_(0, lab, score.double())
-        pos = arrange_communities(q).to(dev)
-        del onehot, score
+        q = torch.bincount(lab[dst] * C + lab[src], minlength=C * C).view(C, C).double()    # edges between communities
+        pos = arrange_communities(q, device=dev if (C > 1500 and dev.type == "cuda") else None).to(dev)
     rank = torch.empty(N, dtype=torch.int64, device=dev)
     rank[torch.argsort(pos[lab] * N + ar)] = ar
     return rank, lab

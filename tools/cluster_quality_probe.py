@@ -69,11 +69,16 @@ def agg_ms(edges):
 
 
 say(f"hierarchical planted graph N={n} E={ei.shape[1]}, levels {PLANTED_LEVELS}; fine group = {n // G_f} nodes, mid group = {n // G_m}")
+from gammagl_amd.partition import halo_stats as _hs  # noqa: E402
+
 for label, edges in (("random ids", ei), ("generator's own order", nat)):
     t, run, loc = agg_ms(edges)
+    h8, share8 = _hs(edges, n, 8)
     say(f"  {label:42s}: edges within a fine / mid width {near(edges, n // G_f):.3f} / {near(edges, n // G_m):.3f}; K=256 aggregate {t:6.2f} ms "
-        f"(xcd_run {run}, locality {loc:.2f})")
-for C, sw, up in ((1020, 20, 1.0), (1020, 20, 0.5), (1020, 40, 0.5), (2040, 20, 0.5), (256, 20, 0.5)):
+        f"(xcd_run {run}, locality {loc:.2f}); P=8: halo rows {h8}, local-source share {share8:.2f}")
+from gammagl_amd.partition import halo_stats  # noqa: E402
+
+for C, sw, up in ((1020, 20, 1.0), (4080, 20, 1.0), (8160, 20, 1.0), (4080, 30, 1.0)):
     eng.clear_caches()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -82,8 +87,10 @@ for C, sw, up in ((1020, 20, 1.0), (1020, 20, 0.5), (1020, 40, 0.5), (2040, 20, 
     dt = time.perf_counter() - t0
     e2 = relabel_edges(ei, rk).contiguous()
     t, run, loc = agg_ms(e2)
-    say(f"  cluster_order({C:4d} labels, {sw} sweeps, update {up}) {dt:5.1f} s: purity fine / mid {purity(lab, G_f):.3f} / {purity(lab, G_m):.3f}; "
-        f"edges within a fine / mid width {near(e2, n // G_f):.3f} / {near(e2, n // G_m):.3f}; K=256 aggregate {t:6.2f} ms (xcd_run {run}, locality {loc:.2f})")
+    h8, share8 = halo_stats(e2, n, 8)
+    say(f"  cluster_order({C:4d} labels, {sw} sweeps) {dt:5.1f} s, {int(torch.unique(lab).numel())} communities left: purity fine / mid "
+        f"{purity(lab, G_f):.3f} / {purity(lab, G_m):.3f}; edges within a fine / mid width {near(e2, n // G_f):.3f} / {near(e2, n // G_m):.3f}; "
+        f"K=256 aggregate {t:6.2f} ms (xcd_run {run}, locality {loc:.2f}); P=8: halo rows {h8}, local-source share {share8:.2f}")
     del rk, lab, e2
 if len(sys.argv) > 1:
     open(sys.argv[1], "w").write("\n".join(lines) + "\n")
