@@ -29,14 +29,14 @@ def report(label, ei, n):
               f"local-source share {share:.2f}", flush=True)
 
 
-def clustered(ei, n, clusters):
+def clustered(ei, n, clusters, sweeps=20):
     eng.graph_cache.clear(); eng.seg_cache.clear()
     t0 = time.perf_counter()
-    rank, lab = cluster_order(ei, n, clusters=clusters, sweeps=20, eng=eng)
+    rank, lab = cluster_order(ei, n, clusters=clusters, sweeps=sweeps, eng=eng)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sizes = torch.bincount(lab, minlength=clusters)
-    print(f"  cluster_order({clusters} labels, 20 sweeps): {dt:.2f} s, community sizes {int(sizes.min())}..{int(sizes.max())}")
+    print(f"  cluster_order({clusters} labels, {sweeps} sweeps): {dt:.2f} s, community sizes {int(sizes.min())}..{int(sizes.max())}")
     return relabel_edges(ei, rank)
 
 
@@ -59,5 +59,5 @@ pi = torch.randperm(n, device=dev)
 ei = torch.stack([pi[s_], pi[d_]]).contiguous()
 del s_, d_
 report("random ids", ei, n)
-report("cluster_order on random ids", clustered(ei, n, max(8, min(1024, n // 2400))), n)
+report("cluster_order on random ids", clustered(ei, n, max(8, min(8192, n // 600)), sweeps=30), n)
 report("oracle order (the generator's own labelling)", nat, n)
