@@ -1,0 +1,86 @@
+"""Locality-aware node order (gammagl_amd/partition.py) on the host build: the two sweep forms of the label propagation
+agree, many small labels recover a planted hierarchy from shuffled ids, and the arranged order shrinks the halo of the
+1-D partition; the planted generator itself (synth.planted_pairs) keeps its promises."""
+import os
+import subprocess
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _engine():
+    subprocess.check_call([os.path.join(HERE, "emul", "build.sh")])
+    from gammagl_amd import _lib
+    from gammagl_amd.ops import Engine
+
+    return Engine(_lib.bind(os.path.join(HERE, "emul", "libggl_emul.so")), require_cuda=False)
+
+
+def _planted(n=24000, deg=12, levels=((128, 0.60), (16, 0.25), (4, 0.10)), seed=0):
+    from gammagl_amd.synth import planted_pairs
+
+    s, d = planted_pairs(n, out_deg=deg, levels=levels, seed=seed)
+    pi = torch.randperm(n, generator=torch.Generator().manual_seed(seed + 1))
+    inv = torch.empty_like(pi)
+    inv[pi] = torch.arange(n)
+    return s, d, torch.stack([pi[s], pi[d]]).contiguous(), inv
+
+
+def test_planted_generator_properties():
+    n, levels = 24000, ((128, 0.60), (16, 0.25), (4, 0.10))
+    s, d, _, _ = _planted(n, levels=levels)
+    assert s.numel() == d.numel() and int((s == d).sum()) == 0 and int(s.max()) < n
+    key = s * n + d
+    assert torch.unique(key).numel() == key.numel()                         # de-duplicated
+    assert torch.equal(torch.sort(key).values, torch.sort(d * n + s).values)   # symmetric
+    inside = [float(((s * g) // n == (d * g) // n).float().mean()) for g, _ in levels]
+    # a draw stays inside the group of a level when that level or a finer one claimed it (+ chance hits of coarser draws)
+    assert 0.58 < inside[0] < 0.68 and 0.83 < inside[1] < 0.92 and 0.93 < inside[2] < 0.99, inside
+    s2, d2 = __import__("gammagl_amd.synth", fromlist=["planted_pairs"]).planted_pairs(n, out_deg=12, levels=levels, seed=0)
+    assert torch.equal(s, s2) and torch.equal(d, d2)                        # counter-based: every rank builds the same list
+
+
+def test_both_sweep_forms_agree_and_recover_the_planted_groups():
+    from gammagl_amd.partition import cluster_order, halo_stats, relabel_edges
+
+    eng = _engine()
+    n = 24000
+    s, d, ei, inv = _planted(n)
+    a_rank, a_lab = cluster_order(ei, n, clusters=96, sweeps=8, seed=3, eng=eng, method="spmm", arrange=False)
+    b_rank, b_lab = cluster_order(ei, n, clusters=96, sweeps=8, seed=3, eng=eng, method="sort", arrange=False)
+    assert torch.equal(a_lab, b_lab) and torch.equal(a_rank, b_rank)        # one SpMM per sweep == one sort per sweep
+
+    def purity(lab, g):
+        true = (inv * g) // n
+        cnt = torch.bincount(lab * g + true, minlength=(int(lab.max()) + 1) * g).view(-1, g)
+        return float(cnt.max(1).values.sum()) / n
+
+    rank, lab = cluster_order(ei, n, clusters=n // 50, sweeps=30, seed=0, eng=eng)     # several times more labels than groups
+    assert purity(lab, 128) > 0.9 and purity(lab, 4) > 0.9
+    assert torch.equal(torch.sort(rank).values, torch.arange(n))             # a permutation
+    h_rand, share_rand = halo_stats(ei, n, 8)
+    h_clu, share_clu = halo_stats(relabel_edges(ei, rank), n, 8)
+    h_own, share_own = halo_stats(torch.stack([s, d]), n, 8)
+    assert h_clu * 2 < h_rand and share_clu > 0.85 > share_rand, (h_rand, h_clu, h_own, share_clu)
+    assert h_clu < 1.6 * h_own                                               # close to what the planted order itself gives
+
+
+def test_arrange_communities_orders_a_hierarchy():
+    from gammagl_amd.partition import arrange_communities
+
+    # 8 communities: pairs (0,5) (1,4) (2,7) (3,6) strongly linked, pairs-of-pairs weakly, everything else barely
+    q = torch.full((8, 8), 0.01, dtype=torch.float64)
+    for a, b in ((0, 5), (1, 4), (2, 7), (3, 6)):
+        q[a, b] = q[b, a] = 10.0
+    for a, b in ((0, 1), (5, 4), (2, 3), (7, 6)):
+        q[a, b] = q[b, a] = 1.0
+    pos = arrange_communities(q)
+    assert sorted(pos.tolist()) == list(range(8))
+    for a, b in ((0, 5), (1, 4), (2, 7), (3, 6)):
+        assert abs(int(pos[a]) - int(pos[b])) == 1, pos.tolist()             # strong pairs adjacent
+    assert {int(pos[i]) // 4 for i in (0, 5, 1, 4)} != {int(pos[i]) // 4 for i in (2, 7, 3, 6)} or True
+    half = lambda xs: {int(pos[i]) // 4 for i in xs}                         # noqa: E731
+    assert len(half((0, 5, 1, 4))) == 1 and len(half((2, 7, 3, 6))) == 1     # the two super-groups are contiguous halves
+    assert torch.equal(pos, arrange_communities(q))                          # deterministic
