@@ -635,12 +635,26 @@ def build_partition(n_nodes, n_edges, seed, rank, world, group, dev, eng, relabe
     `synth.rmat_partitioned` hands every rank only the edges whose destination it owns (same graph for
     every world size), the halo bookkeeping exchanges node ids only.  `parts` > world == 1: a dry
     partition — this process plays rank `rank` of `parts` (one GPU measuring one rank's share).
-    `kind` = "planted" (a graph with community structure) or `relabel` = "cluster" (the locality-aware order of
-    `partition.cluster_order`) need the whole graph in one place: every rank builds it itself
-    (`synth.full_graph_partitioned` — graphs that fit one GPU, i.e. everything up to the products size)."""
-    from .synth import full_graph_partitioned, rmat_partitioned
+    `kind` = "planted" (a graph with community structure) needs the whole graph in one place: every rank builds it
+    itself (`synth.full_graph_partitioned` — graphs that fit one GPU, i.e. everything up to the products size), and so
+    does `relabel` = "cluster" (the locality-aware order of `partition.cluster_order`) in a single process.  With
+    world > 1 the R-MAT shares are relabelled IN PLACE: `partition.cluster_order_distributed` sweeps over the shares
+    (halo labels by all-to-all), `synth.repartition` routes the renamed edges to their new owners — same result as
+    the single-process order, at any graph size."""
+    from .synth import _Comm, full_graph_partitioned, repartition, rmat_partitioned
 
-    if kind != "rmat" or relabel == "cluster":
+    if kind == "rmat" and relabel == "cluster" and world > 1 and (parts or world) == world:
+        from .partition import cluster_order_distributed
+
+        comm = _Comm(rank, world, group)
+        g = rmat_partitioned(n_nodes, n_edges, seed=seed, rank=rank, world=world, group=group, device=dev,
+                             relabel="random", order=order, stats=stats)
+        clusters = max(8, min(8192, int(n_nodes) // 600))
+        new_id, lab = cluster_order_distributed(g, comm, clusters=clusters, sweeps=30, seed=seed)
+        g = repartition(g, new_id, comm, order=order)
+        if stats is not None:
+            stats.update(clusters=clusters, local_edges=int(g["src"].numel()))
+    elif kind != "rmat" or relabel == "cluster":
         g = full_graph_partitioned(kind, n_nodes, n_edges, seed=seed, rank=rank, world=world, device=dev,
                                    relabel=relabel, order=order, parts=parts, stats=stats, eng=eng)
     else:

@@ -65,15 +65,18 @@ def arrange_communities(q, device=None):
     return pos
 
 
-def _sweep_by_sorting(src, dst, lab, C, N, cap, size):
+def _sweep_by_sorting(lab_src, dst, lab, C, cap, size):
     """One propagation sweep without the [N, C] one-hot matrix: the (node, neighbour's community) pairs of all edges are
     sorted and run-length counted, so the cost is one sort of E keys whatever the number of communities (the SpMM form
-    moves N x C floats per sweep: 20 GB at 2 000 labels on the products-sized graph).  Returns the label every node would
-    adopt (same scoring as the dense form: neighbour count, a small pull towards smaller communities, full communities
-    closed to newcomers, ties stay put)."""
+    moves N x C floats per sweep: 20 GB at 2 000 labels on the products-sized graph).  `lab_src` [E] = community of every
+    edge's source, `dst` [E] = its destination among the `lab.numel()` nodes whose labels `lab` holds (all nodes, or a
+    rank's own), `size` [C] the GLOBAL community sizes.  Returns the label every node would adopt (same scoring as the
+    dense form: neighbour count, a small pull towards smaller communities, full communities closed to newcomers, ties
+    stay put)."""
     dev = lab.device
+    N = int(lab.shape[0])
     ar = torch.arange(N, device=dev)
-    key = torch.cat([dst * C + lab[src], ar * C + lab])           # + every node's own label (count 0 if no neighbour has it)
+    key = torch.cat([dst * C + lab_src, ar * C + lab])            # + every node's own label (count 0 if no neighbour has it)
     uk, cnt = torch.unique(key, return_counts=True)
     node, l = uk // C, uk % C
     own = l == lab[node]
@@ -88,6 +91,27 @@ def _sweep_by_sorting(src, dst, lab, C, N, cap, size):
     keeps = torch.zeros(N, dtype=torch.bool, device=dev)
     keeps[node[own & (sc >= mx[node])]] = True
     return torch.where(keeps, lab, best)
+
+
+def _admit(new, lab, C, room, before=None):
+    """Movers are admitted to their target community only up to its free `room`, lowest node id first (deterministic).
+    `before` [C] (distributed runs): movers to each community on lower ranks — ranks own ascending id ranges, so
+    "lowest id first" over the whole graph is "lower ranks first, then local id"."""
+    N, dev = int(lab.shape[0]), lab.device
+    ar = torch.arange(N, device=dev)
+    move = new != lab
+    tgt = torch.where(move, new, torch.full_like(new, C))
+    order = torch.argsort(tgt * N + ar)                             # movers grouped by target community
+    st = tgt[order]
+    first = torch.searchsorted(st, torch.arange(C + 1, device=dev))
+    pos = torch.arange(N, device=dev) - first[st.clamp(max=C)]
+    stc = st.clamp(max=C - 1)
+    if before is not None:
+        pos = pos + before[stc]
+    ok = (st < C) & (pos < room[stc])
+    out = lab.clone()
+    out[order[ok]] = st[ok]
+    return out, move
 
 
 def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=None, balance=4.0, arrange=True, update=1.0,
@@ -116,7 +140,7 @@ def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=Non
     for _ in range(sweeps):
         size = torch.bincount(lab, minlength=C).float()
         if by_sort:
-            new = _sweep_by_sorting(src, dst, lab, C, N, cap, size)
+            new = _sweep_by_sorting(lab[src], dst, lab, C, cap, size)
         else:
             onehot = torch.zeros((N, C), dtype=torch.float32, device=dev)
             onehot[ar, lab] = 1.0
@@ -126,19 +150,10 @@ def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=Non
             score[:, size >= cap] = -1.0                                # full communities accept nobody new ...
             score[ar, lab] += 0.5 + (size[lab] >= cap).float() * 2.0    # ... but keep their members; ties stay put
             new = score.argmax(1)
-        # admit movers only up to each community's free room (lowest node id first: deterministic)
-        move = new != lab
         if update < 1.0:   # damped synchronous sweeps: a random share of the nodes may move (fewer two-cycles)
-            move &= torch.rand(N, generator=g, device=dev) < update
-        room = (cap - size).clamp(min=0)
-        tgt = torch.where(move, new, torch.full_like(new, C))
-        order = torch.argsort(tgt * N + ar)                         # movers grouped by target community
-        st = tgt[order]
-        first = torch.searchsorted(st, torch.arange(C + 1, device=dev))
-        pos = torch.arange(N, device=dev) - first[st.clamp(max=C)]
-        ok = (st < C) & (pos < room[st.clamp(max=C - 1)])
-        lab = lab.clone()
-        lab[order[ok]] = st[ok]
+            new = torch.where(torch.rand(N, generator=g, device=dev) < update, new, lab)
+        # admit movers only up to each community's free room (lowest node id first: deterministic)
+        lab, _ = _admit(new, lab, C, (cap - size).clamp(min=0))
     pos = torch.arange(C, device=dev)
     if arrange and C > 2:
         # communities in the order of the quotient graph's Fiedler vector, so that neighbouring id ranges hold
@@ -148,6 +163,85 @@ def cluster_order(edge_index, num_nodes, clusters=64, sweeps=20, seed=0, eng=Non
     rank = torch.empty(N, dtype=torch.int64, device=dev)
     rank[torch.argsort(pos[lab] * N + ar)] = ar
     return rank, lab
+
+
+class HaloIndex:
+    """Which entries of a per-node vector a rank's edges read from other ranks, and the one all-to-all that fetches
+    them: the id-only counterpart of `dist.PartitionedGraph`'s halo bookkeeping, for passes that run BEFORE the
+    partition is final (label sweeps, renaming).  `src` global ids, the rank owns [lo, hi)."""
+
+    def __init__(self, src, lo, hi, bounds, comm):
+        dev = src.device
+        self.comm, self.n_local = comm, hi - lo
+        rem = (src < lo) | (src >= hi)
+        self.halo_ids = torch.unique(src[rem])
+        bt = torch.tensor(bounds[1:-1], device=dev, dtype=torch.int64)
+        owner = torch.searchsorted(bt, self.halo_ids, right=True)          # ascending ids -> already grouped by owner
+        self.recv_counts = torch.bincount(owner, minlength=comm.world).tolist()
+        wanted = comm.route(self.halo_ids, owner)                            # ids the others read from me, by rank
+        sc = torch.tensor(self.recv_counts, dtype=torch.int64, device=dev)
+        self.send_counts = comm.all_to_all_counts(sc).tolist()
+        self.send_idx = wanted - lo
+        self.src_idx = torch.where(rem, self.n_local + torch.searchsorted(self.halo_ids, src), src - lo)
+
+    def gather(self, v):
+        """[v ; v at the halo ids] for a vector `v` over the rank's own nodes."""
+        if self.comm.world == 1 and not self.comm.always:
+            return v
+        import torch.distributed as dist
+
+        out = torch.empty(sum(self.recv_counts), dtype=v.dtype, device=v.device)
+        dist.all_to_all_single(out, v[self.send_idx].contiguous(), self.recv_counts, self.send_counts,
+                               group=self.comm.group)
+        return torch.cat([v, out])
+
+
+def cluster_order_distributed(g, comm, clusters=64, sweeps=20, seed=0, balance=4.0, arrange=True):
+    """`cluster_order` for a graph no single rank holds: `g` is the rank's share as `synth.rmat_partitioned` returns it
+    (edges into the nodes it owns).  Per sweep the ranks exchange the labels of their halo sources (one all-to-all of
+    int64 ids — 8 bytes per halo node against the 400 of a feature row), run `_sweep_by_sorting` on their own edges,
+    and agree on the community sizes and on the order movers are admitted in (an all-gather of [C] counters).
+    Deterministic and IDENTICAL to the single-process result for the same seed and method="sort": same initial
+    labels (one seeded generator, every rank keeps its slice), same scores, and the admission order "lowest node id
+    first" is "lower ranks first" because ranks own ascending ranges.  Returns (`new_id` [n_local]: new global id of
+    every own node, `label` [n_local])."""
+    src, dstl, bounds, N = g["src"], g["dst"], g["bounds"], int(g["num_nodes"])
+    dev = src.device
+    C = int(clusters)
+    lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    lab = torch.randint(0, C, (N,), generator=gen, device=dev)[lo:hi].clone()
+    real = src != dstl + lo                                   # (the shares carry the self-loops; the sweeps ignore them,
+    src, dstl = src[real], dstl[real]                         #  as `synth.full_graph_partitioned` does)
+    hx = HaloIndex(src, lo, hi, bounds, comm)
+    cap = balance * N / C
+    for _ in range(sweeps):
+        size = comm.all_reduce(torch.bincount(lab, minlength=C)).float()
+        new = _sweep_by_sorting(hx.gather(lab)[hx.src_idx], dstl, lab, C, cap, size)
+        movers = torch.bincount(new[new != lab], minlength=C)
+        before = comm.all_gather(movers)[: comm.rank].sum(0)
+        lab, _ = _admit(new, lab, C, (cap - size).clamp(min=0), before=before)
+    pos = torch.arange(C, device=dev)
+    if arrange and C > 2:
+        q = comm.all_reduce(torch.bincount(lab[dstl] * C + hx.gather(lab)[hx.src_idx], minlength=C * C))
+        if comm.rank == 0:      # one rank arranges, everyone gets ITS answer (eigenvectors are not bit-stable across devices)
+            pos = arrange_communities(q.view(C, C).double(),
+                                      device=dev if (C > 1500 and dev.type == "cuda") else None).to(dev)
+        pos = comm.broadcast(pos.contiguous())
+    # new id = (nodes in communities arranged before mine) + (members of my community on lower ranks) + (my index in it)
+    counts = comm.all_gather(torch.bincount(lab, minlength=C))              # [world, C]
+    size = counts.sum(0)
+    by_pos = torch.argsort(pos)
+    start = torch.empty(C, dtype=torch.int64, device=dev)
+    start[by_pos] = torch.cumsum(size[by_pos], 0) - size[by_pos]
+    n = hi - lo
+    ar = torch.arange(n, device=dev)
+    o = torch.argsort(lab * max(n, 1) + ar)
+    sl = lab[o]
+    first = torch.searchsorted(sl, torch.arange(C, device=dev))
+    new_id = torch.empty(n, dtype=torch.int64, device=dev)
+    new_id[o] = start[sl] + counts[: comm.rank].sum(0)[sl] + (ar - first[sl])
+    return new_id, lab
 
 
 def relabel_edges(edge_index, rank):

@@ -197,6 +197,34 @@ class _Comm:
         dist.all_to_all_single(out, send, rc.tolist(), sc.tolist(), group=self.group)
         return out
 
+    def all_to_all_counts(self, sc):
+        """What every rank sends me, given what I send every rank (`sc` int64 [world])."""
+        if self.world == 1 and not self.always:
+            return sc
+        import torch.distributed as dist
+
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        return rc
+
+    def all_gather(self, t):
+        """[world, *t.shape]: the same-shaped tensor of every rank."""
+        if self.world == 1 and not self.always:
+            return t.unsqueeze(0)
+        import torch.distributed as dist
+
+        bufs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(bufs, t.contiguous(), group=self.group)
+        return torch.stack(bufs)
+
+    def broadcast(self, t, src=0):
+        if self.world > 1 or self.always:
+            import torch.distributed as dist
+
+            dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src,
+                           group=self.group)
+        return t
+
     def all_gather_var(self, t):
         """Concatenation over ranks of 1-D tensors of different lengths (small ones only)."""
         if self.world == 1 and not self.always:
@@ -438,6 +466,42 @@ def cut_share(src, dst, num_nodes, parts=1, rank=0, order="src", dry=False):
         out["send_rows"] = [(torch.unique(so[own == q]) - lo) if q != me else torch.empty(0, dtype=torch.int64, device=dev)
                             for q in range(parts)]
     return out
+
+
+def repartition(g, new_id, comm, order="src"):
+    """A rank's share `g` (the dict `rmat_partitioned` returns, world == parts) after the nodes are RENAMED: `new_id`
+    int64 [n_local] = new global id of every node this rank owns (a permutation of 0..N-1 over the ranks, e.g.
+    `partition.cluster_order_distributed`).  New balanced bounds are cut from the renamed in-degrees, every edge is
+    routed to the rank that owns its renamed destination, order / loops / symmetric norm as `rmat_partitioned` leaves
+    them.  No rank ever holds more than its share (+ the [N] degree vector the shares carry anyway): the relabelling
+    step for graphs that do not fit one GPU.  The result is what `cut_share` makes of the renamed full edge list
+    (tests/test_dist_gloo.py checks exactly that)."""
+    from .partition import HaloIndex
+
+    src, dstl, bounds, N = g["src"], g["dst"], g["bounds"], int(g["num_nodes"])
+    dev = src.device
+    lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+    hx = HaloIndex(src, lo, hi, bounds, comm)
+    ns = hx.gather(new_id)[hx.src_idx]                       # renamed sources (halo ids fetched from their owners)
+    nd = new_id[dstl]
+    keep = ns != nd                                          # the loops are re-made for the new ranges
+    ns, nd = ns[keep], nd[keep]
+    deg = comm.all_reduce(torch.bincount(nd, minlength=N)) + 1
+    nb = bounds_from_degree(deg, comm.world)
+    bt = torch.tensor(nb[1:-1], device=dev, dtype=torch.int64)
+    got = comm.route(torch.stack([ns, nd], 1), torch.searchsorted(bt, nd, right=True))
+    s, d = got[:, 0].contiguous(), got[:, 1].contiguous()
+    del got, ns, nd
+    o = torch.argsort((s * N + d) if order == "src" else (d * N + s))
+    s, d = s[o], d[o]
+    lo, hi = nb[comm.rank], nb[comm.rank + 1]
+    loops = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+    s, d = torch.cat([s, loops]), torch.cat([d, loops])
+    dis = deg.to(torch.float32).pow(-0.5)
+    e_loc = torch.tensor([s.numel()], dtype=torch.int64, device=dev)
+    return {"src": s.contiguous(), "dst": (d - lo).contiguous(), "w": (dis[s] * dis[d]).contiguous(), "bounds": nb,
+            "deg": deg.to(torch.float32), "num_nodes": N, "rank": comm.rank, "parts": comm.world,
+            "e_global": int(comm.all_reduce(e_loc))}
 
 
 PLANTED_LEVELS = ((1024, 0.60), (64, 0.25), (8, 0.10))   # (groups, share of a node's edges that stay inside its group)

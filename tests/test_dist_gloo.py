@@ -453,9 +453,76 @@ def test_bench_launches_its_own_ranks(tmp_path):
         assert few.returncode != 0 and "{" not in few.stdout and "GPU" in (few.stderr + few.stdout)
 
 
+def _cluster_worker(rank, world, port, tmp):
+    """The locality order WITHOUT a global edge list: label sweeps over the ranks' shares (halo labels by all-to-all)
+    give exactly the single-process `cluster_order`, `repartition` gives exactly the share `cut_share` cuts out of the
+    renamed full edge list, and `build_partition(relabel="cluster")` at world > 1 goes that way."""
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = _emul_engine()
+        from gammagl_amd.dist import build_partition
+        from gammagl_amd.partition import cluster_order, cluster_order_distributed
+        from gammagl_amd.synth import _Comm, cut_share, planted_pairs, repartition, rmat_partitioned
+
+        comm = _Comm(rank, world, None)
+        # (a) a planted graph in a random labelling, cut into shares the way the R-MAT builder hands them out
+        N = 3000
+        src, dst = planted_pairs(N, out_deg=8, levels=((60, 0.7), (6, 0.2)), seed=2)
+        pi = torch.randperm(N, generator=torch.Generator().manual_seed(9))
+        src, dst = pi[src], pi[dst]
+        g = cut_share(src, dst, N, parts=world, rank=rank)
+        for C, arrange in ((24, True), (1500, False)):
+            new_id, lab = cluster_order_distributed(g, comm, clusters=C, sweeps=8, seed=4, arrange=arrange)
+            rk, lab1 = cluster_order(torch.stack([src, dst]), N, clusters=C, sweeps=8, seed=4, eng=eng, arrange=arrange,
+                                     method="sort")
+            lo, hi = g["bounds"][rank], g["bounds"][rank + 1]
+            assert torch.equal(lab, lab1[lo:hi]), (C, int((lab != lab1[lo:hi]).sum()))
+            assert torch.equal(new_id, rk[lo:hi])
+            if C == 24:   # (and the dense-score form of the sweep agrees too: what the one-process build uses up to 1024 labels)
+                rk2, _ = cluster_order(torch.stack([src, dst]), N, clusters=C, sweeps=8, seed=4, eng=eng, method="spmm")
+                assert torch.equal(rk2, rk)
+                g2 = repartition(g, new_id, comm)
+                ref = cut_share(rk[src], rk[dst], N, parts=world, rank=rank)
+                assert g2["bounds"] == ref["bounds"] and g2["e_global"] == ref["e_global"]
+                for k in ("src", "dst", "w", "deg"):
+                    assert torch.equal(g2[k], ref[k]), k
+                # the order did its job: fewer remote sources than in the random labelling
+                def remote(gg):
+                    lo_, hi_ = gg["bounds"][rank], gg["bounds"][rank + 1]
+                    t = torch.tensor([int(((gg["src"] < lo_) | (gg["src"] >= hi_)).sum())])
+                    return int(comm.all_reduce(t))
+                assert remote(g2) < 0.6 * remote(g), (remote(g2), remote(g))
+        # (b) the product entry point on the R-MAT shares: same graph as the one-process build, rank's share of it
+        st = {}
+        pg = build_partition(2000, 30000, 5, rank, world, None, "cpu", eng, relabel="cluster", stats=st)
+        g1 = rmat_partitioned(2000, 30000, seed=5, rank=0, world=1, relabel="random")
+        s1, d1 = g1["src"][:-2000], g1["dst"][:-2000]
+        rk, _ = cluster_order(torch.stack([s1, d1]), 2000, clusters=st["clusters"], sweeps=30, seed=5, eng=eng, method="sort")
+        ref = cut_share(rk[s1], rk[d1], 2000, parts=world, rank=rank)
+        assert pg.bounds == ref["bounds"] and pg.e_global == ref["e_global"]
+        assert pg.n_local == ref["bounds"][rank + 1] - ref["bounds"][rank]
+        x = torch.randn(2000, 8, generator=torch.Generator().manual_seed(1))
+        lo, hi = pg.bounds[rank], pg.bounds[rank + 1]
+        got = pg.aggregate(x[lo:hi].contiguous())
+        exp = torch.zeros(hi - lo, 8).index_add_(0, ref["dst"], x[ref["src"]] * ref["w"].unsqueeze(1))
+        assert torch.allclose(got, exp, rtol=1e-5, atol=1e-5)
+        dist.barrier()
+        open(os.path.join(tmp, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_locality_order_over_rank_shares_matches_one_process(world, tmp_path):
+    _run_ranks(world, tmp_path, "cluster")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, REPO)
     sys.path.insert(0, HERE)
     mode = sys.argv[5] if len(sys.argv) > 5 else ""
-    fn = {"bench": _bench_worker, "sage": _sage_worker, "shard": _shard_worker}.get(mode, _worker)
+    fn = {"bench": _bench_worker, "sage": _sage_worker, "shard": _shard_worker, "cluster": _cluster_worker}.get(mode, _worker)
     fn(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])

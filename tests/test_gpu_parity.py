@@ -441,6 +441,17 @@ def test_rccl_self_halo_exchange(eng, dev):
         gb = rmat_partitioned(30000, 500000, seed=2, device=dev)
         assert ga["e_global"] == gb["e_global"] == 530000
         assert torch.equal(ga["src"], gb["src"]) and torch.equal(ga["dst"], gb["dst"]) and torch.equal(ga["w"], gb["w"])
+        # the locality order over rank shares (label all-to-alls, counter all-gathers, the arrangement's broadcast)
+        # through RCCL: the order the one-process sweep finds, and the share cut_share makes of the renamed graph
+        from gammagl_amd.partition import cluster_order, cluster_order_distributed
+        from gammagl_amd.synth import _Comm, cut_share, repartition
+        comm = _Comm(0, 1, None, always=True)
+        new_id, lab = cluster_order_distributed(gb, comm, clusters=40, sweeps=6, seed=3)
+        s0, d0 = gb["src"][:-30000], gb["dst"][:-30000]
+        rk, lab1 = cluster_order(torch.stack([s0, d0]), 30000, clusters=40, sweeps=6, seed=3, eng=eng, method="sort")
+        assert torch.equal(lab, lab1) and torch.equal(new_id, rk)
+        g2, ref = repartition(gb, new_id, comm), cut_share(rk[s0], rk[d0], 30000)
+        assert all(torch.equal(g2[k], ref[k]) for k in ("src", "dst", "w"))
         # fused epilogue behind the exchange == aggregate -> bias_act, on the real backend
         hb = torch.randn(N, 64, generator=g, device=dev)
         bias = torch.randn(1, 64, generator=g, device=dev)
