@@ -85,7 +85,7 @@ class MessagePassing(nn.Module):
             return unsorted_segment_mean(msg, dst_index, num_nodes)
         elif aggr == 'max':
             return unsorted_segment_max(msg, dst_index, num_nodes)
-        raise NotImplementedError('Not support for this opearator')
+        raise NotImplementedError(f'aggr={aggr!r}: this layer aggregates with sum, mean or max')
 
     def message_aggregate(self, x, edge_index, edge_weight=None, aggr='sum'):
         if use_ext:
