@@ -18,12 +18,21 @@ segment ops, ``(Tensor index, Tensor weight, Tensor x) -> Tensor`` for the SpMMs
 tensors' device exactly like the reference's ``x.is_cuda()`` / ``x.is_cpu()`` switch (src/segment_sum.cpp:19-33):
 GPU tensors -> hand-written HIP for gfx950 (libggl_mpops_hip.so), CPU tensors -> the host build of the same kernel
 sources (libggl_mpops_host.so).  Needs ``gammagl_amd`` importable (on ``sys.path`` / installed).
+
+The callables bind the C++-registered dispatcher ops ``torch.ops.ggl.*`` (gammagl_amd/lib/libggl_torch.so: dispatcher ->
+C++ -> C ABI -> kernel, no Python in between — like the pybind module they replace) when that library is built, else the
+Python-registered ``torch.ops.gammagl_amd.*`` over the same kernels (bit-identical results, tests/test_torch_cpp.py).
 """
 import torch
 
-from gammagl_amd import torch_ops as _torch_ops   # registers torch.ops.gammagl_amd.* for the CUDA (HIP) and CPU keys
+from gammagl_amd import cpp_ops as _cpp_ops
 
-_ops = _torch_ops.ops
+if _cpp_ops.enabled():
+    _ops = _cpp_ops.load()
+else:
+    from gammagl_amd import torch_ops as _torch_ops   # registers torch.ops.gammagl_amd.* for the CUDA (HIP) and CPU keys
+
+    _ops = _torch_ops.ops
 
 __all__ = ["c_segment_sum", "c_segment_mean", "c_segment_max", "c_spmm_sum", "c_spmm_mean", "c_spmm_max", "c_bspmm_sum"]
 

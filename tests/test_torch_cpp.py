@@ -1,0 +1,263 @@
+"""torch.ops.ggl.* — the ops registered with the dispatcher from C++ (gammagl_amd/csrc/torch/ggl_torch.cpp ->
+libggl_torch.so) — exercised WITHOUT a GPU through the CPU key (libggl_mpops_host.so, the host build of the kernel
+sources): the reference's known answers and the oracle (the same checkers the ctypes engine passes), bit-for-bit
+equality with the Python-registered ops, dispatcher contracts (opcheck: schema / fake tensors / autograd
+registration), TorchScript visibility, error types, the plan cache's lifetime rules, and the loud failure when a
+kernel library is missing."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import parity_cases as pc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+class CppOps:
+    """The seven entry points under the names the checkers in parity_cases.py call on an Engine."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        for n in ("segment_sum", "segment_mean", "spmm_sum", "spmm_mean", "spmm_max", "bspmm_sum"):
+            setattr(self, "c_" + n, getattr(ops, n))
+
+    def c_segment_max(self, x, index, N):
+        return self.ops.segment_max(x, index, N)[0]
+
+    def segment_max_with_arg(self, x, index, N):
+        return self.ops.segment_max(x, index, N)
+
+
+@pytest.fixture(scope="module")
+def cpp():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "gammagl_amd", "csrc"), "host", "torch"])
+    from gammagl_amd import cpp_ops
+
+    return CppOps(cpp_ops.load())
+
+
+def test_reference_known_answers_and_oracle(cpp, golden, oracle):
+    dev = torch.device("cpu")
+    pc.check_kat(cpp, dev, golden)
+    pc.check_segment_all_dtypes(cpp, dev, golden)
+    pc.check_segment_fwd_bwd(cpp, dev, golden)
+    pc.check_special_values(cpp, dev, golden)
+    pc.check_spmm_golden(cpp, dev, golden)
+    pc.check_random_vs_oracle(cpp, dev, oracle, seed=3)
+    pc.check_edge_cases(cpp, dev, oracle)
+
+
+def _pair(t):
+    return t.clone().requires_grad_(True), t.clone().requires_grad_(True)
+
+
+def test_bit_identical_to_the_python_registered_ops(cpp):
+    """Same kernels, same launch policy (long-row threshold, padded copies, sorted weights on second sight, one-piece
+    16-bit rows): forward values AND gradients equal bit for bit, on a graph with hub rows longer than the threshold."""
+    from gammagl_amd import torch_ops
+
+    P, C = torch_ops.ops, cpp.ops
+    g = torch.Generator().manual_seed(0)
+    N, E = 700, 30000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :6000] = 3                                   # a hub: 6000 > the 256-element threshold of a plan this size
+    ei[0, 6000:9000] = 5
+    for dt in (torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int64, torch.int32, torch.uint8):
+        for K in ((), (1,), (7,), (12,), (3, 5)):
+            x = (torch.randn((E,) + K, generator=g) * 4).to(dt)
+            for name in ("segment_sum", "segment_mean"):
+                assert torch.equal(getattr(P, name)(x, ei[1], N), getattr(C, name)(x, ei[1], N)), (name, dt, K)
+            a, b = P.segment_max(x, ei[1], N), C.segment_max(x, ei[1], N)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (dt, K)
+    for name in ("segment_sum", "segment_mean", "segment_max"):
+        x1, x2 = _pair(torch.randn(E, 9, generator=g))
+        a, b = getattr(P, name)(x1, ei[1], N), getattr(C, name)(x2, ei[1], N)
+        a, b = (a[0], b[0]) if name == "segment_max" else (a, b)
+        go = torch.randn(a.shape, generator=g)
+        a.backward(go)
+        b.backward(go)
+        assert torch.equal(a, b) and torch.equal(x1.grad, x2.grad), name
+    w = torch.rand(E, generator=g)
+    for K in (1, 4, 47, 64, 300):
+        xn = torch.randn(N, K, generator=g)
+        for name in ("spmm_sum", "spmm_mean", "spmm_max"):
+            for ww in (w, None):
+                for rep in range(3):                   # (the third call runs on the sorted copy of the weights)
+                    x1, x2 = _pair(xn)
+                    a, b = getattr(P, name)(ei, ww, x1), getattr(C, name)(ei, ww, x2)
+                    go = torch.randn(a.shape, generator=g)
+                    a.backward(go)
+                    b.backward(go)
+                    assert torch.equal(a, b) and torch.equal(x1.grad, x2.grad), (name, K, ww is None, rep)
+    for H, Cc in ((4, 8), (2, 41), (1, 32), (3, 20), (8, 1)):
+        x1, x2 = _pair(torch.randn(N, H, Cc, generator=g))
+        w1, w2 = _pair(torch.rand(E, H, generator=g))
+        a, b = P.bspmm_sum(ei, w1, x1), C.bspmm_sum(ei, w2, x2)
+        go = torch.randn(a.shape, generator=g)
+        a.backward(go)
+        b.backward(go)
+        assert torch.equal(a, b) and torch.equal(x1.grad, x2.grad) and torch.equal(w1.grad, w2.grad), (H, Cc)
+
+
+def test_dispatcher_contracts(cpp):
+    ops = cpp.ops
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, 11, (2, 60), generator=g)
+    x = torch.randn(60, 5, generator=g)
+    xn = torch.randn(11, 4, generator=g)
+    w = torch.rand(60, generator=g)
+    utils = ("test_schema", "test_faketensor", "test_autograd_registration")
+    torch.library.opcheck(ops.segment_sum.default, (x, ei[1], 11), test_utils=utils)
+    torch.library.opcheck(ops.segment_mean.default, (x.clone().requires_grad_(True), ei[1], 11), test_utils=utils)
+    torch.library.opcheck(ops.segment_max.default, (x, ei[1], 11), test_utils=utils)
+    torch.library.opcheck(ops.spmm_sum.default, (ei, w, xn.clone().requires_grad_(True)), test_utils=utils)
+    torch.library.opcheck(ops.spmm_mean.default, (ei, None, xn), test_utils=utils)
+    torch.library.opcheck(ops.spmm_max.default, (ei, w, xn), test_utils=utils)
+    torch.library.opcheck(ops.bspmm_sum.default, (ei, torch.rand(60, 2, generator=g), torch.randn(11, 2, 4, generator=g)),
+                          test_utils=utils)
+    # numerical gradients (f64 where the op takes it)
+    xd = torch.randn(60, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda t: ops.segment_sum(t, ei[1], 11), (xd,))
+    assert torch.autograd.gradcheck(lambda t: ops.segment_mean(t, ei[1], 11), (xd,))
+    # no grad mode / inference mode run the backend kernel directly; a graph is recorded only when asked for
+    xr = xn.clone().requires_grad_(True)
+    assert ops.spmm_sum(ei, w, xr).grad_fn is not None
+    with torch.no_grad():
+        assert ops.spmm_sum(ei, w, xr).grad_fn is None
+    with torch.inference_mode():
+        assert torch.equal(ops.spmm_sum(ei, w, xn), ops.spmm_sum(ei, w, xr).detach())
+    # the arg-max output carries no gradient; the weight of bspmm does (the reference populates it: gspmm.cpp:259)
+    out, arg = ops.segment_max(x.clone().requires_grad_(True), ei[1], 11)
+    assert out.requires_grad and not arg.requires_grad and arg.dtype == torch.int64
+
+
+def test_visible_to_torchscript_without_python(cpp, tmp_path):
+    """A scripted function calling the op serialises and runs from the saved archive: the call goes dispatcher -> C++,
+    there is no Python callable behind the op to pickle (the Python-registered ops cannot do this)."""
+
+    @torch.jit.script
+    def layer(x: torch.Tensor, ei: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        h = torch.ops.ggl.spmm_sum(ei, w, x)
+        m = torch.ops.ggl.segment_max(h[ei[0]], ei[1], x.size(0))
+        return torch.relu(h) + m[0]
+
+    g = torch.Generator().manual_seed(1)
+    ei = torch.randint(0, 20, (2, 90), generator=g)
+    ei[1, :20] = torch.arange(20)                      # (every node has an in-edge: no -FLT_MAX rows in the max)
+    x, w = torch.randn(20, 6, generator=g), torch.rand(90, generator=g)
+    want = torch.relu(cpp.ops.spmm_sum(ei, w, x)) + cpp.ops.segment_max(cpp.ops.spmm_sum(ei, w, x)[ei[0]], ei[1], 20)[0]
+    assert torch.equal(layer(x, ei, w), want)
+    assert "ggl::spmm_sum" in str(layer.graph)
+    path = str(tmp_path / "layer.pt")
+    layer.save(path)
+    code = ("import sys, torch; sys.path.insert(0, %r); from gammagl_amd import cpp_ops; cpp_ops.load(); "
+            "f = torch.jit.load(%r); torch.manual_seed(0); "
+            "ei = torch.randint(0, 20, (2, 90)); x = torch.randn(20, 6); w = torch.rand(90); "
+            "y = f(x, ei, w); assert y.shape == (20, 6); print('ok')" % (REPO, path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_traces_under_torch_compile_forward_and_backward(cpp):
+    """The autograd formulas only call dispatcher ops (ggl::*_backward have backend AND Meta kernels), so a training
+    graph containing the ops is captured whole (fullgraph) by dynamo and by AOTAutograd — forward and backward."""
+    g = torch.Generator().manual_seed(2)
+    ei = torch.randint(0, 20, (2, 90), generator=g)
+    w = torch.rand(90, generator=g)
+    wh = torch.rand(90, 2, generator=g)
+
+    def net(x, xb):
+        h = torch.relu(torch.ops.ggl.spmm_sum(ei, w, x)) + torch.ops.ggl.spmm_mean(ei, None, x)
+        m = torch.ops.ggl.segment_max(h[ei[0]], ei[1], 20)[0].clamp(min=-10.0)
+        s = torch.ops.ggl.segment_mean(h[ei[0]], ei[1], 20) + torch.ops.ggl.spmm_max(ei, w, x)
+        return (h * m).sum() + s.sum() + torch.ops.ggl.bspmm_sum(ei, wh, xb).pow(2).sum()
+
+    x0, xb0 = torch.randn(20, 6, generator=g), torch.randn(20, 2, 3, generator=g)
+    xe, xbe = x0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+    want = net(xe, xbe)
+    want.backward()
+    for backend in ("eager", "aot_eager"):
+        xc, xbc = x0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+        got = torch.compile(net, backend=backend, fullgraph=True)(xc, xbc)
+        got.backward()
+        assert torch.equal(got, want) and torch.equal(xc.grad, xe.grad) and torch.equal(xbc.grad, xbe.grad), backend
+
+
+def test_error_types_match_the_reference(cpp):
+    ops = cpp.ops
+    x = torch.ones(3, 2)
+    with pytest.raises(RuntimeError, match="Long"):                  # data_ptr<int64_t>() on an int32 index
+        ops.segment_sum(x, torch.tensor([0, 1, 1], dtype=torch.int32), 2)
+    with pytest.raises(IndexError):                                   # segment_sum_cpu.cpp:17-19
+        ops.segment_sum(torch.ones(4, 2), torch.tensor([0, 1, 1]), 2)
+    with pytest.raises(IndexError):                                   # segment_sum_cpu.cpp:13-15
+        ops.segment_sum(x, torch.tensor([[0, 1, 1]]), 2)
+    with pytest.raises(IndexError):                                   # segment_max_cpu.cpp:50 (here: every reduction)
+        ops.segment_max(x, torch.tensor([0, 1, 7]), 2)
+    with pytest.raises(IndexError):
+        ops.segment_sum(x, torch.tensor([0, -1, 1]), 2)
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]])
+    with pytest.raises(RuntimeError, match="Float"):                  # spmm_sum_cpu.cpp:22 data_ptr<float>()
+        ops.spmm_sum(ei, None, torch.ones(3, 2, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="Float"):
+        ops.spmm_sum(ei, torch.ones(3, dtype=torch.float64), torch.ones(3, 2))
+    with pytest.raises(IndexError):                                   # a source id outside x
+        ops.spmm_sum(torch.tensor([[0, 1, 9], [1, 2, 0]]), None, torch.ones(3, 2))
+    with pytest.raises(RuntimeError, match="heads"):
+        ops.bspmm_sum(ei, torch.ones(3), torch.ones(3, 2, 4))
+    with pytest.raises(RuntimeError, match="num_nodes, heads, channels"):
+        ops.bspmm_sum(ei, torch.ones(3, 2), torch.ones(3, 8))
+    with pytest.raises(RuntimeError, match="one row per edge"):
+        ops.spmm_sum(ei, torch.ones(5), torch.ones(3, 2))
+
+
+def test_plan_cache_follows_version_and_storage(cpp):
+    ops = cpp.ops
+    ops.clear_caches()
+    ids = torch.tensor([0, 2, 2, 1, 0])
+    x = torch.arange(10.0).view(5, 2)
+    b0, h0 = ops.plan_stats()
+    r1 = ops.segment_sum(x, ids, 3)
+    r2 = ops.segment_sum(x, ids, 3)                                   # same tensor, same version: the cached plan
+    b1, h1 = ops.plan_stats()
+    assert (b1 - b0, h1 - h0) == (1, 1) and torch.equal(r1, r2)
+    ops.segment_mean(x, ids, 4)                                       # another N: another plan
+    assert ops.plan_stats()[0] - b1 == 1
+    ids[0] = 1                                                        # in-place edit bumps the version counter: re-planned
+    r3 = ops.segment_sum(x, ids, 3)
+    assert ops.plan_stats()[0] - b1 == 2
+    assert r3.tolist() == [[8.0, 9.0], [6.0, 8.0], [6.0, 8.0]]
+    view = ids[1:]                                                    # a view is its own key (offset / shape)
+    assert ops.segment_sum(x[1:], view, 3).tolist() == [[8.0, 9.0], [6.0, 7.0], [6.0, 8.0]]
+    # an entry dies with its storage: a new tensor that lands on the recycled address is never mistaken for the old one
+    for i in range(50):
+        t = torch.full((5,), i % 3, dtype=torch.int64)
+        got = ops.segment_sum(x, t, 3)
+        assert float(got[i % 3].sum()) == float(x.sum()), i
+        del t
+    ops.clear_caches()
+
+
+def test_missing_kernel_library_fails_loudly():
+    code = ("import sys, torch; sys.path.insert(0, %r); from gammagl_amd import cpp_ops; ops = cpp_ops.load()\n"
+            "try:\n    ops.segment_sum(torch.ones(2, 2), torch.tensor([0, 1]), 2)\n"
+            "except RuntimeError as e:\n    print('RAISED', e)\n" % REPO)
+    env = dict(os.environ, GGL_TORCH_HOST_LIB="/nonexistent/libggl_mpops_host.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert "RAISED" in r.stdout and "/nonexistent/libggl_mpops_host.so" in r.stdout, (r.stdout, r.stderr[-1500:])
+
+
+def test_zero_edit_module_binds_the_cpp_ops(cpp):
+    import importlib
+
+    m = importlib.import_module("gammagl_amd.compat._torch_ext")
+    assert m._ops is torch.ops.ggl
+    ei = torch.tensor([[0, 1, 2, 2], [1, 2, 0, 1]])
+    x = torch.arange(6.0).view(3, 2)
+    np.testing.assert_array_equal(m.c_spmm_sum(ei, torch.ones(4), x).numpy(), [[4, 5], [4, 6], [2, 3]])
+    assert m.c_bspmm_sum(ei, torch.ones(4), x.view(3, 1, 2)).shape == (3, 1, 2)     # the 1-D ones([E]) of mpops/torch.py:355
