@@ -77,15 +77,15 @@ class MessagePassing(nn.Module):
             return msg * edge_weight.unsqueeze(-1)
         return msg
 
+    _REDUCERS = {'sum': unsorted_segment_sum, 'mean': unsorted_segment_mean, 'max': unsorted_segment_max}
+
     def aggregate(self, msg, edge_index, num_nodes=None, aggr='sum'):
-        dst_index = edge_index[1, :]
-        if aggr == 'sum':
-            return unsorted_segment_sum(msg, dst_index, num_nodes)
-        elif aggr == 'mean':
-            return unsorted_segment_mean(msg, dst_index, num_nodes)
-        elif aggr == 'max':
-            return unsorted_segment_max(msg, dst_index, num_nodes)
-        raise NotImplementedError(f'aggr={aggr!r}: this layer aggregates with sum, mean or max')
+        """Reduce the messages onto their destination nodes (message_passing.py:63-92: same signature, same three
+        reducers over edge_index[1])."""
+        reduce = self._REDUCERS.get(aggr)
+        if reduce is None:
+            raise NotImplementedError(f'aggr={aggr!r}: this layer aggregates with sum, mean or max')
+        return reduce(msg, edge_index[1, :], num_nodes)
 
     def message_aggregate(self, x, edge_index, edge_weight=None, aggr='sum'):
         if use_ext:
