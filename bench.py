@@ -78,6 +78,12 @@ def parse():
     p.add_argument("--no-tuned-gemm", action="store_true",
                    help="do not load gammagl_amd/tuned/*.csv (PyTorch TunableOp results: which rocBLAS / hipBLASLt f32 "
                         "kernel runs each GEMM shape of the step, chosen offline by tools/tune_gemms.sh)")
+    p.add_argument("--hipgraph", default="auto", choices=["auto", "on", "off"],
+                   help="GCN workloads on ONE rank: record the whole training step (fwd + bwd + Adam, dropout draws and "
+                        "side-stream GEMMs included) into a hipGraph once and time its replays.  auto = graphs below 2^25 "
+                        "edges, whose ~100 launches per step are issued slower than they execute; larger steps are "
+                        "kernel-bound (zero gaps in the timeline) and run eagerly.  N > 1 steps are always eager (RCCL "
+                        "collectives cannot be recorded on this stack, DESIGN.md §7)")
     p.add_argument("--no-comparison", action="store_true",
                    help="skip the other association and the second node order (profiling runs)")
     p.add_argument("--no-cpu-baseline", action="store_true")

@@ -104,14 +104,27 @@ def _gcn_data(pg, f_in, n_cls, seed, rank, dev, world):
     return x, y, train_local, max(int(nt), 1), gen
 
 
+def _wants_graph(args, pg, dev, world):
+    """Record the step into a hipGraph?  One rank on a GPU only; `auto`: launch-bound sizes (bench.py --hipgraph)."""
+    mode = getattr(args, "hipgraph", "off")
+    if mode == "off" or world > 1 or dev.type != "cuda" or (pg.comm and not pg.dry):
+        return False
+    return mode == "on" or pg.e_local < (1 << 25)
+
+
 def _time_steps(trainer, data, args, dev, world):
     x, y, train_local, n_train, _ = data
+    step = lambda: trainer.step(x, y, train_local, n_train)   # noqa: E731
+    trainer.graphed = _wants_graph(args, trainer.pg, dev, world)
+    if trainer.graphed:
+        trainer.capture(x, y, train_local, n_train, warmup=max(int(args.warmup), 3))
+        step = trainer.replay
     for _ in range(args.warmup):
-        trainer.step(x, y, train_local, n_train)
+        step()
     _sync(dev, world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(x, y, train_local, n_train)
+        loss = step()
     _sync(dev, world)
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     lsum = loss.detach().double().reshape(1).clone()
@@ -240,11 +253,12 @@ def run_gcn(args, dev, rank, world, eng=None):
 
     def trainer(aggregate_first):
         return DistGCNTrainer(pg, f_in, args.hidden, n_cls, num_layers=args.layers, seed=args.seed, device=dev,
-                              aggregate_first=aggregate_first)
+                              aggregate_first=aggregate_first, capturable=_wants_graph(args, pg, dev, world))
 
     tr = trainer(af_main)
     dt, lsum = _time_steps(tr, data, args, dev, world)
     n_agg = tr.net.agg_per_step     # aggregations the step actually executed (counted by the model's forward)
+    graphed = bool(getattr(tr, "graphed", False))
     value = n_agg * e_unit * args.steps / dt
     exchange = None
     if pg.comm and not getattr(args, "no_exchange_report", False):
@@ -290,6 +304,8 @@ def run_gcn(args, dev, rank, world, eng=None):
                        f"{pg.n_halo} halo rows; send lists and buffers as in the {parts}-rank run, nothing on the wire); value "
                        f"counts the edges THIS rank aggregates" if parts else ""),
         "association": "A (X W)" if not af_main else "(A X) W where narrower",
+        "hipgraph": ("the whole step (fwd + bwd + Adam) recorded once into a hipGraph, the timed steps are its replays"
+                     if graphed else "no: eager launches"),
         "aggregations_per_step": n_agg,
         "aggregate_first" if not af_main else "transform_first": side,
         "parallelism": (f"node-partition x{world}, 1-hop halo all-to-all-v, per-rank graph construction" if world > 1 else
