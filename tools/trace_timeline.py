@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline view of a rocprofv3 kernel trace: per queue, the launches of the LAST training step (between
 the last two Adam kernels' neighbourhoods) with start offset, duration and idle gap — shows what sits
-on the critical path and what overlaps.   python tools/trace_timeline.py <kernel_trace.csv> [marker]"""
+on the critical path and what overlaps.   python tools/trace_timeline.py <kernel_trace.csv> [marker] [min_ms]"""
 import csv
 import re
 import sys
@@ -20,6 +20,7 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 marker = sys.argv[2] if len(sys.argv) > 2 else "multi_tensor_apply"
+min_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.15   # launches shorter than this (and not after a gap) are not listed
 marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 # a step = from the first kernel after the previous step's last optimizer kernel to this step's last one
 ends = [marks[i] for i in range(len(marks)) if i + 1 == len(marks) or marks[i + 1] - marks[i] > 20]
@@ -34,5 +35,5 @@ for r in rows[lo:hi + 1]:
     gap = (r["s"] - busy_until.get(q, r["s"])) / 1e6
     busy_until[q] = r["e"]
     dur = (r["e"] - r["s"]) / 1e6
-    if dur >= 0.15 or gap >= 0.15:
+    if dur >= min_ms or gap >= 0.15:
         print(f"q{q} +{(r['s'] - t0) / 1e6:8.2f} ms  dur {dur:7.3f}  gap {gap:6.3f}  {short(r['Kernel_Name'])}")
