@@ -478,6 +478,38 @@ def test_rccl_self_halo_exchange(eng, dev):
         dist.destroy_process_group()
 
 
+def test_bench_line_contract_on_the_gpu():
+    """`python bench.py` end to end on the MI355X at toy size: ONE JSON line with every field of the driver's contract,
+    a roofline fraction that cannot exceed 1, the in-run counter pass (or its stated reason), the CPU baseline on the
+    reference's ops, and the step replayed from a hipGraph (toy sizes are launch-bound)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--workload", "tiny", "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "edges/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert "workload" in d["config"] and d["config"]["association"] == "A (X W)" and d["engine"] == "hip"
+    assert d["config"]["hipgraph"].startswith("the whole step")
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - min(rf["achieved"], rf["peak"]) / rf["peak"]) < 1e-6
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
+
+
 def test_cpp_registered_ops_match_the_engine_bit_for_bit(eng, dev):
     """torch.ops.ggl.* (TORCH_LIBRARY in C++: dispatcher -> libggl_torch.so -> C ABI -> HIP kernel) against the ctypes
     engine on the GPU: same kernels and the same launch policy, so values and gradients are equal bit for bit — hub
