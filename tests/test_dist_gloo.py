@@ -245,6 +245,10 @@ def _bench_worker(rank, world, port, tmp):
         assert set(rf) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "eff_GBps", "compulsory_bytes"}
         assert rf["frac"] <= 1.0 and abs(rf["achieved"] - 3000.0) < 1e-6 and rf["traffic_over_compulsory"] == 6.0
         json.dumps(out)
+        # --relabel cluster at world > 1: the order is computed over the ranks' shares, the same bench body runs on it
+        args.relabel, args.no_comparison, args.no_exchange_report = "cluster", True, True
+        out2, ctx2 = benchmarks.run_gcn(args, torch.device("cpu"), rank, world, eng=_emul_engine())
+        assert ctx2["pg"].e_global == 6400 and out2["value"] > 0 and "relabel=cluster" in out2["config"]["workload"]
         open(os.path.join(tmp, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()
