@@ -413,9 +413,9 @@ def main():
         # library GEMM selection only: the same IEEE f32 products, each shape on the rocBLAS / hipBLASLt kernel an offline
         # TunableOp pass measured fastest on this part (the file's validators — torch / HIP / library versions, gfx
         # arch — must match, otherwise torch ignores it and the default heuristics pick)
-        ds = WORKLOADS[args.workload]["dataset"] or "tiny"
+        ds = (WORKLOADS[args.workload]["dataset"] or "tiny") if kind == "gcn" else args.workload.replace("-", "_")
         path = os.path.join(REPO, "gammagl_amd", "tuned", f"tunableop_gfx950_{ds}.csv")
-        if os.path.exists(path) and kind == "gcn":
+        if os.path.exists(path):
             try:
                 import torch.cuda.tunable as tun
 
