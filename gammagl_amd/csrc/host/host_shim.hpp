@@ -58,6 +58,7 @@ template <typename T> static inline T __builtin_amdgcn_readfirstlane(T v) { retu
 
 // order-independent atomics only (min): one host thread at a time, so a plain update is the same result
 static inline long long atomicMin(long long *p, long long v) { const long long o = *p; if (v < o) *p = v; return o; }
+static inline int atomicMax(int *p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };

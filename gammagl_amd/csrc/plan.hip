@@ -66,6 +66,30 @@ __global__ __launch_bounds__(kBlock) void check_ids_kernel(const int64_t *ids, i
   }
 }
 
+// the two kernels above in one pass (small plans): flags as check_ids_kernel, keys = ids, vals = 0..E-1
+__global__ __launch_bounds__(kBlock) void check_keys_kernel(const int64_t *ids, int64_t E, int64_t N, int32_t *flags,
+                                                            uint32_t *keys, int32_t *vals) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < E; i += stride) {
+    const int64_t v = ids[i];
+    if (v < 0 || v >= N) flags[0] = 1;
+    if (i > 0 && ids[i - 1] > v) flags[1] = 1;
+    keys[i] = (uint32_t)v;
+    vals[i] = (int32_t)i;
+  }
+}
+
+// out[0] = max_s (rowptr[s + 1] - rowptr[s])   (out zeroed by the caller; E < 2^31 so a row length fits an int)
+__global__ __launch_bounds__(kBlock) void max_len_kernel(const int64_t *rowptr, int64_t N, int32_t *out) {
+  const int64_t stride = grid_threads();
+  int32_t m = 0;
+  for (int64_t i = thread_id(); i < N; i += stride) {
+    const int32_t len = (int32_t)(rowptr[i + 1] - rowptr[i]);
+    m = len > m ? len : m;
+  }
+  if (m > 0) atomicMax(out, m);   // order-independent
+}
+
 __global__ __launch_bounds__(kBlock) void keys_iota_kernel(const int64_t *ids, int64_t E,
                                                            uint32_t *keys, int32_t *vals) {
   const int64_t stride = grid_threads();
@@ -92,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void rowptr_kernel(const KeyT *keys, int64_
 
 // ---- two-level ordered scan over rows (no atomics, no LDS) --------------------------------------
 constexpr int64_t kSpan = 2048;  // rows per scanning thread
+constexpr int64_t kSmallPlan = (int64_t)1 << 22;  // plans up to this many elements are built behind one host read
 
 // per span: number of long rows, number of chunks, longest row
 __global__ __launch_bounds__(kBlock) void span_count_kernel(const int64_t *rowptr, int64_t N,
@@ -337,8 +362,43 @@ extern "C" int ggl_plan_build(const int64_t *ids, int64_t E, int64_t N, int32_t 
   int32_t *vals_in = reinterpret_cast<int32_t *>(ws + off);
   off += align_up((size_t)E * 4, 256);
 
-  int32_t flags_host[2] = {0, 0};
+  int32_t flags_host[4] = {0, 0, 0, 0};
   GGL_HIP_CHECK(hipMemsetAsync(flags, 0, 256, s));
+  if (E > 0 && E <= kSmallPlan) {
+    // A small plan is usually a FRESH one (a sampled block's edge list, rebuilt every mini-batch by loaders that hand
+    // out COO): its cost is host round trips, not device work.  Everything is queued behind ONE read at the end —
+    // the ids are sorted whether or not they arrive sorted (a stable sort of sorted keys leaves the identity), range
+    // and sortedness flags and the longest row come back together.  (Large plans below keep the early read: skipping
+    // the sort of an already sorted 10^8-element list is worth a round trip.)
+    GGL_LAUNCH((check_keys_kernel), grid_for(E), kBlock, s, ids, E, N, flags, keys_in, vals_in);
+    GGL_LAUNCH_CHECK();
+#ifndef GGL_EMULATE
+    const int bits = key_bits(N);
+    size_t tmp = sort_temp_bytes(E, bits);
+    GGL_HIP_CHECK(rocprim::radix_sort_pairs(ws + off, tmp, (const uint32_t *)keys_in, keys_out,
+                                            (const int32_t *)vals_in, perm, (size_t)E, 0u, (unsigned)bits, s));
+#else
+    {
+      std::vector<int32_t> order((size_t)E);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return keys_in[a] < keys_in[b]; });
+      for (int64_t i = 0; i < E; ++i) {
+        perm[i] = order[(size_t)i];
+        keys_out[i] = keys_in[order[(size_t)i]];
+      }
+    }
+#endif
+    GGL_LAUNCH((rowptr_kernel<uint32_t>), grid_for(N + 1), kBlock, s, (const uint32_t *)keys_out, E, N, rowptr);
+    GGL_LAUNCH_CHECK();
+    GGL_LAUNCH((max_len_kernel), grid_for(N > 0 ? N : 1), kBlock, s, (const int64_t *)rowptr, N, flags + 2);
+    GGL_LAUNCH_CHECK();
+    GGL_HIP_CHECK(hipMemcpyAsync(flags_host, flags, 16, hipMemcpyDeviceToHost, s));
+    GGL_HIP_CHECK(hipStreamSynchronize(s));
+    GGL_REQUIRE(flags_host[0] == 0, GGL_EINDEX, "segment id out of range [0, %lld)", (long long)N);
+    if (is_sorted_host) *is_sorted_host = flags_host[1] == 0 ? 1 : 0;
+    if (max_len_host) *max_len_host = flags_host[2];
+    return GGL_OK;
+  }
   if (E > 0) {
     GGL_LAUNCH((check_ids_kernel), grid_for(E), kBlock, s, ids, E, N, flags);
     GGL_LAUNCH_CHECK();

@@ -152,11 +152,18 @@ static int64_t auto_chunk(int64_t E) {   // the largest power of two <= E / resi
   return c;
 }
 
+static Tensor row_order_of(const Tensor &counts);
+
 struct SegPlan {
   int64_t N = 0, E = 0, chunk = 0, n_long = 0, n_chunks = 0, max_len = 0, xcd_run = 0;
   bool sorted = false;
   uint64_t uid = 0;
-  Tensor rowptr, perm, long_rows, chunk_ptr, row_order;
+  Tensor rowptr, perm, long_rows, chunk_ptr;
+  // the row hand-out order is a scheduling aid worth ~100 us of sorting: computed when the plan is launched a SECOND
+  // time, so a plan used once (a fresh edge list per mini-batch) never pays for it (ops.py SegPlan.c_struct)
+  mutable Tensor row_order;
+  mutable std::mutex order_mu;
+  mutable int uses = 0;
 
   // `unsplit`: every row walked in one piece; `skip_long`: rows longer than chunk left to ggl_segment_hub16
   ggl_segplan_t c(const Tensor &partial, bool unsplit = false, bool skip_long = false) const {
@@ -172,6 +179,10 @@ struct SegPlan {
     s.partial = partial.defined() ? partial.data_ptr() : nullptr;
     s.N = N;
     s.E = E;
+    if (N > 1) {
+      std::lock_guard<std::mutex> g(order_mu);
+      if (!row_order.defined() && ++uses >= 2) row_order = row_order_of(counts());
+    }
     s.row_order = row_order.defined() ? row_order.data_ptr<int32_t>() : nullptr;
     s.xcd_run_rows = xcd_run;
     return s;
@@ -230,7 +241,6 @@ static std::shared_ptr<SegPlan> build_plan(const Tensor &ids_in, int64_t N) {
   p->max_len = max_len;
   if (!p->sorted) p->perm = perm.slice(0, 0, p->E);
   fill_long_rows(a, *p, st);
-  if (N > 1) p->row_order = row_order_of(p->counts());
   p->uid = ++g_plans_built;
   return p;
 }
@@ -376,8 +386,8 @@ static Cache<GraphPlan> &graph_cache() {
 static void check_range(const Tensor &ids, int64_t n) {   // one host read per plan
   if (ids.numel() == 0) return;
   auto mm = at::aminmax(ids);
-  TORCH_CHECK_INDEX(std::get<0>(mm).item<int64_t>() >= 0 && std::get<1>(mm).item<int64_t>() < n,
-                    "node id out of range [0, ", n, ")");
+  Tensor both = at::stack({std::get<0>(mm), std::get<1>(mm)}).cpu();   // one host read
+  TORCH_CHECK_INDEX(both[0].item<int64_t>() >= 0 && both[1].item<int64_t>() < n, "node id out of range [0, ", n, ")");
 }
 
 static std::shared_ptr<GraphPlan> graph_plan(const Tensor &index, int64_t n_dst, int64_t n_src) {

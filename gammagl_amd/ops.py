@@ -45,7 +45,7 @@ class SegPlan:
     """Destination-sorted view of one id vector (struct ggl_segplan + the tensors that own it)."""
 
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
-                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run")
+                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run", "order_fn", "uses")
 
     def c_struct(self, partial=None, perm_override=None, unsplit=False, skip_long=False):
         """`unsplit`: present the plan without its long-row table, every row walked in one piece.
@@ -53,6 +53,14 @@ class SegPlan:
         of the launch (ggl_segment_hub16 fills them in)."""
         perm = self.perm if perm_override is None else perm_override
         n_long = 0 if (unsplit or skip_long) else self.n_long
+        fn = getattr(self, "order_fn", None)
+        if fn is not None:
+            # the row hand-out order is a scheduling aid worth ~100 us of sorting: a plan that is used ONCE (a fresh
+            # edge list per mini-batch) never pays for it, a plan that comes back gets it on its second launch
+            self.uses = getattr(self, "uses", 0) + 1
+            if self.uses >= 2:
+                self.order_fn = None
+                self.row_order = fn(self.counts())
         return SegPlanC(
             rowptr=self.rowptr.data_ptr(), perm=(perm.data_ptr() if perm is not None else None),
             long_rows=(self.long_rows.data_ptr() if n_long else None),
@@ -218,6 +226,10 @@ class _PlanCache:
     @staticmethod
     def _nbytes(val):
         """HBM held by a cached value (SegPlan / GraphPlan / tensor), for the byte bound."""
+        if isinstance(val, SegPlan):   # the common miss (a fresh id tensor per mini-batch): no generic walk
+            own = sum(t.untyped_storage().nbytes() for t in (val.rowptr, val.perm, val.long_rows, val.chunk_ptr)
+                      if t is not None)
+            return own + 4 * val.N        # (+ the row order it gets if it is launched again)
         seen, total = set(), 0
 
         def visit(o, depth=0):
@@ -353,9 +365,9 @@ class Engine:
     def _check_range(self, ids, n):
         if ids.numel() == 0:
             return
-        # one-off (per plan) validation of the gathered side of an edge list
-        lo, hi = torch.aminmax(ids)
-        if int(lo) < 0 or int(hi) >= n:
+        # one-off (per plan) validation of the gathered side of an edge list (one host read)
+        lo, hi = torch.stack(torch.aminmax(ids)).tolist()
+        if lo < 0 or hi >= n:
             raise IndexError(f"node id out of range [0, {n})")
 
     @staticmethod
@@ -405,8 +417,9 @@ class Engine:
             self._check(self.lib.ggl_plan_long_fill(_ptr(p.rowptr), N, chunk, p.n_long,
                                                     _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws),
                                                     lwb, st))
-        # scheduling aid: rows by descending length inside id windows, see _row_order / ggl_segplan.row_order
-        p.row_order = self._row_order(p.counts()) if N > 1 else None
+        # scheduling aid: rows by descending length inside id windows, see _row_order / ggl_segplan.row_order —
+        # computed when the plan is launched a second time (SegPlan.c_struct)
+        p.row_order, p.uses, p.order_fn = None, 0, (self._row_order if N > 1 else None)
         self.stats["plans_built"] += 1
         p.uid = self.stats["plans_built"]
         return p
@@ -452,7 +465,7 @@ class Engine:
             p.chunk_ptr = torch.empty(p.n_long + 1, dtype=torch.int64, device=dev)
             self._check(self.lib.ggl_plan_long_fill(_ptr(p.rowptr), p.N, p.chunk, p.n_long,
                                                     _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws), lwb, st))
-        p.row_order = self._row_order(p.counts()) if p.N > 1 else None
+        p.row_order, p.uses, p.order_fn = None, 0, (self._row_order if p.N > 1 else None)
         self.stats["plans_built"] += 1
         p.uid = self.stats["plans_built"]
         return p
