@@ -188,6 +188,23 @@ def test_traces_under_torch_compile_forward_and_backward(cpp):
         assert torch.equal(got, want) and torch.equal(xc.grad, xe.grad) and torch.equal(xbc.grad, xbe.grad), backend
 
 
+def test_called_from_a_cpp_program_without_python(cpp, tmp_path):
+    """tests/cpp/ops_from_cpp.cpp: a C++ executable (no interpreter in the process) dlopens libggl_torch.so, finds the
+    operators in the dispatcher and checks values, gradients and the arg-max against plain ATen."""
+    import torch.utils.cpp_extension as ce
+
+    from gammagl_amd import cpp_ops
+
+    tdir = os.path.dirname(torch.__file__)
+    exe = str(tmp_path / "ops_from_cpp")
+    inc = [f"-I{p}" for p in ce.include_paths()]
+    subprocess.check_call(["g++", "-O1", "-std=c++17", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+                           *inc, os.path.join(HERE, "cpp", "ops_from_cpp.cpp"), "-o", exe, f"-L{tdir}/lib", "-ltorch",
+                           "-ltorch_cpu", "-lc10", "-ldl", f"-Wl,-rpath,{tdir}/lib"])
+    r = subprocess.run([exe, cpp_ops.LIB_PATH], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.stdout, r.stderr[-2000:])
+
+
 def test_error_types_match_the_reference(cpp):
     ops = cpp.ops
     x = torch.ones(3, 2)
