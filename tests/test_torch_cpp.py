@@ -104,6 +104,58 @@ def test_bit_identical_to_the_python_registered_ops(cpp):
         assert torch.equal(a, b) and torch.equal(x1.grad, x2.grad) and torch.equal(w1.grad, w2.grad), (H, Cc)
 
 
+def test_fuzz_against_the_python_registered_ops(cpp):
+    """hypothesis: random sizes (empty inputs, one row, hubs longer than the long-row threshold of a small plan, sorted
+    ids), widths, dtypes, weights present or not — the C++ route and the Python route give the same bits, forward and
+    backward (the plan's long-row threshold depends on E, so both sides chunk the same rows)."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    from gammagl_amd import torch_ops
+
+    P, C = torch_ops.ops, cpp.ops
+
+    @st.composite
+    def problems(draw):
+        N = draw(st.integers(1, 60))
+        E = draw(st.integers(0, 1500))
+        K = draw(st.sampled_from([1, 2, 3, 4, 7, 8, 12, 47, 64, 65, 260]))
+        kind = draw(st.sampled_from(["uniform", "sorted", "hub", "single"]))
+        return N, E, K, kind, draw(st.integers(0, 2**31 - 1))
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(problems(), st.sampled_from([torch.float32, torch.float64, torch.int32, torch.float16, torch.bfloat16]),
+           st.booleans())
+    def run(prob, dt, weighted):
+        N, E, K, kind, seed = prob
+        g = torch.Generator().manual_seed(seed)
+        ids = torch.randint(0, N, (E,), generator=g)
+        if kind == "single" and E:
+            ids[:] = ids[0]
+        if kind == "hub" and E > 4:
+            ids[: E // 2 + 300 if E > 700 else E // 2] = ids[0]
+        if kind == "sorted":
+            ids = ids.sort().values
+        x = (torch.randn(E, K, generator=g) * 3).to(dt)
+        for name in ("segment_sum", "segment_mean"):
+            assert torch.equal(getattr(P, name)(x, ids, N), getattr(C, name)(x, ids, N)), (name, prob, dt)
+        a, b = P.segment_max(x, ids, N), C.segment_max(x, ids, N)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (prob, dt)
+        src = torch.randint(0, N, (E,), generator=g)
+        ei = torch.stack([src, ids])
+        w = torch.rand(E, generator=g) if weighted else None
+        xn = torch.randn(N, K, generator=g)
+        for name in ("spmm_sum", "spmm_mean", "spmm_max"):
+            x1, x2 = _pair(xn)
+            ya, yb = getattr(P, name)(ei, w, x1), getattr(C, name)(ei, w, x2)
+            go = torch.randn(ya.shape, generator=g)
+            ya.backward(go)
+            yb.backward(go)
+            assert torch.equal(ya, yb) and torch.equal(x1.grad, x2.grad), (name, prob, weighted)
+
+    run()
+
+
 def test_dispatcher_contracts(cpp):
     ops = cpp.ops
     g = torch.Generator().manual_seed(3)
