@@ -413,9 +413,10 @@ def main():
         # library GEMM selection only: the same IEEE f32 products, each shape on the rocBLAS / hipBLASLt kernel an offline
         # TunableOp pass measured fastest on this part (the file's validators — torch / HIP / library versions, gfx
         # arch — must match, otherwise torch ignores it and the default heuristics pick)
-        ds = (WORKLOADS[args.workload]["dataset"] or "tiny") if kind == "gcn" else args.workload.replace("-", "_")
-        path = os.path.join(REPO, "gammagl_amd", "tuned", f"tunableop_gfx950_{ds}.csv")
-        if os.path.exists(path):
+        names = [args.workload.replace("-", "_")] + ([WORKLOADS[args.workload]["dataset"] or "tiny"] if kind == "gcn" else [])
+        paths = [os.path.join(REPO, "gammagl_amd", "tuned", f"tunableop_gfx950_{n}.csv") for n in names]
+        path = next((p for p in paths if os.path.exists(p)), None)   # the workload's own file, else its dataset's
+        if path is not None:
             try:
                 import torch.cuda.tunable as tun
 
