@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void hop_reset_kernel(const int64_t *__rest
                                                            const int64_t *__restrict__ n_seeds, int64_t B_cap,
                                                            const int64_t *__restrict__ nbr,
                                                            const int64_t *__restrict__ out_rowptr, int64_t N,
-                                                           long long *__restrict__ first_pos) {
+                                                           long long *__restrict__ first_pos, int64_t *__restrict__ rng) {
   const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
   const int64_t ne = out_rowptr[B_cap];
   const int64_t stride = grid_threads();
@@ -310,6 +310,9 @@ __global__ __launch_bounds__(kBlock) void hop_reset_kernel(const int64_t *__rest
     const int64_t node = t < nb ? seeds[t] : nbr[t - nb];
     if (node >= 0 && node < N) first_pos[node] = kBigPos;
   }
+  // the hop's draws are done (hop_pick ran earlier on this stream): the next hop gets a fresh offset — was a launch
+  // of its own (sample_rng_advance_kernel)
+  if (rng != nullptr && thread_id() == 0) rng[1] += 1;
 }
 
 // thread per row: columns ascending by local id (sample.cpp:112-118), e_pos carried along; rows hold <= fanout
@@ -630,7 +633,7 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
              (const int64_t *)new_id, S_cap, out_nid, local, out_counts);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_reset_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
-             (const int64_t *)out_rowptr, num_nodes, fp);
+             (const int64_t *)out_rowptr, num_nodes, fp, rng_state);
   GGL_LAUNCH_CHECK();
   if (in_regs)
     GGL_LAUNCH((hop_rowsort_reg_kernel), grid_for(B_cap), kBlock, s, (const int64_t *)out_rowptr, B_cap, E_cap,
@@ -638,8 +641,6 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   else
     GGL_LAUNCH((hop_rowsort_kernel), grid_for(B_cap), kBlock, s, (const int64_t *)out_rowptr, B_cap, E_cap, local, e_pos,
                out_col, out_eid);
-  GGL_LAUNCH_CHECK();
-  GGL_LAUNCH((sample_rng_advance_kernel), 1, 64, s, rng_state);
   GGL_LAUNCH_CHECK();
   return GGL_OK;
 }

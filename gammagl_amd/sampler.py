@@ -224,6 +224,7 @@ class BlockSampler:
         self.value = (torch.arange(ei.shape[1], device=ei.device) if plan.perm is None else plan.perm.long())
         self._first_pos = torch.full((self.num_nodes,), _BIG, dtype=torch.int64, device=ei.device)
         self._overflow = torch.zeros((), dtype=torch.int64, device=ei.device)
+        self._n_full = {}
 
     def capacities(self, batch_size):
         """Worst-case [(n_src_cap, e_cap)] per hop, innermost (the seeds' own block) first."""
@@ -268,8 +269,11 @@ class BlockSampler:
         eng = self.eng
         dev = self.rowptr.device
         seeds = seeds.to(device=dev, dtype=torch.int64).contiguous().reshape(-1)
-        if n_seeds is None:
-            n_seeds = torch.full((1,), seeds.shape[0], dtype=torch.int64, device=dev)
+        if n_seeds is None:   # "every seed is valid": one constant per batch size, made once (a fill per call otherwise)
+            key = (int(seeds.shape[0]), str(dev))
+            n_seeds = self._n_full.get(key)
+            if n_seeds is None:
+                n_seeds = self._n_full[key] = torch.full((1,), seeds.shape[0], dtype=torch.int64, device=dev)
         st = eng._stream(dev)
         blocks = []
         cur, n_cur = seeds, n_seeds
@@ -281,7 +285,7 @@ class BlockSampler:
             col = torch.empty(e_cap, dtype=torch.int32, device=dev)
             e_pos = torch.empty(e_cap, dtype=torch.int64, device=dev)
             nid = torch.empty(s_cap, dtype=torch.int64, device=dev)
-            counts = torch.zeros(3, dtype=torch.int64, device=dev)
+            counts = torch.empty(3, dtype=torch.int64, device=dev)   # (all three are assigned by the hop's kernels)
             wsb = eng.lib.ggl_sample_hop_workspace_bytes(b_cap, e_cap)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             eng._check(eng.lib.ggl_sample_hop(_ptr(self.rowptr), _ptr(self.col), _ptr(cur), _ptr(n_cur), b_cap,
