@@ -28,7 +28,7 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_p
     ``first_pos``: optional int64 scratch of one entry per graph node, filled with ``_BIG`` (NeighborSampler
     keeps one): the relabelling then runs on it without sorting (first occurrence of every node by a
     scatter-min, ids by a prefix sum over the first occurrences) and hands it back reset."""
-    eng = eng or _engine()
+    eng = eng or _engine(rowptr)   # (CPU tensors: the host build, as the reference's c_sample_adj serves them)
     dev = eng._dev(rowptr, col, idx)
     rowptr = rowptr.contiguous().to(torch.int64)
     col = col.contiguous().to(torch.int64)

@@ -17,7 +17,7 @@ from .ops import _ptr
 
 def ind2ptr(ind, M, eng=None):
     """ptr[M+1] with ptr[r+1]-ptr[r] = number of entries of ``ind`` equal to r (int64)."""
-    eng = eng or _engine()
+    eng = eng or _engine(ind)      # (CPU tensors: the host build, as the reference's c_ind2ptr serves them)
     dev = eng._dev(ind)
     ind = ind.contiguous().to(torch.int64)
     E, M = int(ind.shape[0]), int(M)
@@ -30,7 +30,7 @@ def ind2ptr(ind, M, eng=None):
 
 def ptr2ind(ptr, E=None, eng=None):
     """ind[p] = r for ptr[r] <= p < ptr[r+1] (int64 [E]; E defaults to ptr[-1])."""
-    eng = eng or _engine()
+    eng = eng or _engine(ptr)
     dev = eng._dev(ptr)
     ptr = ptr.contiguous().to(torch.int64)
     M = int(ptr.shape[0]) - 1
@@ -43,7 +43,7 @@ def ptr2ind(ptr, E=None, eng=None):
 
 def sort_edge_index(edge_index, edge_attr=None, num_nodes=None, sort_by_row=True, eng=None):
     """Row-wise (or column-wise) lexicographic sort of ``edge_index`` and its attributes."""
-    eng = eng or _engine()
+    eng = eng or _engine(edge_index)
     dev = eng._dev(edge_index)
     ei = edge_index.contiguous().to(torch.int64)
     E = int(ei.shape[1])

@@ -13,6 +13,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -117,3 +118,41 @@ def test_gcn_trainer_example_runs_on_the_cpu():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if "loss" in ln.lower()]
     assert len(lines) >= 2, r.stdout[-1000:]
+
+
+def test_zero_edit_binding_of_the_sparse_ops(tmp_path, golden):
+    """`gammagl/ops/sparse/sparse.py:26-29` binds its GPU module in one import statement: a stand-in package holding
+    exactly that statement binds `gammagl_amd/compat/_sparse_cuda.py` dropped at `ops/sparse/_sparse_cuda.py`; the
+    conversions reproduce the reference's compiled c_ind2ptr / c_ptr2ind (golden/convert.npz), sample_adj the branches of
+    c_sample_adj that draw nothing (golden/sampler.npz)."""
+    root = tmp_path / "ggl_standin2"
+    (root / "ops" / "sparse").mkdir(parents=True)
+    for d in (root, root / "ops", root / "ops" / "sparse"):
+        (d / "__init__.py").write_text("")
+    (root / "ops" / "sparse" / "sparse.py").write_text(
+        "from ._sparse_cuda import (cuda_torch_ind2ptr, cuda_torch_ptr2ind, cuda_torch_neighbor_sample, cuda_torch_sample_adj)\n")
+    shutil.copy(os.path.join(REPO, "gammagl_amd", "compat", "_sparse_cuda.py"), root / "ops" / "sparse" / "_sparse_cuda.py")
+    sys.path.insert(0, str(tmp_path))
+    try:
+        m = importlib.import_module("ggl_standin2.ops.sparse.sparse")
+    finally:
+        sys.path.pop(0)
+    g = golden["convert"]
+    for i in range(int(g["ncases"])):
+        ind, M = torch.from_numpy(g[f"v{i}_ind"].copy()), int(g[f"v{i}_M"])
+        ptr = m.cuda_torch_ind2ptr(ind, M)
+        np.testing.assert_array_equal(ptr.numpy(), g[f"v{i}_ptr"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(m.cuda_torch_ptr2ind(ptr, ind.shape[0]).numpy(), np.sort(g[f"v{i}_ind"]), err_msg=f"case {i}")
+    # one hop, against the blocks the reference's compiled c_sample_adj produced (the branches that draw nothing)
+    import parity_cases as pc
+
+    gs = golden["sampler"]
+    for ci in range(int(gs["ncases"])):
+        k = f"c{ci}"
+        rowptr, col, seeds = (torch.from_numpy(gs[k + n].copy()) for n in ("_rowptr", "_col", "_seeds"))
+        out = m.cuda_torch_sample_adj(rowptr, col, seeds, torch.tensor([int(gs[k + "_fanout"])]), False, False, 0)
+        assert isinstance(out, list) and len(out) == 4
+        pc.compare_block_with_reference([t.numpy() for t in out], gs, k, f"sampler case {ci}")
+    rowptr, col = torch.tensor([0, 2, 3, 6, 6]), torch.tensor([1, 2, 0, 0, 1, 3])
+    with pytest.raises(NotImplementedError):
+        m.cuda_torch_neighbor_sample(rowptr, col, torch.tensor([0]), torch.tensor([2, 2]), False, False, 0)
