@@ -173,9 +173,13 @@ static int64_t dot_block_width(int64_t E, int64_t N, int64_t C) {   // C = one l
   (void)E; (void)N;
   return C;
 #else
-  if (options().col_block > 0 && C % 4 == 0 && C >= 2 * options().col_block && N > 0 &&
+  // the block width is an A/B knob (ggl_set_option "col_block"): the slab loads are float4 and the tail template covers
+  // (width % 32) / 4 quads, so a width that is not a multiple of 4 would drop columns from the dot — such a setting
+  // runs as ONE launch here instead
+  const int64_t bw = options().col_block;
+  if (bw > 0 && bw % 4 == 0 && C % 4 == 0 && C >= 2 * bw && N > 0 &&
       E >= options().col_block_min_degree * N && E >= options().col_block_min_edges)
-    return options().col_block;
+    return bw;
   return C;
 #endif
 }

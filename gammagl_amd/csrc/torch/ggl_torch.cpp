@@ -25,6 +25,7 @@
 #include <ATen/ATen.h>
 #include <ATen/core/dispatch/Dispatcher.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <c10/hip/HIPStream.h>
 #include <dlfcn.h>
 #include <torch/csrc/autograd/custom_function.h>
@@ -154,6 +155,12 @@ static int64_t auto_chunk(int64_t E) {   // the largest power of two <= E / resi
 
 static Tensor row_order_of(const Tensor &counts);
 
+static bool capturing(const c10::Device &d) {
+  if (!d.is_cuda()) return false;
+  c10::OptionalDeviceGuard guard(d);
+  return c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
+}
+
 struct SegPlan {
   int64_t N = 0, E = 0, chunk = 0, n_long = 0, n_chunks = 0, max_len = 0, xcd_run = 0;
   bool sorted = false;
@@ -181,7 +188,8 @@ struct SegPlan {
     s.E = E;
     if (N > 1) {
       std::lock_guard<std::mutex> g(order_mu);
-      if (!row_order.defined() && ++uses >= 2) row_order = row_order_of(counts());
+      // (not while a hipGraph is being recorded: the sort would be allocated in the capture pool and filled on replay only)
+      if (!row_order.defined() && ++uses >= 2 && !capturing(rowptr.device())) row_order = row_order_of(counts());
     }
     s.row_order = row_order.defined() ? row_order.data_ptr<int32_t>() : nullptr;
     s.xcd_run_rows = xcd_run;
@@ -559,6 +567,8 @@ static void f32(const char *name, const Tensor &t) {
 }
 
 static Tensor opt(const c10::optional<Tensor> &t) { return t.has_value() ? *t : Tensor(); }
+// the kernels read weight.data_ptr() as E dense floats (spmm_sum_cpu.cpp:48-50 makes it contiguous in backward too)
+static Tensor opt_dense(const c10::optional<Tensor> &t) { return t.has_value() && t->defined() ? t->contiguous() : Tensor(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backend kernels (forward only; these are what the CUDA / CPU keys run, e.g. under no_grad)
@@ -689,20 +699,20 @@ static std::shared_ptr<GraphPlan> bwd_plan(const Tensor &index, int64_t n) {
 }
 // gx[src] += w[e] * g[dst]: the same walk on the transposed plan          (spmm_sum_cpu.cpp:43-80)
 static Tensor spmm_sum_backward_kernel(const Tensor &index, const c10::optional<Tensor> &weight, const Tensor &grad) {
-  Tensor g = grad.contiguous(), w = opt(weight);
+  Tensor g = grad.contiguous(), w = opt_dense(weight);
   c10::OptionalDeviceGuard guard(g.device());
   auto gp = bwd_plan(index, g.size(0));
   return spmm_fwd(SpOp::Sum, *gp, *gp->bwd, gp->colT, w, g, gp->N_src).first;
 }
 static Tensor spmm_mean_backward_kernel(const Tensor &index, const c10::optional<Tensor> &weight, const Tensor &grad) {
-  Tensor g = grad.contiguous(), w = opt(weight);
+  Tensor g = grad.contiguous(), w = opt_dense(weight);
   c10::OptionalDeviceGuard guard(g.device());
   auto gp = bwd_plan(index, g.size(0));
   return spmm_fwd(SpOp::MeanBwd, *gp, *gp->bwd, gp->colT, w, g, gp->N_src, gp->fwd->rowptr).first;
 }
 static Tensor spmm_max_backward_kernel(const Tensor &index, const c10::optional<Tensor> &weight, const Tensor &grad,
                                        const Tensor &arg) {
-  Tensor g = grad.contiguous(), w = opt(weight);
+  Tensor g = grad.contiguous(), w = opt_dense(weight);
   c10::OptionalDeviceGuard guard(g.device());
   auto gp = bwd_plan(index, g.size(0));
   return spmm_fwd(SpOp::MaxBwd, *gp, *gp->bwd, gp->colT, w, g, gp->N_src, arg.contiguous()).first;

@@ -45,7 +45,7 @@ class SegPlan:
     """Destination-sorted view of one id vector (struct ggl_segplan + the tensors that own it)."""
 
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
-                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run", "order_fn", "uses")
+                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run", "order_fn", "uses", "wperm")
 
     def c_struct(self, partial=None, perm_override=None, unsplit=False, skip_long=False):
         """`unsplit`: present the plan without its long-row table, every row walked in one piece.
@@ -58,7 +58,9 @@ class SegPlan:
             # the row hand-out order is a scheduling aid worth ~100 us of sorting: a plan that is used ONCE (a fresh
             # edge list per mini-batch) never pays for it, a plan that comes back gets it on its second launch
             self.uses = getattr(self, "uses", 0) + 1
-            if self.uses >= 2:
+            # never while a hipGraph is being recorded: the argsort would be allocated in the capture pool and only
+            # FILLED on replay, and an eager launch of this plan before the first replay would read garbage row ids
+            if self.uses >= 2 and not (self.rowptr.is_cuda and torch.cuda.is_current_stream_capturing()):
                 self.order_fn = None
                 self.row_order = fn(self.counts())
         return SegPlanC(
@@ -122,6 +124,9 @@ class GraphPlan:
         gp._bwd = engine.plan_from_rowptr(col_ptr.clone() if col_ptr.dtype == torch.int64 else col_ptr, gp.E)
         gp._colT = own_i32(row_ind)
         gp._posT = own_i32(permute)
+        # edge weights arrive in CSR order: the transposed walk reads them through `permute` (a COO-built plan's CSC side
+        # carries the original edge id of every position in its own `perm` instead)
+        gp._bwd.wperm = gp._posT
         gp._rowidx = None
         gp.aux = {}
         gp._schedule()
@@ -597,10 +602,8 @@ class Engine:
         if out.shape[1] != K or out.shape[0] != plan.N:
             raise RuntimeError("out must be [plan rows, x columns]")
         part = self._partial(plan, torch.float32, K, False, dev)
-        cs = plan.c_struct(part)
-        w_by_pos = 0
-        if w is not None and plan.perm is not None:
-            w, w_by_pos = self._sorted_weights(plan, w)
+        w, w_by_pos, wp = self._weights(plan, w)
+        cs = plan.c_struct(part, wp)
         self._check(self.lib.ggl_spmm_sum_ex(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
                                              self._row_stride(x, "x"), K, _ptr(out), self._row_stride(out, "out"),
                                              int(bool(accumulate)), self._stream(dev)))
@@ -626,10 +629,8 @@ class Engine:
         if out.shape[1] != K or out.shape[0] != plan.N:
             raise RuntimeError("out must be [plan rows, x columns]")
         part = self._partial(plan, torch.float32, K, False, dev)
-        cs = plan.c_struct(part)
-        w_by_pos = 0
-        if w is not None and plan.perm is not None:
-            w, w_by_pos = self._sorted_weights(plan, w)
+        w, w_by_pos, wp = self._weights(plan, w)
+        cs = plan.c_struct(part, wp)
         b = None
         if bias is not None:
             b = ctypes.c_void_p(bias.data_ptr() + 4 * int(col0))
@@ -676,10 +677,8 @@ class Engine:
         out = torch.empty((n_out,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
         st = self._stream(dev)
         part = self._partial(plan, torch.float32, K, op == "max", dev)
-        cs = plan.c_struct(part, perm_override)
-        w_by_pos = 0
-        if w is not None and perm_override is None and plan.perm is not None:
-            w, w_by_pos = self._sorted_weights(plan, w)
+        w, w_by_pos, wp = self._weights(plan, w, perm_override)
+        cs = plan.c_struct(part, wp)
         L = self.lib
         if op == "sum":
             self._check(L.ggl_spmm_sum(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), K,
@@ -712,7 +711,19 @@ class Engine:
             raise ValueError(op)
         return out, None
 
-    def _sorted_weights(self, plan, w):
+    def _weights(self, plan, w, perm_override=None):
+        """(weights, w_by_pos, perm for the launch struct) of one walk over `plan`: weights that came back a second time
+        are streamed in sorted order (`_sorted_weights`); otherwise the kernel reads w[perm[p]] — through the plan's own
+        permutation, or, on the CSC side of a CSR-built plan, through `wperm` (GraphPlan.from_csr)."""
+        if perm_override is not None or w is None:
+            return w, 0, perm_override
+        wp = plan.perm if plan.perm is not None else getattr(plan, "wperm", None)
+        if wp is None:
+            return w, 0, None
+        w, by_pos = self._sorted_weights(plan, w, wp)
+        return w, by_pos, (wp if plan.perm is None else None)
+
+    def _sorted_weights(self, plan, w, perm=None):
         """Edge weights in the plan's sorted order, for weights that are REUSED.
 
         The kernels can read w[perm[p]] themselves (one random 4-byte read per edge).  A weight tensor
@@ -728,7 +739,7 @@ class Engine:
             E = int(plan.E)
             H = w.numel() // E if E > 0 else 1
             ws = torch.empty_like(w)
-            self._check(self.lib.ggl_gather_rows_f32(_ptr(w), _ptr(plan.perm), E, max(H, 1), _ptr(ws),
+            self._check(self.lib.ggl_gather_rows_f32(_ptr(w), _ptr(plan.perm if perm is None else perm), E, max(H, 1), _ptr(ws),
                                                      self._stream(w.device)))
             self.w_cache.put(w, key_extra, ws)
             hit = ws
@@ -739,10 +750,8 @@ class Engine:
         H, C = int(x.shape[1]), int(x.shape[2])
         out = torch.empty((n_out, H, C), dtype=torch.float32, device=dev)
         part = self._partial(plan, torch.float32, H * C, False, dev)
-        cs = plan.c_struct(part, perm_override)
-        w_by_pos = 0
-        if perm_override is None and plan.perm is not None:
-            w, w_by_pos = self._sorted_weights(plan, w)
+        w, w_by_pos, wp = self._weights(plan, w, perm_override)
+        cs = plan.c_struct(part, wp)
         self._check(self.lib.ggl_bspmm_sum(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), H, C,
                                            _ptr(out), self._stream(dev)))
         return out
@@ -880,7 +889,9 @@ class Engine:
                 gx = eng._bspmm_fwd(gp.bwd, gp.colT, w, g, gp.N_src)
                 H, C = int(x.shape[1]), int(x.shape[2])
                 gw = torch.empty_like(w)
-                if eng.gradw_sorted and C % 4 == 0 and C > eng.gradw_sorted_min_c:
+                # a plan built from the caller's CSR has no COO edge list to walk (gp.index is None): it always takes the
+                # sorted route, whose plain kernel covers any channel count
+                if gp.index is None or (eng.gradw_sorted and C % 4 == 0 and C > eng.gradw_sorted_min_c):
                     # along the destination-sorted forward plan, strips staged through LDS (edgedot.hip): the g rows
                     # of a batch are a handful of rows, only x[src] is a random gather — and a coalesced one
                     sb = eng.lib.ggl_bspmm_grad_w_sorted_scratch_bytes(gp.E, gp.N_dst, H, C)
@@ -890,8 +901,6 @@ class Engine:
                                                                _ptr(g), H, C, _ptr(gw), _ptr(scratch),
                                                                eng._stream(g.device)))
                 else:
-                    if gp.index is None:
-                        raise RuntimeError("bspmm backward on a CSR-built plan needs channel counts that are multiples of 4")
                     eng._check(eng.lib.ggl_bspmm_grad_w(_ptr(gp.index), _ptr(x), _ptr(g), gp.E, H, C,
                                                         _ptr(gw), eng._stream(g.device)))
                 # the reference returns grad_weight although it marked weight non-differentiable
@@ -1033,10 +1042,8 @@ class Engine:
                 plan = gp.fwd
                 y = torch.empty((gp.N_dst, K), dtype=torch.float32, device=dev)
                 part = eng._partial(plan, torch.float32, K, False, dev)
-                cs = plan.c_struct(part)
-                ww, w_by_pos = w, 0
-                if w is not None and plan.perm is not None:
-                    ww, w_by_pos = eng._sorted_weights(plan, w)
+                ww, w_by_pos, wp = eng._weights(plan, w)
+                cs = plan.c_struct(part, wp)
                 rng = eng._rng_state(dev) if p_drop > 0 else None
                 ctx.rng_used = rng.clone() if rng is not None else None
                 b = bias.contiguous().reshape(-1) if bias is not None else None

@@ -28,18 +28,22 @@ def arrange_communities(q, device=None):
     q = q + q.t()
     q.fill_diagonal_(0.0)
     live = torch.nonzero(q.sum(1) > 0).reshape(-1).tolist()
-    dead = [c for c in range(C) if c not in set(live)]
+    live_set = set(live)
+    dead = [c for c in range(C) if c not in live_set]
 
-    def order(nodes):
+    def split(nodes):
+        """One bisection step: ('leaf', nodes) when the group is final, else ('split', left, right) — both sides still to
+        be ordered, left before right.  ('tail', keep, lone): `lone` (no link into the group) goes after `keep`."""
         if len(nodes) <= 2:
-            return nodes
+            return ("leaf", nodes)
         idx = torch.tensor(nodes, device=q.device)
         sub = q[idx][:, idx]
         d = sub.sum(1)
         lone = [nodes[i] for i in torch.nonzero(d <= 0).reshape(-1).tolist()]
         if lone:   # communities with no link into this group: to the end, the rest is ordered on its own
-            keep = [n for n in nodes if n not in set(lone)]
-            return order(keep) + lone if len(keep) < len(nodes) and keep else nodes
+            lone_set = set(lone)
+            keep = [n for n in nodes if n not in lone_set]
+            return ("tail", keep, lone) if keep else ("leaf", nodes)
         dis = d.pow(-0.5)
         lap = torch.eye(len(nodes), dtype=torch.float64, device=q.device) - dis.unsqueeze(1) * sub * dis.unsqueeze(0)
         _, vec = torch.linalg.eigh(lap)
@@ -56,8 +60,27 @@ def arrange_communities(q, device=None):
         denom = torch.minimum(csum_vol, csum_vol[-1] - csum_vol).clamp(min=1e-12)
         score = (cut / denom)[:-1]
         k = int(torch.argmin(score)) + 1
-        left, right = [nodes[i] for i in o[:k].tolist()], [nodes[i] for i in o[k:].tolist()]
-        return order(left) + order(right)
+        return ("split", [nodes[i] for i in o[:k].tolist()], [nodes[i] for i in o[k:].tolist()])
+
+    def order(nodes):
+        # an explicit stack instead of recursion: a run of unbalanced cuts (k = 1 on star / chain quotient graphs of up to
+        # 8192 communities) is as deep as it is long, far past Python's frame limit
+        out, stack = [], [("todo", nodes)]
+        while stack:
+            tag, grp = stack.pop()
+            if tag == "done":
+                out.extend(grp)
+                continue
+            r = split(grp)
+            if r[0] == "leaf":
+                out.extend(r[1])
+            elif r[0] == "tail":
+                stack.append(("done", r[2]))
+                stack.append(("todo", r[1]))
+            else:
+                stack.append(("todo", r[2]))
+                stack.append(("todo", r[1]))
+        return out
 
     seq = order(live) + dead
     pos = torch.empty(C, dtype=torch.int64)

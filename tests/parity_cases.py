@@ -1099,6 +1099,36 @@ def check_bspmm_gradw_sorted(eng, dev, oracle):
     gp = eng.graph_plan(ei, N)
     gp2 = eng.graph_plan_from_csr(gp.fwd.rowptr.clone(), gp.col.clone(), gp.bwd.rowptr.clone(), gp.colT.clone(), gp.posT.clone())
     assert torch.equal(gp2.rowidx.long(), ei[1])
+    # ... and its weight gradient takes the sorted route for ANY channel count (there is no COO list to walk): narrow
+    # and odd heads included, with the switch for the sorted walk off as well (round 3 raised here)
+    for C2, sorted_walk in ((8, True), (16, True), (5, True), (8, False), (24, False)):
+        eng.gradw_sorted = sorted_walk
+        try:
+            xs = torch.randn(N, H, C2, generator=g).to(dev)
+            ws = torch.rand(90, H, generator=g).to(dev)
+            gos = torch.randn(N, H, C2, generator=g).to(dev)
+            res = []
+            for plan in (gp, gp2):
+                wt, xt = ws.clone().requires_grad_(True), xs.clone().requires_grad_(True)
+                eng.BSpMMSum.apply(plan, wt, xt).backward(gos)
+                res.append((wt.grad, xt.grad))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (C2, sorted_walk)
+        finally:
+            eng.gradw_sorted = True
+    # weighted gspmm over the CSR-built plan: the transposed walk reads the (CSR-ordered) weights through `permute`
+    # — twice, so the second call streams the copy sorted into CSC order
+    for reduce in ("sum", "mean", "max"):
+        xs = torch.randn(N, 6, generator=g).to(dev)
+        ws = torch.rand(90, generator=g).to(dev)
+        gos = torch.randn(N, 6, generator=g).to(dev)
+        for _ in range(2):
+            res = []
+            for plan in (gp, gp2):
+                xt = xs.clone().requires_grad_(True)
+                y = eng.spmm(plan, ws, xt, reduce)
+                y.backward(gos)
+                res.append((y.detach(), xt.grad))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), reduce
 
 
 def check_plan_cache(eng, dev):

@@ -84,3 +84,24 @@ def test_arrange_communities_orders_a_hierarchy():
     half = lambda xs: {int(pos[i]) // 4 for i in xs}                         # noqa: E731
     assert len(half((0, 5, 1, 4))) == 1 and len(half((2, 7, 3, 6))) == 1     # the two super-groups are contiguous halves
     assert torch.equal(pos, arrange_communities(q))                          # deterministic
+
+
+def test_arrange_communities_is_not_recursive():
+    """A star quotient graph peels one community per bisection (k = 1 every time): the arrangement is as deep as it is
+    long.  With the frame limit lowered to well below the community count the explicit-stack walk still finishes and
+    returns a permutation (round 3 recursed once per level and died past ~1000 communities)."""
+    import inspect
+    import sys
+
+    from gammagl_amd.partition import arrange_communities
+
+    C = 300
+    q = torch.zeros(C, C)
+    q[0, 1:] = torch.arange(1, C, dtype=torch.float32) + 1.0     # distinct weights: a deterministic peel order
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(len(inspect.stack()) + 120)
+    try:
+        pos = arrange_communities(q)
+    finally:
+        sys.setrecursionlimit(old)
+    assert sorted(pos.tolist()) == list(range(C))

@@ -156,6 +156,30 @@ def test_fuzz_against_the_python_registered_ops(cpp):
     run()
 
 
+def test_backward_reads_a_dense_copy_of_strided_weights(cpp):
+    """A weight vector that is a column of a wider matrix, or a stride-0 expand: the forward makes it contiguous
+    (spmm_args) and so must the three backward kernels — the reference does (spmm_sum_cpu.cpp:48-50).  Gradients equal
+    the dense copy's bit for bit (round 3 read the saved strided tensor's data_ptr as E dense floats)."""
+    C = cpp.ops
+    g = torch.Generator().manual_seed(11)
+    N, E, K = 300, 5000, 12
+    ei = torch.randint(0, N, (2, E), generator=g)
+    wfull = torch.rand(E, 3, generator=g)
+    go = torch.randn(N, K, generator=g)
+    for w in (wfull[:, 0], wfull[:, 2], torch.full((1,), 0.5).expand(E), wfull.t()[1]):
+        assert not w.is_contiguous()
+        wd = w.contiguous()
+        for name in ("spmm_sum", "spmm_mean", "spmm_max"):
+            x1, x2 = _pair(torch.randn(N, K, generator=g))
+            getattr(C, name)(ei, w, x1).backward(go)
+            getattr(C, name)(ei, wd, x2).backward(go)
+            assert torch.equal(x1.grad, x2.grad), (name, w.stride())
+            assert bool(torch.isfinite(x1.grad).all())
+        # and the backward ops called on their own
+        assert torch.equal(C.spmm_sum_backward(ei, w, go), C.spmm_sum_backward(ei, wd, go))
+        assert torch.equal(C.spmm_mean_backward(ei, w, go), C.spmm_mean_backward(ei, wd, go))
+
+
 def test_dispatcher_contracts(cpp):
     ops = cpp.ops
     g = torch.Generator().manual_seed(3)
