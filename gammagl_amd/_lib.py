@@ -15,7 +15,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_host.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SegPlanC(ctypes.Structure):
@@ -105,6 +105,7 @@ SIGNATURES = {
     "ggl_block_transpose": (c_int, [_V, _V, c_int64, c_int64, c_int64, _V, _V, _V, c_size_t, _V]),
     "ggl_set_option": (c_int, [c_char_p, c_int64]),
     "ggl_get_option": (c_int64, [c_char_p]),
+    "ggl_calib_stream": (c_int, [_V, _V, c_int64, c_int, _V]),
     "ggl_time_spmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V, c_int, POINTER(c_float)]),
 }
 

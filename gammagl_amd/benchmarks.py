@@ -48,6 +48,75 @@ def _sync(dev, world):
         torch.cuda.synchronize()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# PMC calibration: two launches of KNOWN byte counts in the access patterns of the aggregate, so that the counter
+# corrections applied to the dominant kernel are measured on this part, in this run (MI355X_MICROARCH.md, HBM section:
+# "calibrate on a known byte count in your own access pattern")
+# ---------------------------------------------------------------------------------------------------------------
+CALIB = {"reps": 3,
+         # kernel-name fragments of the calibration launches in a rocprofv3 counter file, bytes each moves
+         # a 16 B / lane streaming READ (16 x the 256 MB Infinity Cache): what the aggregate mostly does
+         "stream_read": {"kernel": "calib_stream_kernel<0>", "vec4": 1 << 28},      # 4 GiB: the ramp of a 0.7 ms launch is small
+         # 2 GiB read + 2 GiB written
+         "stream_copy": {"kernel": "calib_stream_kernel<1>", "vec4": 1 << 27},
+         # a gather of 256-byte rows (what a 64-column block of the aggregate reads per edge): a random PERMUTATION of
+         # 2^22 rows, so every source line is needed exactly once — known bytes with no cache-reuse term
+         "gather256": {"kernel": "gather_rows_ex_kernel", "rows": 1 << 22, "K": 64}}
+CALIB_ORDER = ("stream_read", "stream_copy", "gather256")
+
+
+def calib_known_bytes(which):
+    """(bytes read, bytes written) of one calibration launch"""
+    c = CALIB[which]
+    if which == "stream_read":
+        return c["vec4"] * 16, 0
+    if which == "stream_copy":
+        return c["vec4"] * 16, c["vec4"] * 16
+    return c["rows"] * c["K"] * 4 + c["rows"] * 8, c["rows"] * c["K"] * 4     # the rows + their int64 row ids
+
+
+def calibration_launches(eng, dev, time_it=False):
+    """Launch the calibration patterns CALIB["reps"] times each (`ggl_calib_stream` read / copy, then the library's
+    row-gather kernel over a random permutation).  With `time_it`: ms per launch of each (hipEvents on the launch
+    stream, median) -> the rates this part ACHIEVES, the yardstick for `frac_of_achievable`."""
+    import ctypes
+
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(99)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for which in CALIB_ORDER:
+        if which == "gather256":
+            n, K = CALIB[which]["rows"], CALIB[which]["K"]
+            src = torch.randn(n, K, generator=g, device=dev)
+            dst = torch.empty(n, K, device=dev)
+            idx = torch.randperm(n, generator=g, device=dev)
+            run = lambda: eng.gather_rows_into(src, idx, dst)      # noqa: E731
+        else:
+            n4 = CALIB[which]["vec4"]
+            src = torch.randn(n4 * 4, generator=g, device=dev)
+            dst = torch.empty(n4 * 4 if which == "stream_copy" else 65536, device=dev)
+            mode = 1 if which == "stream_copy" else 0
+            run = lambda: eng._check(eng.lib.ggl_calib_stream(ctypes.c_void_p(src.data_ptr()),   # noqa: E731
+                                                              ctypes.c_void_p(dst.data_ptr()), n4, mode, st))
+        ts = []
+        for _ in range(CALIB["reps"]):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            run()
+            b.record()
+            if time_it:
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+        torch.cuda.synchronize()
+        if time_it:
+            rd, wr = calib_known_bytes(which)
+            ms = min(ts)
+            out[which] = {"ms": ms, "GBps": (rd + wr) / (ms * 1e-3) / 1e9, "bytes": rd + wr}
+        del src, dst, run
+    torch.cuda.empty_cache()
+    return out
+
+
 def roofline_block(kernel, launches, ms_per_aggregate, alg_bytes_aggregate, compulsory_bytes, edges,
                    traffic_per_launch=None, traffic_source=None, extra=None):
     """The `roofline` object of the line.  `frac` is a fraction of the HBM peak that cannot exceed 1: measured
@@ -66,26 +135,43 @@ def roofline_block(kernel, launches, ms_per_aggregate, alg_bytes_aggregate, comp
     return rf
 
 
-def set_traffic(rf, traffic_per_launch, source):
-    """Fill `achieved` / `frac` / `traffic*` of a roofline block from measured bytes per launch (or mark them as
-    the algorithmic estimate, capped at the peak, when no counter data exists for this workload)."""
+def set_traffic(rf, traffic_per_launch, source, achievable=None):
+    """Fill the rate fields of a roofline block so that every fraction can be recomputed from fields of the block:
+
+      traffic              bytes per launch the counters saw on the L2's FABRIC side (FETCH_SIZE / WRITE_SIZE with the
+                           corrections `pmc_calibration` measured in this run) — Infinity-Cache hits INCLUDED: the
+                           counters sit between L2 and the fabric and cannot tell MALL from DRAM
+      achieved             = traffic / ms_per_launch                      [GB/s]
+      frac_of_peak         = achieved / peak (8 TB/s HBM3E)               — can exceed what DRAM alone delivers when the
+                                                                            Infinity Cache serves part of the misses
+      frac_of_achievable   = achieved / achievable_GBps                   — achievable = the rate a 16 B/lane streaming
+                                                                            copy reaches on this part, timed in this run
+      alg_frac             = alg_bytes_per_aggregate / ms_per_aggregate / peak  (SURVEY.md §8d's no-reuse byte model;
+                             ABOVE 1 when L2 / MALL serve gathers the model counts as DRAM reads — it is a rate of
+                             useful work, not a traffic fraction)
+      frac                 = min(frac_of_peak, 1): the contract's field."""
     rf["traffic"], rf["traffic_source"] = traffic_per_launch, source
+    rf["traffic_side"] = "L2-fabric side (FETCH_SIZE / WRITE_SIZE): Infinity-Cache hits included, not DRAM-only"
     if traffic_per_launch:
         rf["achieved"] = traffic_per_launch / (rf["ms_per_launch"] * 1e-3) / 1e9
-        rf["achieved_basis"] = "measured HBM-side bytes per launch (rocprofv3 --pmc: (2 x FETCH_SIZE + WRITE_SIZE) KiB) / launch duration"
+        rf["achieved_basis"] = "measured fabric-side bytes per launch (rocprofv3 --pmc, corrections calibrated in-run) / launch duration"
         rf["traffic_per_aggregate"] = traffic_per_launch * rf["launches_per_aggregate"]
         rf["traffic_over_compulsory"] = rf["traffic_per_aggregate"] / max(rf["compulsory_bytes"], 1)
+        rf["traffic_over_algorithmic"] = rf["traffic_per_aggregate"] / max(rf["alg_bytes_per_aggregate"], 1)
     else:
         rf["achieved"] = min(rf["eff_GBps"], PEAK_GBPS)
         rf["achieved_basis"] = "no counter data for this workload: algorithmic bytes / duration, capped at the peak"
-    # L2-miss traffic is served by HBM or by the 256 MB Infinity Cache in front of it (the counters cannot tell them
-    # apart): on a graph whose order carries locality the rate can exceed what HBM alone delivers.  The roofline
-    # fraction is then 1 — the kernel is at or beyond the HBM bound — and the excess is reported as such.
     raw = rf["achieved"] / PEAK_GBPS
+    rf["frac_of_peak"] = raw
+    rf["alg_frac"] = rf["eff_GBps"] / PEAK_GBPS
+    if achievable is not None:
+        rf["achievable_GBps"] = achievable
+    if rf.get("achievable_GBps"):
+        rf["frac_of_achievable"] = rf["achieved"] / rf["achievable_GBps"]
     rf["frac"] = min(raw, 1.0)
     if raw > 1.0:
         rf["beyond_hbm_peak"] = {"achieved_over_peak": raw,
-                                 "note": "L2-miss traffic above the HBM peak: part of it is served by the Infinity Cache"}
+                                 "note": "fabric-side traffic above the HBM peak: part of it is served by the Infinity Cache"}
     return rf
 
 
@@ -209,6 +295,7 @@ def pmc_probe_gcn(args, dev, eng):
     spec = WORKLOADS[args.workload]
     n_nodes, n_edges, _, _ = sizes_of(args.workload)
     parts, play = _dry(args, spec)
+    calibration_launches(eng, dev)
     pg = build_partition(n_nodes, n_edges, args.seed, play, 1, None, dev, eng, relabel=args.relabel,
                          order=args.order, parts=parts, kind=spec["gen"])
     gen = torch.Generator(device=dev).manual_seed(1)
@@ -289,7 +376,10 @@ def run_gcn(args, dev, rank, world, eng=None):
     rf = roofline_block(
         f"row_reduce_kernel<float,4,SUM,SPMM> (CSR SpMM-sum, rank 0's {'halo-source' if use_halo else 'local-source'} "
         f"edge block: {gp_t.E} edges into {pg.n_local} rows from {rows_t} source rows; the K={K} aggregate runs as "
-        f"{launches} launch(es) over {K // max(launches, 1)}-column blocks)",
+        f"{launches} launch(es) over {K // max(launches, 1)}-column blocks"
+        + (f"; the {gp_t.fwd.n_long} rows longer than {gp_t.fwd.chunk} elements are summed in the reference's serial order by "
+           f"hub_rows_f32_kernel on a side stream BESIDE each launch: a launch's duration is the later of the two, its "
+           f"traffic the sum of both" if gp_t.fwd.n_long > 0 else "") + ")",
         launches, ms_op, alg, b_min, gp_t.E)
 
     kc = n_cls + (-n_cls) % 4
@@ -387,6 +477,7 @@ def _event_ms(fn, reps=9, warm=3):
 def pmc_probe_gat(args, dev, eng):
     from .synth import rmat_graph
 
+    calibration_launches(eng, dev)
     n, e, _, _ = DATASETS["reddit"]
     ei = rmat_graph(n, e, seed=args.seed, device=dev)
     H, C = 8, 8

@@ -94,6 +94,10 @@ struct Options {
   // the lanes of a wave); 2 = also for the wave-per-row kernels (heavy rows first)
   int64_t row_order = 1;
   int64_t max_grid_x = 1 << 22;  // blocks per grid row before a launch is folded into 2-D (tests lower it)
+  // f32 sums: rows longer than the plan's chunk are added up in the reference's serial order (hubf32.hip: bit-identical to
+  // the CPU extension on EVERY row) instead of chunk by chunk (within rounding of it); 0 = the chunked walk (A/B switch)
+  int64_t exact_long_rows = 1;
+  int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
 };
 Options &options();
 
@@ -119,6 +123,27 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t index, uint64_t offset, uin
 }
 
 int rng_advance(int64_t *rng_state, void *stream);  // offset += 1 on the stream (epilogue.hip)
+
+#ifndef GGL_EMULATE
+// hubf32.hip: the long rows of an f32 sum in serial order, one partial row each (see the file's header)
+struct HubF32Args {
+  const float *x;
+  int64_t x_ld;
+  const int32_t *perm;      // segment mode: element of sorted position p; SpMM: weight index of p when !w_by_pos
+  const int32_t *col;       // SpMM: source row of sorted position p (NULL = segment mode)
+  const float *w;           // edge weights or NULL
+  int w_by_pos;
+  int64_t H, C;             // C > 0: multi-head weights w[wi * H + column / C]
+  const int64_t *rowptr;
+  const int32_t *long_rows;
+  int64_t n_long;
+  int64_t K;                // columns of this launch (a column block of a wider matrix: x points at its first column)
+  float *partial;           // [n_long, K]
+  int64_t avg_long_len;     // average length of the long rows (picks the stage size)
+};
+int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *forked);
+int hub_f32_join(hipStream_t stream);
+#endif
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,284 @@
+// gammagl_amd/csrc/hubf32.hip — hub rows of the f32 sums IN THE REFERENCE'S SERIAL ORDER (GPU build only: LDS + barriers).
+//
+// The reference adds a row's elements one after the other (spmm_sum_cpu.cpp:29-39: for e in edge order:
+// out[dst] += w[e] * x[src]; segment_sum_cpu.cpp:47-56 likewise), every add rounded to f32.  The row kernel of
+// reduce.hip reproduces that chain add for add on rows it walks in one piece; rows LONGER than the plan's chunk used to
+// be cut into chunks reduced by independent wavefronts and combined in chunk order — the same adds in another
+// association, i.e. a result within rounding of the reference's (measured against the reference's own c_spmm_sum at the
+// products size: 1752 of 2 449 029 rows differ, by up to 1.4e-5 of the row's magnitude) but not its bits.
+//
+// What is serial in such a row is only the ADD chain, not the gathers that feed it.  Here a workgroup owns
+// (hub row, 64-column slab): eight producer wavefronts gather the row's elements — four per load instruction, 16 lanes x
+// 16 bytes each, four stages (up to 512 elements) in flight per workgroup — multiply them by their edge weight (one rounded
+// multiply, as the row kernel does) and park them in a double-buffered LDS tile; ONE consumer wavefront, a column per
+// lane, folds the tile into its running sum in element order: ds_read_b32 + v_add_f32, eight reads issued ahead of the
+// eight dependent adds.  Its output is one partial row per hub row, which long_final_kernel (reduce.hip) turns into the
+// output row exactly like a chunk partial (mean, bias / ReLU / dropout epilogue, accumulate) — so every mode that sums
+// goes through here unchanged.  The launch runs on a side stream BESIDE the launch over the other rows (disjoint
+// outputs), forked and joined with events inside the library (legal under hipGraph capture).
+//
+// Cost model: the chain is >= len x ~8 cycles (a 150 000-element hub: 0.5 ms); a workgroup sustains ~384 elements per
+// gather latency.  The bytes are the ones the chunked walk moved (each element's slab once).
+#include "common.hpp"
+
+namespace ggl {
+
+constexpr int kHfCols = 64;                          // columns per slab = consumer lanes
+constexpr int kHfProd = 8;                           // producer wavefronts
+constexpr int kHfDepth = 4;                          // stages of gathers in flight per producer (and of ids ahead of them)
+constexpr int kHfBlock = kWave * (1 + kHfProd);      // wavefront 0 consumes
+// PER = load instructions per producer lane and stage (4 elements each): a stage is 32 PER elements.
+//   PER = 4: 128-element stages, 512 elements in flight, 144 VGPRs + 64 KiB of LDS -> one workgroup per CU: the
+//            configuration for LONG hub rows (products-sized graph, chunk 4096: 14.81 ms per K = 256 aggregate against
+//            14.78 chunked; PER = 2 there: 15.55);
+//   PER = 2:  64-element stages, 78 VGPRs + 32 KiB -> two workgroups per CU and half the padding of a short row: the
+//            configuration where "long" starts at 257 elements (arxiv-sized graph: 0.347 ms against 0.386 with PER = 4;
+//            chunked 0.290) — profiles/r4_hub_exact_timing.txt.
+constexpr int64_t kHfHeavyFrom = 4096;               // average long-row length from which PER = 4 is launched
+
+// The stage barrier.  __syncthreads() is a workgroup-scope release + acquire fence around s_barrier, and on gfx9 the
+// release waits for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)) — the producers' gathers of the
+// next stages included: with it each stage cost one full memory round trip however deep the pipeline was (2.15 us per
+// 128-element stage measured, profiles/r4_hub_exact_timeline.txt).  Only the LDS tile is shared here, so the fences
+// name the LDS address space alone: the barrier waits for the wave's LDS traffic (lgkmcnt) and nothing else.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// One pipeline slot of a producer lane: the ids / weights of a stage (requested kHfDepth iterations before its rows are)
+// and the rows themselves (requested kHfDepth iterations before they are parked).  The memory counter (vmcnt) retires
+// loads IN ORDER, so a wait for any load waits for every older one: ids and rows of the same slot are therefore issued
+// back to back, `rows(s), ids(s + Depth)`, and by the time either is needed everything issued after them — three more
+// stages of rows and ids — may still be in flight.  For the backend to COUNT that (s_waitcnt vmcnt(n), n > 0) the loop
+// body must be straight-line code: the index mode is a template parameter and no load is conditional — positions past
+// the row's end and lanes past the slab's last column load a clamped (valid) address and are simply not used.
+enum HubMode {
+  HUB_SEG = 0,        // rows x[p]                      (ids arrived sorted)
+  HUB_SEG_PERM = 1,   // rows x[perm[p]]
+  HUB_SPMM = 2,       // rows x[col[p]], no weights
+  HUB_SPMM_W = 3,     // ... * w[p]                     (weights in sorted order: every call but the first of a weight vector)
+  HUB_SPMM_WP = 4,    // ... * w[perm[p]]               (first sight: a dependent load, drains the pipeline — once)
+  HUB_BSPMM_W = 5,    // ... * w[p, head(column)]
+  HUB_BSPMM_WP = 6    // ... * w[perm[p], head(column)]
+};
+constexpr bool hub_seg(int m) { return m == HUB_SEG || m == HUB_SEG_PERM; }
+constexpr bool hub_has_w(int m) { return m >= HUB_SPMM_W; }
+constexpr bool hub_w_perm(int m) { return m == HUB_SPMM_WP || m == HUB_BSPMM_WP; }
+constexpr bool hub_heads(int m) { return m == HUB_BSPMM_W || m == HUB_BSPMM_WP; }
+
+template <int PER> struct HfRows { float4 r[PER]; };                 // the gathered quads of one stage
+template <int PER, int NW> struct HfW { float w[PER][NW]; };          // their weights (NW = 4: one per column — heads that change inside a quad)
+template <int PER> struct HfIds { int32_t row[PER], wi[PER]; };       // source rows (+ weight positions when they go through perm) of a stage
+
+// VEC4: K % 4 == 0, 16-byte aligned base and row stride — a lane moves its four columns as one 16-byte load.
+// WPC (multi-head weights only): the head changes inside a quad (C % 4 != 0) — a weight per column.
+template <int MODE, bool VEC4, bool WPC, int PER>
+__global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args a) {
+  constexpr int kHfPer = PER, kHfStage = kHfProd * PER * 4;
+  __shared__ float buf[2][kHfStage][kHfCols];        // 2 x 32 KiB (PER = 4) / 2 x 16 KiB (PER = 2)
+  constexpr int NW = WPC ? 4 : 1;
+  const int64_t slabs = (a.K + kHfCols - 1) / kHfCols;
+  const int64_t j = block_id() / slabs, slab = block_id() - j * slabs;
+  if (j >= a.n_long) return;
+  const int64_t row = a.long_rows[j];
+  const int64_t beg = a.rowptr[row], end = a.rowptr[row + 1], len = end - beg;   // (a long row: len > 0)
+  const int64_t c0 = slab * kHfCols;
+  const int ncol = (int)((a.K - c0) < kHfCols ? (a.K - c0) : kHfCols);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t nst = (len + kHfStage - 1) / kHfStage;
+  const int64_t nstp = (nst + 3) & ~(int64_t)3;      // stages incl. the padding of the last group of four (see below)
+  if (tid >= kWave) {
+    // ---- producers ------------------------------------------------------------------------------------------------
+    const int pw = (tid >> 6) - 1, eg = lane >> 4, piece = lane & 15;
+    const bool live = piece * 4 < ncol;
+    const int cl = live ? piece * 4 : 0;                        // first of this lane's four columns inside the slab
+    const int e0 = pw * (kHfPer * 4) + eg;                      // this lane's elements of a stage: e0 + 4 i
+    const float *xs = a.x + c0 + cl;
+    int64_t hd[NW];                                             // head of each weight this lane applies
+#pragma unroll
+    for (int c = 0; c < NW; ++c) {
+      const int64_t k = c0 + cl + c;
+      hd[c] = hub_heads(MODE) ? (k < a.K ? k : a.K - 1) / a.C : 0;
+    }
+    // register rings of Depth slots each (slot = stage % Depth), nothing is ever copied between slots:
+    //   step s:  park stage s (R, W);  request rows + weights of stage s + Depth into the slots just freed, addressed by
+    //            the ids requested at step s - Depth;  request the ids of stage s + 2 Depth into the id slot just used.
+    HfRows<PER> R[kHfDepth];
+    HfW<PER, NW> W[kHfDepth];
+    HfIds<PER> I[kHfDepth];
+    auto load_idx = [&](HfIds<PER> &t, int64_t st) {                  // ids of stage st (positions clamped into the row)
+#pragma unroll
+      for (int i = 0; i < kHfPer; ++i) {
+        int64_t p = beg + st * kHfStage + e0 + 4 * i;
+        p = p < end ? p : end - 1;
+        if (MODE == HUB_SEG) t.row[i] = (int32_t)p;
+        else if (MODE == HUB_SEG_PERM) t.row[i] = a.perm[p];
+        else t.row[i] = a.col[p];
+        if (hub_has_w(MODE)) t.wi[i] = hub_w_perm(MODE) ? a.perm[p] : (int32_t)p;
+      }
+    };
+    auto issue = [&](HfRows<PER> &d, HfW<PER, NW> &wv, const HfIds<PER> &t) {   // rows + weights of the stage whose ids sit in t
+#pragma unroll
+      for (int i = 0; i < kHfPer; ++i) {
+        const float *g = xs + (int64_t)t.row[i] * a.x_ld;
+        if (VEC4) {
+          d.r[i] = *reinterpret_cast<const float4 *>(g);
+        } else {                                                  // (columns past the slab's end: the last valid one again)
+          const int last = ncol - 1 - cl;
+          d.r[i].x = g[0];
+          d.r[i].y = g[last < 1 ? last : 1];
+          d.r[i].z = g[last < 2 ? last : 2];
+          d.r[i].w = g[last < 3 ? last : 3];
+        }
+        if (hub_has_w(MODE)) {
+#pragma unroll
+          for (int c = 0; c < NW; ++c)
+            wv.w[i][c] = hub_heads(MODE) ? a.w[(int64_t)t.wi[i] * a.H + hd[c]] : a.w[t.wi[i]];
+        }
+      }
+    };
+    auto park = [&](const HfRows<PER> &d, const HfW<PER, NW> &wv, int b) {
+#pragma unroll
+      for (int i = 0; i < kHfPer; ++i) {
+        float4 v = d.r[i];
+        if (hub_has_w(MODE)) {
+          v.x = __fmul_rn(wv.w[i][0], v.x);
+          v.y = __fmul_rn(wv.w[i][WPC ? 1 : 0], v.y);
+          v.z = __fmul_rn(wv.w[i][WPC ? 2 : 0], v.z);
+          v.w = __fmul_rn(wv.w[i][WPC ? 3 : 0], v.w);
+        }
+        // every lane parks at its own columns: elements past the row's end and columns past the slab's end are never read
+        *reinterpret_cast<float4 *>(&buf[b][e0 + 4 * i][piece * 4]) = v;
+      }
+    };
+    static_assert(kHfDepth == 4, "the stage loop below is unrolled for four slots");
+    // (sched_barrier: the backend's scheduler must not reorder the gathers across slots — it hoisted slot 0's rows to
+    //  the END of the prologue, after which every iteration waited for all outstanding loads: vmcnt(0) in the ISA)
+    // prologue: the ids of stages 0 .. Depth-1, then per slot `rows + weights (k), ids (k + Depth)`
+#pragma unroll
+    for (int k = 0; k < kHfDepth; ++k) load_idx(I[k], k);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < kHfDepth; ++k) {
+      issue(R[k], W[k], I[k]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_idx(I[k], k + kHfDepth);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#define GGL_HF_STEP(SL, ST)                                   \
+    park(R[SL], W[SL], (int)((ST) & 1));                      \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    issue(R[SL], W[SL], I[SL]);       /* stage ST + Depth */  \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    load_idx(I[SL], (ST) + 2 * kHfDepth);                     \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    lds_barrier();
+    // whole groups of four steps, NO exit inside a group: an early exit is lowered to a common latch block that merges
+    // the different "what is in flight" states of the steps, and the backend then waits for everything at the loop head
+    // (vmcnt(0) in the ISA).  The last group runs past the row's end on clamped positions: up to three stages of loads
+    // that hit the lines just read, parked and never consumed (the consumer keeps the same barrier count).
+    for (int64_t s = 0; s < nstp; s += 4) {
+      GGL_HF_STEP(0, s)
+      GGL_HF_STEP(1, s + 1)
+      GGL_HF_STEP(2, s + 2)
+      GGL_HF_STEP(3, s + 3)
+    }
+#undef GGL_HF_STEP
+    return;
+  }
+  // ---- consumer: one column per lane, the elements of a stage in order ---------------------------------------------
+  float acc = 0.0f;
+  for (int64_t s = 0; s < nstp; ++s) {
+    lds_barrier();                       // stage s is parked (the producers go on to park stage s + 1 in the other half)
+    const int b = (int)(s & 1);
+    if (lane < ncol && s < nst) {
+      const int cnt = (int)((len - s * kHfStage) < kHfStage ? (len - s * kHfStage) : kHfStage);
+      int e = 0;
+      for (; e + 8 <= cnt; e += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = buf[b][e + q][lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __fadd_rn(acc, v[q]);
+      }
+      for (; e < cnt; ++e) acc = __fadd_rn(acc, buf[b][e][lane]);
+    }
+  }
+  if (lane < ncol) a.partial[j * a.K + c0 + lane] = acc;
+}
+
+// ---- the side stream the hub launch runs on (one per device, created on first use) ----------------------------------
+struct HubSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static HubSide *hub_side() {
+  static HubSide sides[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  HubSide &s = sides[dev];
+  if (!s.ok) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    s.ok = true;
+  }
+  return &s;
+}
+
+// Launch the exact-order walk of the plan's long rows.  With `beside` the launch goes to the library's side stream,
+// forked from `stream` here; the caller launches its kernel over the other rows on `stream` and then calls
+// hub_f32_join(stream) before anything reads `partial`.
+int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *forked) {
+  *forked = false;
+  if (a.n_long <= 0 || a.K <= 0) return GGL_OK;
+  hipStream_t s = stream;
+  HubSide *side = beside ? hub_side() : nullptr;
+  if (side != nullptr) {
+    GGL_HIP_CHECK(hipEventRecord(side->fork, stream));
+    GGL_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+    s = side->stream;
+    *forked = true;
+  }
+  const int64_t slabs = ceil_div(a.K, (int64_t)kHfCols);
+  const int64_t grid = a.n_long * slabs;
+  const bool vec4 = a.K % 4 == 0 && a.x_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0;
+  const bool seg = a.col == nullptr, has_w = !seg && a.w != nullptr;
+  const bool w_perm = has_w && !a.w_by_pos && a.perm != nullptr;
+  const bool heads = has_w && a.C > 0, wpc = heads && a.C % 4 != 0;
+  const bool heavy = a.avg_long_len >= kHfHeavyFrom;
+#define GGL_HF(M, W)                                                                           \
+  do {                                                                                         \
+    if (vec4 && heavy) GGL_LAUNCH((hub_rows_f32_kernel<M, true, W, 4>), grid, kHfBlock, s, a);       \
+    else if (vec4) GGL_LAUNCH((hub_rows_f32_kernel<M, true, W, 2>), grid, kHfBlock, s, a);           \
+    else if (heavy) GGL_LAUNCH((hub_rows_f32_kernel<M, false, W, 4>), grid, kHfBlock, s, a);         \
+    else GGL_LAUNCH((hub_rows_f32_kernel<M, false, W, 2>), grid, kHfBlock, s, a);                    \
+  } while (0)
+  if (seg) {
+    if (a.perm) GGL_HF(HUB_SEG_PERM, false); else GGL_HF(HUB_SEG, false);
+  } else if (!has_w) {
+    GGL_HF(HUB_SPMM, false);
+  } else if (!heads) {
+    if (w_perm) GGL_HF(HUB_SPMM_WP, false); else GGL_HF(HUB_SPMM_W, false);
+  } else if (!wpc) {
+    if (w_perm) GGL_HF(HUB_BSPMM_WP, false); else GGL_HF(HUB_BSPMM_W, false);
+  } else {
+    if (w_perm) GGL_HF(HUB_BSPMM_WP, true); else GGL_HF(HUB_BSPMM_W, true);
+  }
+#undef GGL_HF
+  GGL_LAUNCH_CHECK();
+  if (*forked) GGL_HIP_CHECK(hipEventRecord(side->join, side->stream));
+  return GGL_OK;
+}
+
+int hub_f32_join(hipStream_t stream) {
+  HubSide *side = hub_side();
+  GGL_REQUIRE(side != nullptr, GGL_EHIP, "hub side stream is gone");
+  GGL_HIP_CHECK(hipStreamWaitEvent(stream, side->join, 0));
+  return GGL_OK;
+}
+
+}  // namespace ggl

@@ -50,6 +50,8 @@ Options &options() {
     t.col_block_min_degree = env_i64("GGL_COL_BLOCK_MIN_DEGREE", t.col_block_min_degree);
     t.row_order = env_i64("GGL_ROW_ORDER", t.row_order);
     t.max_grid_x = env_i64("GGL_MAX_GRID_X", t.max_grid_x);
+    t.exact_long_rows = env_i64("GGL_EXACT_LONG_ROWS", t.exact_long_rows);
+    t.exact_side_stream = env_i64("GGL_EXACT_SIDE_STREAM", t.exact_side_stream);
     return t;
   }();
   return o;
@@ -285,6 +287,8 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "col_block_min_degree")) o.col_block_min_degree = value;
   else if (!strcmp(name, "row_order")) o.row_order = value;
   else if (!strcmp(name, "max_grid_x")) o.max_grid_x = value > 0 ? value : 1;
+  else if (!strcmp(name, "exact_long_rows")) o.exact_long_rows = value;
+  else if (!strcmp(name, "exact_side_stream")) o.exact_side_stream = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
 }
@@ -302,6 +306,8 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "col_block_min_degree")) return o.col_block_min_degree;
   if (!strcmp(name, "row_order")) return o.row_order;
   if (!strcmp(name, "max_grid_x")) return o.max_grid_x;
+  if (!strcmp(name, "exact_long_rows")) return o.exact_long_rows;
+  if (!strcmp(name, "exact_side_stream")) return o.exact_side_stream;
   return -1;
 }
 
@@ -501,6 +507,47 @@ extern "C" int ggl_gather_rows_f32(const float *src, const int32_t *perm, int64_
   if (E == 0) return GGL_OK;
   GGL_LAUNCH((gather_rows_f32_kernel), grid_for(E * H), kBlock, as_stream(stream), src, perm, E * H,
              H, out);
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+// ---- ggl_calib_stream: the streaming yardstick of bench.py's roofline leg ------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void calib_stream_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                              int64_t n, float *__restrict__ sink) {
+  const int64_t stride = grid_threads();
+  float4 acc{0.0f, 0.0f, 0.0f, 0.0f};
+  int64_t i = thread_id();
+  for (; i + 7 * stride < n; i += 8 * stride) {     // eight independent 16-byte loads in flight per lane
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (MODE == 1) dst[i + u * stride] = v[u];
+      else { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+  }
+  for (; i < n; i += stride) {
+    const float4 a = src[i];
+    if (MODE == 1) dst[i] = a; else { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+  }
+  if (MODE == 0) {   // keep the loads alive: one float per wavefront-sized group of threads
+    const float v = acc.x + acc.y + acc.z + acc.w;
+    if (v == 1234.5678f || (threadIdx.x & 63) == 0) sink[(thread_id() >> 6) & 65535] = v;
+  }
+}
+
+extern "C" int ggl_calib_stream(const float *src, float *dst, int64_t n_vec4, int mode, void *stream) {
+  GGL_REQUIRE(n_vec4 >= 0 && (mode == 0 || mode == 1), GGL_EINVAL, "bad arguments");
+  if (n_vec4 == 0) return GGL_OK;
+  GGL_REQUIRE(src && dst && (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0,
+              GGL_EINVAL, "src / dst must be 16-byte aligned");
+  int64_t g = ceil_div(n_vec4, (int64_t)kBlock * 4);
+  if (g > 256 * 8) g = 256 * 8;        // 256 CUs x 8 blocks of 4 wavefronts (full occupancy), grid-stride for the rest
+  const float4 *s4 = reinterpret_cast<const float4 *>(src);
+  if (mode == 1) GGL_LAUNCH((calib_stream_kernel<1>), g, kBlock, as_stream(stream), s4, reinterpret_cast<float4 *>(dst), n_vec4, dst);
+  else GGL_LAUNCH((calib_stream_kernel<0>), g, kBlock, as_stream(stream), s4, reinterpret_cast<float4 *>(dst), n_vec4, dst);
   GGL_LAUNCH_CHECK();
   return GGL_OK;
 }

@@ -58,6 +58,7 @@ struct ReduceDims {
   int64_t H, C;
   int64_t n_long, n_chunks;
   int64_t chunk_blocks;  // leading blocks of the launch that reduce long-row chunks
+  int exact_long;        // long rows arrive as ONE partial each, summed in the reference's serial order (hubf32.hip)
   int logL;
   int swizzle;
   int w_by_pos;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kBlock) void long_final_kernel(const int64_t *__res
   const int64_t j = block_id();  // one block per long row
   if (j >= d.n_long) return;
   const int64_t row = long_rows[j];
-  const int64_t c0 = chunk_ptr[j], c1 = chunk_ptr[j + 1];
+  const int64_t c0 = d.exact_long ? j : chunk_ptr[j], c1 = d.exact_long ? j + 1 : chunk_ptr[j + 1];
   const int64_t len = rowptr[row + 1] - rowptr[row];
   for (int64_t k = threadIdx.x; k < d.K; k += kBlock) {
     A acc[1];
@@ -608,14 +609,59 @@ static inline int pow2_ceil_log2(int64_t v) {
 #define GGL_RPTR_ARGS(S)                                                                           \
   static_cast<const S *>(a.x), a.perm, a.col, a.w, a.rowptr, a.aux_rowptr, a.aux_arg, a.epi_bias, a.epi_rng, a.epi_add
 
+// f32 sums whose long rows are reduced in the reference's serial order instead of chunk by chunk (hubf32.hip): every
+// mode whose value is "an element, times its weight" — segment sum / mean, SpMM sum / mean, bspmm, with or without the
+// epilogue.  (max has no rounding; the mean / max backward walks keep their chunks.)
+template <typename T, int OP, int MODE> constexpr bool exact_long_mode() {
+  return std::is_same<T, float>::value && OP != OP_MAX &&
+         (seg_like(MODE) || spmm_like(MODE) || MODE == MODE_BSPMM);
+}
+
 template <typename T, int VEC, int OP, int MODE, int IDX, bool RAG = false>
-static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
+static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) {
   using S = typename TT<T>::S;
+  ReduceArgs a = a_in;
   const bool uniform = !RAG && (d.logL == 6) && std::is_same<T, float>::value;   // (ragged rows: K <= 128 only)
   S *out = static_cast<S *>(a.out);
+  bool exact = false, forked = false;
+  // (positions travel as int32 in the hub kernel's registers, like the plan's own perm entries)
+  if constexpr (exact_long_mode<T, OP, MODE>())
+    exact = a.n_long > 0 && options().exact_long_rows != 0 && a.E < ((int64_t)1 << 31);
+#ifdef GGL_EMULATE
+  if (exact) {   // the host build walks a row with one thread anyway: no chunks at all is the serial order
+    a.n_long = 0; a.n_chunks = 0;
+    d.n_long = 0; d.n_chunks = 0;
+    d.chunk = (int64_t)1 << 62;
+    exact = false;
+  }
+#endif
   if (a.n_long > 0)
     GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
-  d.chunk_blocks = a.n_long > 0 ? ceil_div(a.n_chunks, kWavesPerBlock) : 0;
+  d.chunk_blocks = (a.n_long > 0 && !exact) ? ceil_div(a.n_chunks, kWavesPerBlock) : 0;
+  d.exact_long = exact ? 1 : 0;
+#ifndef GGL_EMULATE
+  if constexpr (exact_long_mode<T, OP, MODE>()) {
+    if (exact) {
+      HubF32Args h{};
+      h.x = reinterpret_cast<const float *>(a.x);
+      h.x_ld = d.x_ld;
+      h.perm = a.perm;
+      h.col = seg_like(MODE) ? nullptr : a.col;
+      h.w = seg_like(MODE) ? nullptr : a.w;
+      h.w_by_pos = a.w_by_pos;
+      h.H = a.H;
+      h.C = (MODE == MODE_BSPMM) ? a.C : 0;
+      h.rowptr = a.rowptr;
+      h.long_rows = a.long_rows;
+      h.n_long = a.n_long;
+      h.K = a.K;
+      h.partial = static_cast<float *>(a.partial);
+      h.avg_long_len = a.n_chunks * a.chunk / (a.n_long > 0 ? a.n_long : 1);   // (chunks are full but the last of a row)
+      const int rc = hub_f32_launch(h, stream, options().exact_side_stream != 0, &forked);
+      if (rc) return rc;
+    }
+  }
+#endif
   const int64_t grid = d.chunk_blocks + d.nblocks;
   GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "grid too large");
   const int32_t *order = (options().row_order && (!uniform || options().row_order > 1)) ? a.row_order : nullptr;
@@ -643,6 +689,12 @@ static int launch_idx(const ReduceArgs &a, ReduceDims d, hipStream_t stream) {
   }
 #undef GGL_RR_ARGS
   GGL_LAUNCH_CHECK();
+#ifndef GGL_EMULATE
+  if (forked) {
+    const int rc = hub_f32_join(stream);
+    if (rc) return rc;
+  }
+#endif
   if (a.n_long > 0) {
     GGL_LAUNCH((long_final_kernel<T, OP, MODE>), a.n_long, kBlock, stream, a.rowptr, a.long_rows,
                a.chunk_ptr, static_cast<const S *>(a.partial), (const int64_t *)a.partial_arg, out,

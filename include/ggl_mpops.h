@@ -38,7 +38,8 @@ extern "C" {
 
 /* 5 (round 3): + ggl_bspmm_grad_w_sorted[_scratch_bytes]; v4's number had not been raised for the symbols added
  * late in round 2 (ggl_sample_hop, ggl_block_transpose, ggl_gat_sh_*, ggl_segment_hub16*, ggl_spmm_col_blocks) */
-#define GGL_ABI_VERSION 5
+/* 6 (round 4): + ggl_calib_stream (bench.py's achievable-rate yardstick) */
+#define GGL_ABI_VERSION 6
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
 enum {
@@ -431,6 +432,12 @@ int ggl_block_transpose(const int64_t *rowptr, const int32_t *col, int64_t N_dst
  * ---------------------------------------------------------------------------------------------- */
 int ggl_set_option(const char *name, int64_t value);
 int64_t ggl_get_option(const char *name);
+
+/* Measurement aid (bench.py's roofline leg): a grid-stride pass over `n_vec4` 16-byte vectors of `src`, 16 bytes per
+ * lane and four independent loads in flight — mode 0: read-only (every wavefront folds what it read into ONE float of
+ * `dst`, which must hold at least 65536 floats), mode 1: copy to `dst`.  The rate it reaches is "what a streaming kernel
+ * achieves on this part" next to the 8 TB/s spec peak; no reference counterpart. */
+int ggl_calib_stream(const float *src, float *dst, int64_t n_vec4, int mode, void *stream);
 
 /* Profiling aid: run `reps` launches of the dominant SpMM-sum kernel bracketed by hipEvents on
  * `stream` and return the average milliseconds per launch in *ms_host (SYNCHRONOUS). */

@@ -1,0 +1,69 @@
+"""How a HIP result is compared with the reference's at full size.
+
+TEST INFRASTRUCTURE ONLY (like everything under oracle/): used by tests/ and by bench.py's cpu_baseline leg, never by
+the product package.  One function, so that the GPU tests and the bench line's `parity` object state the same thing.
+
+Criterion (BASELINE.json north_star: "bit-exact for segment_max argmax indices and within 1e-5 relative for float
+reductions"):
+
+* rows the HIP kernels reduce in ONE piece follow the reference's serial order (spmm_sum_cpu.cpp:29-39: for e in edge
+  order: out[dst] += w * x[src]) add for add — they must be BIT-IDENTICAL, and `rows_bit_exact_frac` says how many are;
+* rows longer than the plan's chunk are combined from in-order partial sums, a different association of the same adds:
+  `max_rel_err` = max |got - ref| / max(|ref|, floor_i), floor_i = the largest |ref| of row i (an element that cancels to
+  ~0 inside a row whose other elements are O(1) has no meaningful relative error of its own; the row's magnitude is the
+  scale its rounding errors live on).  Pass = max_rel_err <= tol.
+"""
+import torch
+
+TOL = 1e-5
+
+
+def _bits(t):
+    if t.dtype == torch.float32:
+        return t.contiguous().view(torch.int32)
+    if t.dtype == torch.float64:
+        return t.contiguous().view(torch.int64)
+    if t.dtype in (torch.float16, torch.bfloat16):
+        return t.contiguous().view(torch.int16)
+    return t
+
+
+def report(got, ref, tol=TOL, rows_in_one_piece=None, floor_min=0.0):
+    """`got`, `ref`: tensors of the same shape [rows, ...] (any device; compared where `got` lives).
+    `rows_in_one_piece`: optional bool [rows] — rows that MUST be bit-identical (reduced without chunk partials).
+    `floor_min`: lower bound of the per-row scale, for quantities that cancel to ~0 over a whole row by construction
+    (the logit gradients of an edge softmax: exactly 0 for a one-edge row) — callers pass the tensor's mean |ref|."""
+    ref = ref.to(got.device)
+    assert got.shape == ref.shape and got.dtype == ref.dtype, (got.shape, ref.shape, got.dtype, ref.dtype)
+    n = int(got.shape[0])
+    g2, r2 = got.reshape(n, -1), ref.reshape(n, -1)
+    same = _bits(g2) == _bits(r2)
+    if g2.dtype.is_floating_point:      # NaN payloads / signed zeros are compared as bits above; as values for the error
+        both_nan = torch.isnan(g2) & torch.isnan(r2)
+        same = same | both_nan
+    row_same = same.all(dim=1)
+    out = {"rows": n, "rows_bit_exact_frac": float(row_same.double().mean()) if n else 1.0,
+           "elems_bit_exact_frac": float(same.double().mean()) if same.numel() else 1.0, "tol": tol}
+    if g2.dtype.is_floating_point and same.numel():
+        d = (g2.double() - r2.double()).abs()
+        d = torch.where(same, torch.zeros_like(d), d)
+        floor = r2.double().abs().amax(dim=1, keepdim=True).clamp(min=max(float(floor_min), 1e-30))
+        rel = d / torch.maximum(r2.double().abs(), floor)
+        out["max_abs_err"] = float(d.max())
+        out["max_rel_err"] = float(torch.nan_to_num(rel, nan=float("inf")).max())
+    else:
+        out["max_abs_err"] = 0.0 if bool(same.all()) else float("inf")
+        out["max_rel_err"] = out["max_abs_err"]
+    out["ok"] = out["max_rel_err"] <= tol
+    if rows_in_one_piece is not None:
+        m = rows_in_one_piece.to(got.device)
+        out["one_piece_rows"] = int(m.sum())
+        out["one_piece_rows_bit_exact"] = bool(row_same[m].all()) if int(m.sum()) else True
+        out["ok"] = bool(out["ok"] and out["one_piece_rows_bit_exact"])
+    return out
+
+
+def check(got, ref, what, tol=TOL, rows_in_one_piece=None, floor_min=0.0):
+    r = report(got, ref, tol, rows_in_one_piece, floor_min)
+    assert r["ok"], f"{what}: {r}"
+    return r

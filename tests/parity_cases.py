@@ -342,6 +342,103 @@ def check_long_rows(eng, dev, oracle, chunk=8):
         eng.graph_cache.clear()
 
 
+def check_exact_long_rows(eng, dev, oracle, chunk=64):
+    """f32 sums on rows LONGER than the plan's chunk are the reference's serial chain, add for add (hubf32.hip on the
+    GPU: producer wavefronts gather, one consumer wavefront adds in element order; the host build walks rows in one
+    piece): every mode that sums is BIT-IDENTICAL to the oracle on every row — real-valued inputs, where another
+    association of the same adds shows in the last bits.  Hubs of several LDS stages, ragged last stages, a row just
+    over the threshold, widths that are / are not 16-byte rows, column-block launches, strided + accumulate forms."""
+    old = eng.chunk
+    eng.chunk = chunk
+    eng.clear_caches()
+    try:
+        rng = np.random.default_rng(17)
+        N, E = 50, 5000
+        hubs = ((7, 2900), (0, 1024), (33, 385), (12, chunk + 1))     # (row, length); stages are 128 elements
+
+        def hub_ids():
+            ids = rng.integers(0, N, size=E).astype(np.int64)
+            at = 0
+            for r, n in hubs:
+                ids[at:at + n] = r
+                at += n
+            return ids
+
+        # ---- segment sum / mean: unsorted ids (perm) and sorted ids
+        for K in (1, 4, 5, 47, 64, 100, 130, 256):
+            ids = hub_ids()
+            rng.shuffle(ids)
+            for sort in (False, True):
+                ids_k = np.sort(ids) if sort else ids
+                x = (rng.standard_normal((E, K)) * 3).astype(np.float32)
+                xt, it = to_t(x, dev), to_t(ids_k, dev)
+                plan = eng.seg_plan(it, N)
+                assert plan.n_long >= 3
+                assert_same(to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids_k, N), f"exact seg sum K{K} sorted={sort}")
+                assert_same(to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids_k, N), f"exact seg mean K{K} sorted={sort}")
+        # ---- gspmm sum / mean, forward and transposed backward; weights absent / first sight / sorted copy
+        for K in (4, 48, 64, 100, 256):
+            index = np.stack([rng.integers(0, N, size=E), hub_ids()]).astype(np.int64)
+            index[0, E - 1500:] = 11                      # a source hub: long rows in the transposed plan too
+            o = rng.permutation(E)
+            index = np.ascontiguousarray(index[:, o])
+            w = rng.standard_normal(E).astype(np.float32)
+            x = rng.standard_normal((N, K)).astype(np.float32)
+            go = rng.standard_normal((N, K)).astype(np.float32)
+            it, wt = to_t(index, dev), to_t(w, dev)
+            gp = eng.graph_plan(it, N)
+            assert gp.fwd.n_long >= 3 and gp.bwd.n_long >= 1
+            want, want_g = oracle.spmm_sum_fwd(index, w, x), oracle.spmm_sum_bwd(index, w, go)
+            for call in range(3):                          # call 0: w[perm[p]] in the kernel; later: streamed sorted copy
+                xt = to_t(x, dev).requires_grad_(True)
+                y = eng.c_spmm_sum(it, wt, xt)
+                y.backward(to_t(go, dev))
+                assert_same(to_np(y), want, f"exact spmm sum K{K} call {call}")
+                assert_same(to_np(xt.grad), want_g, f"exact spmm sum backward K{K} call {call}")
+            assert_same(to_np(eng.c_spmm_mean(it, wt, to_t(x, dev))), oracle.spmm_mean_fwd(index, w, x)[0], f"exact spmm mean K{K}")
+            ones = np.ones(E, np.float32)
+            assert_same(to_np(eng.c_spmm_sum(it, None, to_t(x, dev))), oracle.spmm_sum_fwd(index, ones, x), f"exact spmm sum no weights K{K}")
+            # the 64-column block launches (forced: the graph is far below the automatic threshold)
+            if K % 64 == 0 and K >= 128:
+                with option(eng, "col_block_min_edges", 0), option(eng, "col_block_min_degree", 0):
+                    assert int(eng.lib.ggl_spmm_col_blocks(E, K, N)) > 1
+                    assert_same(to_np(eng.c_spmm_sum(it, wt, to_t(x, dev))), want, f"exact spmm sum K{K} column blocks")
+            # strided + accumulate: a column block of a wider matrix, a second edge set added onto a result
+            if K >= 48 and K % 16 == 0:
+                wide = to_t(np.concatenate([x, x[:, :16]], axis=1), dev)
+                outw = torch.zeros(N, K + 16, device=dev)
+                eng.spmm_sum_into(gp.fwd, gp.col, wt, wide[:, :K], outw[:, 16:])
+                assert_same(to_np(outw[:, 16:].contiguous()), want, f"exact spmm_sum_into strided K{K}")
+            # the fused epilogue rides on the same partial rows
+            b = rng.standard_normal(K).astype(np.float32)
+            if K % 4 == 0:
+                ye = eng.spmm_epi(gp, wt, to_t(x, dev), "sum", bias=to_t(b, dev), relu=True)
+                assert_same(to_np(ye), np.maximum(want + b, 0).astype(np.float32), f"exact spmm epi K{K}")
+        # ---- bspmm: per-head weights
+        for H, C in ((2, 8), (4, 16), (3, 5), (8, 32)):
+            index = np.stack([rng.integers(0, N, size=E), hub_ids()]).astype(np.int64)
+            index = np.ascontiguousarray(index[:, rng.permutation(E)])
+            w = rng.standard_normal((E, H)).astype(np.float32)
+            x = rng.standard_normal((N, H, C)).astype(np.float32)
+            go = rng.standard_normal((N, H, C)).astype(np.float32)
+            ogx, ogw = oracle.bspmm_sum_bwd(index, w, x, go)
+            for call in range(2):
+                wt, xt = to_t(w, dev).requires_grad_(True), to_t(x, dev).requires_grad_(True)
+                y = eng.c_bspmm_sum(to_t(index, dev), wt, xt)
+                y.backward(to_t(go, dev))
+                assert_same(to_np(y), oracle.bspmm_sum_fwd(index, w, x), f"exact bspmm {H}x{C} call {call}")
+                assert_same(to_np(xt.grad), ogx, f"exact bspmm gx {H}x{C} call {call}")
+        # ---- the A/B switch: the chunked walk is still there, within rounding
+        with option(eng, "exact_long_rows", 0):
+            ids = hub_ids()
+            x = (rng.standard_normal((E, 64)) * 3).astype(np.float32)
+            np.testing.assert_allclose(to_np(eng.c_segment_sum(to_t(x, dev), to_t(ids, dev), N)),
+                                       oracle.segment_sum(x, ids, N), rtol=1e-5, atol=1e-4)
+    finally:
+        eng.chunk = old
+        eng.clear_caches()
+
+
 def _check_gat(eng, dev, oracle, index, N, H, C, rng):
     el = rng.standard_normal((N, H)).astype(np.float32)
     er = rng.standard_normal((N, H)).astype(np.float32)

@@ -103,6 +103,10 @@ def test_long_row_chunking(eng, oracle):
     pc.check_long_rows(eng, DEV, oracle)
 
 
+def test_long_rows_in_the_reference_order(eng, oracle):
+    pc.check_exact_long_rows(eng, DEV, oracle)
+
+
 def test_gat_fused_random(eng, oracle):
     pc.check_gat_random(eng, DEV, oracle)
 
