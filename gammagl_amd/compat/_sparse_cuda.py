@@ -7,7 +7,7 @@ gammagl/ops/sparse/cuda/sparse_module.cu:10-16).
 
 and routes GPU tensors to these four names (CPU tensors keep going to GammaGL's own CPU extension,
 ``sparse.py:42-52,65-75,148-160``).  Copy (or symlink) THIS file to ``gammagl/ops/sparse/_sparse_cuda.py`` and that
-statement binds the callables below with zero edits to GammaGL: ``ind2ptr`` / ``ptr2ind`` / ``sample_adj`` — hence
+statement binds the callables below with zero edits to GammaGL: ``ind2ptr`` / ``ptr2ind`` / ``sample_adj`` / ``neighbor_sample`` — hence
 ``SparseGraph.sample_adj`` and ``loader.NeighborSampler`` — run on the MI355X kernels (``ggl_ind2ptr``,
 ``ggl_ptr2ind``, ``ggl_sample_count`` / ``ggl_sample_pick``; include/ggl_mpops.h).  Same argument lists and return
 values as the pybind functions (cuda/convert.cu:108-133, cuda/neighbor_sample.cu:882-929).  Needs ``gammagl_amd``
@@ -48,8 +48,9 @@ def cuda_torch_sample_adj(colptr, row, input_nodes, fanouts, replace=False, dire
 
 
 def cuda_torch_neighbor_sample(colptr, row, input_nodes, fanouts, replace=False, directed=False, random_seed=0):
-    """torch_cu_neighbor_sample (cuda/neighbor_sample.cu:744-778), the multi-hop PyG-style sampler: NOT on the path this
-    package accelerates (GammaGL's own loader, loader/neighbor_sampler.py:74-109, samples hop by hop through
-    ``sample_adj``).  Raises instead of answering with something else."""
-    raise NotImplementedError("cuda_torch_neighbor_sample is outside the accelerated path: use loader.NeighborSampler "
-                              "(sample_adj per hop), or GammaGL's CPU c_neighbor_sample")
+    """torch_cu_neighbor_sample (cuda/neighbor_sample.cu:744-778), the multi-hop sampler: returns
+    ``[sample_cols, sample_rows, sample_nodes, sample_edges]`` as cu_neighbor_sample assembles them (:704-733) — see
+    ``gammagl_amd.sampler.neighbor_sample`` for the hop-by-hop statement.  ``fanouts`` is the CPU int64 tensor the
+    caller builds (its data pointer is read on the host, :753); ``directed`` and ``random_seed`` are accepted: the
+    reference kernel ignores the first and the draws here come from the engine's device RNG stream."""
+    return _sampler.neighbor_sample(colptr, row, input_nodes, fanouts, bool(replace))

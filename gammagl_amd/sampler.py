@@ -83,6 +83,68 @@ def sample_adj(rowptr, col, idx, num_neighbors, replace=False, eng=None, first_p
     return out_rowptr, local, out_n_id, e_pos
 
 
+def neighbor_sample(colptr, row, input_nodes, fanouts, replace=False, eng=None):
+    """The multi-hop sampler behind ``cuda_torch_neighbor_sample`` (ops/sparse/cuda/neighbor_sample.cu:744-778 ->
+    cu_neighbor_sample :634-741), chained on the device from the per-hop kernels:
+
+    * hop l samples ``min(degree, fanouts[l])`` distinct in-edges (all of them for -1) of every node ADDED by hop
+      l - 1 (hop 0: ``input_nodes``) — cu_neighbor_sample_one_hop :198-306, frontier = ``input_nodes +
+      last_num_input_node`` :647-650; the edge ids are positions in ``row`` (``row_offset + colptr[node]`` :131),
+      frontier node by frontier node;
+    * the nodes those edges lead to (``row[eid]`` :308-318) that are not in the node list yet are appended to it in
+      ASCENDING id order (get_new_input_nodes :436-532: a sort of old / new ids tagged in the low bit, new = odd, first
+      of its value and not preceded by its own even twin); no new node ends the loop early (:665-668);
+    * returns ``[sample_cols, sample_rows, sample_nodes, sample_edges]`` (:729-733): the node list, the edge ids of all
+      hops concatenated (:706-718), and per edge the position in the node list of the node it was sampled FOR (the owner
+      of that stretch of ``row``, kernal_get_col :362-378) and of the node it leads to (kernal_get_row :380-396).
+
+    ``replace=True`` leaves the reference's hop undefined (:217-218 is an empty branch); here it draws with replacement.
+    The draws come from the engine's device RNG (Floyd's algorithm on Philox4x32-10), not from ``random_seed`` + cuRAND's
+    reservoir-with-atomicMax (:103-135) — same contract (distinct in-edges, uniformly), other bits.  One host read per
+    hop (the hop's edge count)."""
+    eng = eng or _engine(colptr)
+    dev = eng._dev(colptr, row, input_nodes)
+    colptr = colptr.contiguous().to(torch.int64)
+    row = row.contiguous().to(torch.int64)
+    nodes = input_nodes.contiguous().to(torch.int64).reshape(-1)
+    fan = [int(f) for f in (fanouts.reshape(-1).tolist() if isinstance(fanouts, torch.Tensor) else list(fanouts))]
+    n_graph = int(colptr.shape[0]) - 1
+    st = eng._stream(dev)
+    frontier, f_off = nodes, 0                      # the nodes the next hop samples for, and where they sit in `nodes`
+    eids, owners = [], []
+    for fanout in fan:
+        B = int(frontier.shape[0])
+        if B == 0:
+            break
+        deg = torch.empty(B, dtype=torch.int64, device=dev)
+        eng._check(eng.lib.ggl_sample_count(_ptr(colptr), _ptr(frontier), B, n_graph, fanout, int(bool(replace)), _ptr(deg), st))
+        ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(deg, 0, out=ptr[1:])
+        E = int(ptr[-1])                             # the one host read of this hop
+        e_pos = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+        nbr = torch.empty(max(E, 1), dtype=torch.int64, device=dev)
+        eng._check(eng.lib.ggl_sample_pick(_ptr(colptr), _ptr(row), _ptr(frontier), B, fanout, int(bool(replace)), _ptr(ptr),
+                                           _ptr(eng._rng_state(dev)), _ptr(e_pos), _ptr(nbr), st))
+        e_pos, nbr = e_pos[:E], nbr[:E]
+        eids.append(e_pos)
+        owners.append(torch.repeat_interleave(torch.arange(f_off, f_off + B, device=dev), deg, output_size=E))
+        new = torch.unique(nbr)                      # ascending
+        new = new[~torch.isin(new, nodes)]
+        if new.numel() == 0:
+            break
+        f_off = int(nodes.shape[0])
+        nodes = torch.cat([nodes, new])
+        frontier = new
+    edges = torch.cat(eids) if eids else torch.empty(0, dtype=torch.int64, device=dev)
+    cols = torch.cat(owners) if owners else torch.empty(0, dtype=torch.int64, device=dev)
+    # position of every sampled edge's far end in the node list (each is there by construction)
+    order = torch.argsort(nodes, stable=True)
+    srt = nodes[order]
+    far = row[edges]
+    rows = order[torch.searchsorted(srt, far).clamp(max=max(int(nodes.shape[0]) - 1, 0))] if edges.numel() else edges.clone()
+    return [cols, rows, nodes, edges]
+
+
 @dataclass
 class EdgeIndex:  # loader/neighbor_sampler.py:12-16
     edge_index: torch.Tensor

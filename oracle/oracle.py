@@ -307,3 +307,44 @@ def sample_adj_full(rowptr, col, idx):
     flat = [t for r in cols for t in r]
     return (np.array(out_rowptr, np.int64), np.array([t[0] for t in flat], np.int64),
             np.array(n_ids, np.int64), np.array([t[1] for t in flat], np.int64))
+
+
+# ---- the multi-hop GPU sampler's deterministic branch (fan-out -1), restated in Python ---------------------------
+def neighbor_sample_full(colptr, row, input_nodes, num_hops):
+    """ops/sparse/cuda/neighbor_sample.cu:634-741 (cu_neighbor_sample) with every fan-out = -1 (no draw:
+    get_eids_neighbor_sampler :120-123 takes rnd = row_offset): hop l lists ALL in-edges of the nodes hop l - 1 added
+    (positions colptr[v] .. colptr[v + 1] - 1 of `row`, frontier node by frontier node, :131); the far ends not yet in
+    the node list are appended in ascending id order (get_new_input_nodes :436-532); no new node ends the loop (:665-668).
+    Returns (sample_cols, sample_rows, sample_nodes, sample_edges) as int64 arrays (:704-733): per edge the position in
+    the node list of its owner (kernal_get_col :362-378) and of its far end (kernal_get_row :380-396).
+    PARITY UNPINNED: the CUDA file cannot be built here (no nvcc) and the CPU counterpart (neighbor_sample.cpp) needs the
+    `parallel_hashmap` submodule, which is empty in the reference checkout — this restatement follows the .cu line by
+    line and is the only checker of that function's node / edge ORDER; its per-hop building block (sample_adj) is pinned
+    against the reference's compiled c_sample_adj (tests/golden/sampler.npz)."""
+    colptr, row = np.asarray(colptr, np.int64), np.asarray(row, np.int64)
+    nodes = [int(v) for v in np.asarray(input_nodes).reshape(-1)]
+    have = set(nodes)
+    frontier, f_off = list(nodes), 0
+    cols, edges = [], []
+    for _ in range(int(num_hops)):
+        if not frontier:
+            break
+        new = set()
+        for k, v in enumerate(frontier):
+            for e in range(int(colptr[v]), int(colptr[v + 1])):
+                edges.append(e)
+                cols.append(f_off + k)
+                u = int(row[e])
+                if u not in have:
+                    new.add(u)
+        if not new:
+            break
+        f_off = len(nodes)
+        frontier = sorted(new)
+        nodes.extend(frontier)
+        have.update(frontier)
+    pos = {}
+    for i, v in enumerate(nodes):
+        pos.setdefault(v, i)
+    rows = [pos[int(row[e])] for e in edges]
+    return (np.array(cols, np.int64), np.array(rows, np.int64), np.array(nodes, np.int64), np.array(edges, np.int64))

@@ -1573,3 +1573,140 @@ def check_block_sampler(eng, dev, oracle):
     assert out.shape == (blocks[1].n_dst_cap, 4) and bool(torch.isfinite(out).all())
     out[: len(sd)].sum().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+# --------------------------------------------------------------------------------------------------
+# the dgNN boundary (row G's call site)
+# the one statement through which GammaGL's fused GAT layer binds its kernel (layers/conv/fusedgat_conv.py:70-71)
+DGNN_BINDING = "from dgNN.operators import GATConvFuse\nop = GATConvFuse\n"
+
+
+def dgnn_standin(tmp_path):
+    """A stand-in module holding exactly the layer's import, with gammagl_amd/compat/dgNN reachable as `dgNN` (a
+    symlink in a scratch directory on sys.path: what INTEGRATION.md tells a maintainer to do).  No reference file is
+    copied."""
+    import importlib
+    import os
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = tmp_path / "dgnn_site"
+    root.mkdir(exist_ok=True)
+    link = root / "dgNN"
+    if not link.exists():
+        os.symlink(os.path.join(repo, "gammagl_amd", "compat", "dgNN"), link)
+    (root / "fused_layer_standin.py").write_text(DGNN_BINDING)
+    sys.path.insert(0, str(root))
+    try:
+        for m in ("dgNN", "dgNN.operators", "fused_layer_standin"):
+            sys.modules.pop(m, None)
+        return importlib.import_module("fused_layer_standin")
+    finally:
+        sys.path.pop(0)
+
+
+def check_dgnn_dropin(dev, oracle, tmp_path):
+    """`GATConvFuse(alpha_dst, alpha_src, row_ptr, col_ind, col_ptr, row_ind, permute, slope, x, 0)` called exactly as
+    fusedgat_conv.py:102-121 does — CSR built on edge_index[0] with the layer's own preprocessing steps restated in
+    torch — equals the in-tree GATConv math (gat_conv.py:103-112 + softmax.py:29-35, the oracle) on the graph whose
+    destinations are edge_index[0]: forward 1e-5, the three gradients 1e-4 (the GAT tolerances of this suite)."""
+    mod = dgnn_standin(tmp_path)
+    rng = np.random.default_rng(23)
+    for N, E, H, C in ((40, 300, 4, 8), (64, 900, 8, 8), (30, 200, 2, 5), (50, 400, 8, 41)):
+        ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
+        ei[0, : E // 5] = 3                                   # a hub row
+        x = rng.standard_normal((N, H, C)).astype(np.float32)
+        a_dst = rng.standard_normal((N, H)).astype(np.float32)
+        a_src = rng.standard_normal((N, H)).astype(np.float32)
+        go = rng.standard_normal((N, H, C)).astype(np.float32)
+        # fusedgat_conv.py:106-117: sort by row, CSR pointer, then sort by column carrying the position -> CSC + permute
+        eit = torch.from_numpy(ei)
+        o = torch.argsort(eit[0] * N + eit[1], stable=True)
+        er_sorted = eit[:, o]
+        row_ptr = torch.zeros(N + 1, dtype=torch.int64)
+        row_ptr[1:] = torch.cumsum(torch.bincount(er_sorted[0], minlength=N), 0)
+        col_ind = er_sorted[1]
+        permute = torch.arange(E)
+        o2 = torch.argsort(er_sorted[1] * N + er_sorted[0], stable=True)
+        ec_sorted, permute = er_sorted[:, o2], permute[o2]
+        row_ind = ec_sorted[0]
+        col_ptr = torch.zeros(N + 1, dtype=torch.int64)
+        col_ptr[1:] = torch.cumsum(torch.bincount(ec_sorted[1], minlength=N), 0)
+        i32 = lambda t: t.to(torch.int32).to(dev)             # noqa: E731  (tlx.convert_to_tensor(.., tlx.int32), :113-117)
+        xt, ad, as_ = (to_t(v, dev).requires_grad_(True) for v in (x, a_dst, a_src))
+        out = mod.op(ad, as_, i32(row_ptr), i32(col_ind), i32(col_ptr), i32(row_ind), i32(permute), 0.2, xt, 0.0)
+        out.backward(to_t(go, dev))
+        # oracle: edges j -> i with i = edge_index[0] (the aggregating row), j = edge_index[1]; el = the source's term
+        index = np.stack([ei[1], ei[0]])
+        want = oracle.gat_fwd(index, a_src, a_dst, x, 0.2)
+        gel, ger, gx = oracle.gat_bwd(index, a_src, a_dst, x, go, 0.2)
+        np.testing.assert_allclose(to_np(out), want, rtol=1e-5, atol=1e-5, err_msg=f"GATConvFuse forward {H}x{C}")
+        np.testing.assert_allclose(to_np(xt.grad), gx, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(to_np(as_.grad), gel, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(to_np(ad.grad), ger, rtol=1e-4, atol=1e-4)
+        # a second call with the same five tensors hits the plan cache (identity + version of row_ptr)
+    # dropout: kept coefficients are rescaled, dropped ones are zero — the op applies attn_drop as passed
+    N, E, H, C = 32, 256, 2, 4
+    ei = torch.from_numpy(rng.integers(0, N, size=(2, E)).astype(np.int64))
+    o = torch.argsort(ei[0] * N + ei[1], stable=True)
+    e1 = ei[:, o]
+    rp = torch.zeros(N + 1, dtype=torch.int64); rp[1:] = torch.cumsum(torch.bincount(e1[0], minlength=N), 0)
+    o2 = torch.argsort(e1[1] * N + e1[0], stable=True)
+    e2 = e1[:, o2]
+    cp = torch.zeros(N + 1, dtype=torch.int64); cp[1:] = torch.cumsum(torch.bincount(e2[1], minlength=N), 0)
+    args = [t.to(torch.int32).to(dev) for t in (rp, e1[1], cp, e2[0], torch.arange(E)[o2])]
+    z = torch.zeros(N, H, device=dev)
+    ones = torch.ones(N, H, C, device=dev)
+    y0 = mod.op(z, z, *args, 0.2, ones, 0.0)
+    has = (rp[1:] > rp[:-1]).to(dev)
+    assert float((y0[has] - 1).abs().max()) < 1e-5            # softmax weights sum to one
+    y5 = mod.op(z, z, *args, 0.2, ones, 0.5)
+    assert not torch.allclose(y5, y0) and bool(torch.isfinite(y5).all())
+
+
+def check_neighbor_sample(fn, dev, oracle):
+    """`cuda_torch_neighbor_sample(colptr, row, input_nodes, fanouts, replace, directed, seed)` (neighbor_sample.cu:744-778):
+    with fan-out -1 every array equals the Python restatement of cu_neighbor_sample (oracle.neighbor_sample_full: node
+    order, edge order, local positions); with positive fan-outs the contract of every hop: min(degree, fan-out) DISTINCT
+    in-edges of each frontier node, new nodes appended in ascending order, local positions consistent."""
+    rng = np.random.default_rng(31)
+    for N, E, seeds, hops in ((30, 200, [3, 7, 11], 2), (200, 3000, list(range(0, 40, 3)), 3), (50, 60, [49, 0], 4), (10, 0, [1, 2], 2)):
+        src = rng.integers(0, N, size=E)
+        dst = np.sort(rng.integers(0, N, size=E))
+        colptr = np.zeros(N + 1, np.int64)
+        np.add.at(colptr, dst + 1, 1)
+        colptr = np.cumsum(colptr)
+        row = src.astype(np.int64)
+        cp, rw, sd = to_t(colptr, dev), to_t(row, dev), to_t(np.array(seeds, np.int64), dev)
+        got = fn(cp, rw, sd, torch.tensor([-1] * hops), False, False, 0)
+        want = oracle.neighbor_sample_full(colptr, row, seeds, hops)
+        assert isinstance(got, list) and len(got) == 4
+        for g, w, nm in zip(got, want, ("cols", "rows", "nodes", "edges")):
+            assert g.dtype == torch.int64
+            np.testing.assert_array_equal(to_np(g), w, err_msg=f"neighbor_sample -1: {nm} (N={N})")
+        # positive fan-outs: the hop contract
+        fan = [3, 2, 2, 2][:hops]
+        cols, rows, nodes, edges = (to_np(t) for t in fn(cp, rw, sd, torch.tensor(fan), False, False, 0))
+        assert nodes[: len(seeds)].tolist() == seeds and len(set(nodes.tolist())) == len(nodes)
+        assert len(cols) == len(rows) == len(edges)
+        if len(edges):
+            assert np.array_equal(nodes[rows], row[edges]), "far end of every edge sits at its local position"
+            owner = nodes[cols]
+            assert np.all((colptr[owner] <= edges) & (edges < colptr[owner + 1])), "every edge belongs to its owner's stretch"
+        # per owner: min(deg, fanout of the hop it was sampled in) distinct edges; owners appear hop by hop
+        at, f_lo, f_hi = 0, 0, len(seeds)
+        for f in fan:
+            exp = np.minimum(colptr[nodes[f_lo:f_hi] + 1] - colptr[nodes[f_lo:f_hi]], f)
+            n_e = int(exp.sum())
+            hop_cols, hop_edges = cols[at:at + n_e], edges[at:at + n_e]
+            assert np.array_equal(hop_cols, np.repeat(np.arange(f_lo, f_hi), exp)), "edges of a hop: frontier node by node"
+            for k in range(f_lo, f_hi):
+                mine = hop_edges[hop_cols == k]
+                assert len(set(mine.tolist())) == len(mine), "distinct in-edges"
+            at += n_e
+            new = np.setdiff1d(np.unique(row[hop_edges]), nodes[:f_hi])
+            if len(new) == 0:
+                break
+            assert np.array_equal(nodes[f_hi:f_hi + len(new)], new), "new nodes ascending"
+            f_lo, f_hi = f_hi, f_hi + len(new)
+        assert at == len(edges)

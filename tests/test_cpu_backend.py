@@ -153,6 +153,16 @@ def test_zero_edit_binding_of_the_sparse_ops(tmp_path, golden):
         out = m.cuda_torch_sample_adj(rowptr, col, seeds, torch.tensor([int(gs[k + "_fanout"])]), False, False, 0)
         assert isinstance(out, list) and len(out) == 4
         pc.compare_block_with_reference([t.numpy() for t in out], gs, k, f"sampler case {ci}")
-    rowptr, col = torch.tensor([0, 2, 3, 6, 6]), torch.tensor([1, 2, 0, 0, 1, 3])
-    with pytest.raises(NotImplementedError):
-        m.cuda_torch_neighbor_sample(rowptr, col, torch.tensor([0]), torch.tensor([2, 2]), False, False, 0)
+    # the multi-hop sampler (neighbor_sample.cu:744-778): node / edge order of the fan-out -1 branch vs its restatement,
+    # the hop contract for positive fan-outs
+    from oracle import oracle as orc
+
+    pc.check_neighbor_sample(m.cuda_torch_neighbor_sample, torch.device("cpu"), orc)
+
+
+def test_dgnn_dropin_for_the_fused_gat_layer(tmp_path, oracle):
+    """gammagl_amd/compat/dgNN: `from dgNN.operators import GATConvFuse` (fusedgat_conv.py:70-71) binds the fused
+    kernels with zero edits; called the way the layer calls it, CPU tensors -> the host build."""
+    import parity_cases as pc
+
+    pc.check_dgnn_dropin(torch.device("cpu"), oracle, tmp_path)

@@ -976,3 +976,16 @@ def test_partitioned_trainer_step_captures_into_a_hipgraph(eng, dev):
         assert all(v == v for v in seq) and seq[-1] < 0.7 * seq[0]
         assert len(set(seq)) > 30                                    # fresh masks: no two replays repeat
     assert abs(losses["graph"][-1] - losses["eager"][-1]) < 0.25 * losses["eager"][0]
+
+
+def test_dgnn_dropin_for_the_fused_gat_layer(eng, dev, oracle, tmp_path):
+    """The zero-edit drop-in for `from dgNN.operators import GATConvFuse` (fusedgat_conv.py:70-71) on the MI355X:
+    the layer's own call, against the in-tree GATConv math on the CSR's direction."""
+    pc.check_dgnn_dropin(dev, oracle, tmp_path)
+
+
+def test_multi_hop_neighbor_sample(eng, dev, oracle):
+    """cuda_torch_neighbor_sample (ops/sparse/cuda/neighbor_sample.cu:744-778) through the zero-edit module, on the GPU."""
+    from gammagl_amd.compat import _sparse_cuda
+
+    pc.check_neighbor_sample(_sparse_cuda.cuda_torch_neighbor_sample, dev, oracle)
