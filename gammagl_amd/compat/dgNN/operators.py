@@ -32,7 +32,12 @@ stand-in package holding exactly the layer's import), tests/test_gpu_parity.py (
 """
 import torch
 
+from gammagl_amd import cpp_ops as _cpp_ops
 from gammagl_amd import engine as _engine
+
+# dispatcher -> C++ -> C ABI -> kernel (torch.ops.ggl.gat_fused_csr, csrc/torch/ggl_torch.cpp) when libggl_torch.so is
+# built; else the ctypes engine over the same kernels (bit-identical, tests/test_torch_cpp.py)
+_cpp = _cpp_ops.load() if _cpp_ops.enabled() else None
 
 __all__ = ["GATConvFuse"]
 
@@ -43,6 +48,9 @@ def GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute,
     ``permute`` [E] int32 or int64.  Returns [N, H, C]."""
     if not (isinstance(in_feat, torch.Tensor) and in_feat.dim() == 3):
         raise RuntimeError("GATConvFuse: in_feat must be [num_nodes, heads, channels]")
+    if _cpp is not None:
+        return _cpp.gat_fused_csr(row_ptr, col_ind, col_ptr, row_ind, permute, attn_col, attn_row, in_feat,
+                                  float(negative_slope), float(attn_drop))
     eng = _engine(in_feat)
     n_rows, n_cols = int(row_ptr.shape[0]) - 1, int(col_ptr.shape[0]) - 1
     if attn_row.shape[0] != n_rows or attn_col.shape[0] != n_cols or in_feat.shape[0] != n_cols:

@@ -32,6 +32,7 @@
 #include <torch/library.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -54,7 +55,11 @@ using torch::autograd::variable_list;
   X(ggl_segment_sum) X(ggl_segment_mean) X(ggl_segment_max) X(ggl_segment_hub16_supported) X(ggl_segment_hub16)      \
   X(ggl_segment_sum_bwd) X(ggl_segment_mean_bwd) X(ggl_segment_max_bwd) X(ggl_spmm_sum) X(ggl_spmm_mean)             \
   X(ggl_spmm_max) X(ggl_spmm_mean_bwd) X(ggl_spmm_max_bwd) X(ggl_bspmm_sum) X(ggl_bspmm_grad_w)                      \
-  X(ggl_bspmm_grad_w_sorted_scratch_bytes) X(ggl_bspmm_grad_w_sorted)
+  X(ggl_bspmm_grad_w_sorted_scratch_bytes) X(ggl_bspmm_grad_w_sorted)                                                \
+  X(ggl_gat_partial_bytes) X(ggl_gat_fused_fwd) X(ggl_gat_fused_bwd_dst) X(ggl_gat_fused_bwd_src)                      \
+  X(ggl_gat_fast_supported) X(ggl_gat_fast_fwd) X(ggl_gat_fast_bwd) X(ggl_bias_act_fwd)                                \
+  X(ggl_bias_act_bwd_workspace_bytes) X(ggl_bias_act_bwd) X(ggl_spmm_epi_ex) X(ggl_segment_epi)                        \
+  X(ggl_sample_hop_workspace_bytes) X(ggl_sample_hop)
 
 struct Api {
   void *handle = nullptr;
@@ -384,6 +389,19 @@ struct GraphPlan {
     if (rowidx.defined()) return;
     rowidx = gather_i32(api_for(index.device()), index.select(0, 1), fwd->perm);
   }
+  // transposed sorted position -> forward sorted position (int32 [E]; ops.py GraphPlan.posT)
+  Tensor posT;
+  void need_posT(const Tensor &index) {
+    need_bwd(index);
+    std::lock_guard<std::mutex> g(mu);
+    if (posT.defined()) return;
+    auto i32 = fwd->rowptr.options().dtype(at::kInt);
+    Tensor ar = at::arange(E, i32);
+    Tensor pf = fwd->perm.defined() ? fwd->perm : ar, pt = bwd->perm.defined() ? bwd->perm : ar;
+    Tensor inv = at::empty({E}, i32);
+    inv.index_put_({pf.to(at::kLong)}, ar);
+    posT = inv.index_select(0, pt.to(at::kLong)).contiguous();
+  }
 };
 
 static Cache<GraphPlan> &graph_cache() {
@@ -566,6 +584,7 @@ static void f32(const char *name, const Tensor &t) {
   TORCH_CHECK(t.scalar_type() == at::kFloat, "expected scalar type Float but found ", t.scalar_type(), " (", name, ")");
 }
 
+using OptT_ = c10::optional<Tensor>;
 static Tensor opt(const c10::optional<Tensor> &t) { return t.has_value() ? *t : Tensor(); }
 // the kernels read weight.data_ptr() as E dense floats (spmm_sum_cpu.cpp:48-50 makes it contiguous in backward too)
 static Tensor opt_dense(const c10::optional<Tensor> &t) { return t.has_value() && t->defined() ? t->contiguous() : Tensor(); }
@@ -755,6 +774,380 @@ static std::tuple<Tensor, Tensor> bspmm_sum_backward_kernel(const Tensor &index,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The fused route: edge-softmax + aggregate, the layer epilogue in the aggregate's
+// store, one static-shape sampler hop — registered like the seven operators above: forward and backward passes are
+// dispatcher ops of their own, the autograd formulas only call ops.  (Until round 4 these existed as Python-registered
+// ops only, gammagl_amd/torch_ops.py: 20-30 us of Python + ctypes per call.)
+// ---------------------------------------------------------------------------------------------------------------
+// device-resident {seed, offset} of the fused dropouts, seeded from torch's CPU generator on first use (follows
+// torch.manual_seed, like ops.py Engine._rng_state); ggl::reseed() forgets it
+static std::mutex g_rng_mu;
+static std::vector<std::pair<c10::Device, Tensor>> g_rng;
+static Tensor rng_state(const c10::Device &d) {
+  std::lock_guard<std::mutex> g(g_rng_mu);
+  for (auto &e : g_rng)
+    if (e.first == d) return e.second;
+  const int64_t seed = at::randint(0, int64_t(1) << 62, {1}, at::TensorOptions().dtype(at::kLong)).item<int64_t>();
+  Tensor st = at::tensor({seed, int64_t(0)}, at::TensorOptions().dtype(at::kLong)).to(d);
+  g_rng.emplace_back(d, st);
+  return st;
+}
+static void reseed() {
+  std::lock_guard<std::mutex> g(g_rng_mu);
+  g_rng.clear();
+}
+
+static bool gat_pads(const GraphPlan &gp, const Tensor &x) {   // 41 classes per head -> 44: 16-byte slices in every walk
+  const int64_t C = x.size(2);
+  return C % 4 != 0 && C >= 8 && gp.E >= 8 * x.size(0);
+}
+static void gat_check(const Tensor &el, const Tensor &er, const Tensor &x) {
+  same_device({&el, &er, &x});
+  f32("el", el); f32("er", er); f32("x", x);
+  TORCH_CHECK(x.dim() == 3 && el.dim() == 2 && er.dim() == 2 && el.size(1) == x.size(1) && er.size(1) == x.size(1) &&
+              el.size(0) == x.size(0), "gat_fused expects el [N_src, H], er [N_dst, H], x [N_src, H, C]");
+}
+
+// (out, rowmax, rowden, rng_used, fast): one launch (+ the hub-chunk combine inside the library)
+static std::tuple<Tensor, Tensor, Tensor, Tensor, bool> gat_forward(GraphPlan &gp, const Tensor &el_, const Tensor &er_,
+                                                                    const Tensor &x_, double slope, double p) {
+  const auto dev = x_.device();
+  const Api &a = api_for(dev);
+  Tensor el = el_.contiguous(), er = er_.contiguous(), x = x_.contiguous();
+  TORCH_CHECK(er.size(0) == gp.N_dst && x.size(0) == gp.N_src, "gat_fused: er has ", er.size(0), " rows for ", gp.N_dst,
+              " destinations, x ", x.size(0), " for ", gp.N_src, " sources");
+  const int64_t N = gp.N_dst, H = x.size(1), C = x.size(2);
+  Tensor out = at::empty({N, H, C}, x.options()), rmax = at::empty({N, H}, x.options()), rden = at::empty({N, H}, x.options());
+  Tensor part;
+  if (gp.fwd->n_long > 0)
+    part = at::empty({static_cast<int64_t>(a.ggl_gat_partial_bytes(gp.fwd->n_chunks, H, C)) + 16}, x.options().dtype(at::kByte));
+  ggl_segplan_t cs = gp.fwd->c(part);
+  Tensor rng, rng_used;
+  if (p > 0) {
+    rng = rng_state(dev);
+    rng_used = rng.clone();   // the {seed, offset} this launch reads; the backward redraws the mask
+  }
+  static const bool want_fast = env_int("GGL_GAT_FAST", 1) != 0;
+  const bool fast = want_fast && a.ggl_gat_fast_supported(H, C) != 0;
+  void *st = stream_of(dev);
+  int64_t *rp = rng.defined() ? rng.data_ptr<int64_t>() : nullptr;
+  if (fast)
+    check(a, a.ggl_gat_fast_fwd(&cs, gp.col.data_ptr<int32_t>(), el.data_ptr<float>(), er.data_ptr<float>(),
+                                x.data_ptr<float>(), x.size(0), static_cast<float>(slope), H, C, static_cast<float>(p), rp,
+                                out.data_ptr<float>(), rmax.data_ptr<float>(), rden.data_ptr<float>(), st));
+  else
+    check(a, a.ggl_gat_fused_fwd(&cs, gp.col.data_ptr<int32_t>(), el.data_ptr<float>(), er.data_ptr<float>(),
+                                 x.data_ptr<float>(), static_cast<float>(slope), H, C, static_cast<float>(p), rp,
+                                 out.data_ptr<float>(), rmax.data_ptr<float>(), rden.data_ptr<float>(), st));
+  return {out, rmax, rden, rng_used.defined() ? rng_used : at::empty({0}, x.options().dtype(at::kLong)), fast};
+}
+
+// (gel, ger, gx): the destination walk and the source walk
+static std::tuple<Tensor, Tensor, Tensor> gat_backward(GraphPlan &gp, const Tensor &colT, const Tensor &posT,
+                                                       const Tensor &el, const Tensor &er, const Tensor &x, const Tensor &g_,
+                                                       const Tensor &out, const Tensor &rmax, const Tensor &rden,
+                                                       const Tensor &rng_used, double slope, double p, bool fast) {
+  const auto dev = x.device();
+  const Api &a = api_for(dev);
+  Tensor g = g_.contiguous();
+  const int64_t H = x.size(1), C = x.size(2);
+  void *st = stream_of(dev);
+  const SegPlan &fw = *gp.fwd, &bw = *gp.bwd;
+  Tensor ger = at::empty_like(er), gx = at::empty({gp.N_src, H, C}, x.options()), gel = at::empty({gp.N_src, H}, x.options());
+  Tensor part_f = partial_for(a, fw, x, H, false), part_t = partial_for(a, bw, x, H * C + H, false);
+  ggl_segplan_t cs = fw.c(part_f), csT = bw.c(part_t);
+  const int64_t *ru = (p > 0 && rng_used.numel() == 2) ? rng_used.data_ptr<int64_t>() : nullptr;
+  if (fast) {
+    Tensor stats = at::empty({gp.N_dst, H, 4}, x.options());
+    check(a, a.ggl_gat_fast_bwd(&cs, gp.col.data_ptr<int32_t>(), &csT, colT.data_ptr<int32_t>(),
+                                p > 0 ? posT.data_ptr<int32_t>() : nullptr, el.data_ptr<float>(), er.data_ptr<float>(),
+                                x.data_ptr<float>(), g.data_ptr<float>(), out.data_ptr<float>(), rmax.data_ptr<float>(),
+                                rden.data_ptr<float>(), static_cast<float>(slope), H, C, static_cast<float>(p), ru,
+                                stats.data_ptr<float>(), gx.data_ptr<float>(), gel.data_ptr<float>(), ger.data_ptr<float>(), st));
+    return {gel, ger, gx};
+  }
+  // alpha and de interleaved [E, H, 2]: the source-side walk fetches both with one 64-byte line
+  Tensor ad = at::empty({std::max<int64_t>(gp.E, 1), H, 2}, x.options());
+  float *alpha = ad.data_ptr<float>(), *de = alpha + 1;
+  check(a, a.ggl_gat_fused_bwd_dst(&cs, gp.col.data_ptr<int32_t>(), nullptr, el.data_ptr<float>(), er.data_ptr<float>(),
+                                   x.data_ptr<float>(), g.data_ptr<float>(), out.data_ptr<float>(), rmax.data_ptr<float>(),
+                                   rden.data_ptr<float>(), static_cast<float>(slope), H, C, static_cast<float>(p), ru, alpha,
+                                   de, ger.data_ptr<float>(), nullptr, st));
+  check(a, a.ggl_gat_fused_bwd_src(&csT, colT.data_ptr<int32_t>(), posT.data_ptr<int32_t>(), alpha, de, g.data_ptr<float>(),
+                                   H, C, gx.data_ptr<float>(), gel.data_ptr<float>(), st));
+  return {gel, ger, gx};
+}
+
+static std::shared_ptr<GraphPlan> gat_plan(const Tensor &index, int64_t n_dst, int64_t n_src) {
+  TORCH_CHECK(index.scalar_type() == at::kLong, "expected scalar type Long but found ", index.scalar_type());
+  return graph_plan(index.contiguous(), n_dst, n_src);
+}
+
+// out[i, h, :] = sum_{j -> i} dropout(softmax_i(LeakyReLU(el[j, h] + er[i, h]))) x[j, h, :]   (gat_conv.py:103-112)
+static std::tuple<Tensor, Tensor, Tensor, Tensor, bool> gat_fused_forward_kernel(const Tensor &index, const Tensor &el,
+                                                                                const Tensor &er, const Tensor &x,
+                                                                                double slope, int64_t num_nodes, double p) {
+  gat_check(el, er, x);
+  TORCH_CHECK(p >= 0.0 && p < 1.0, "dropout_rate must be in [0, 1)");
+  c10::OptionalDeviceGuard guard(x.device());
+  auto gp = gat_plan(index, num_nodes, x.size(0));
+  return gat_forward(*gp, el, er, x, slope, p);
+}
+static std::tuple<Tensor, Tensor, Tensor> gat_fused_backward_kernel(const Tensor &index, const Tensor &el, const Tensor &er,
+                                                                    const Tensor &x, const Tensor &grad, const Tensor &out,
+                                                                    const Tensor &rmax, const Tensor &rden,
+                                                                    const Tensor &rng_used, double slope, int64_t num_nodes,
+                                                                    double p, bool fast) {
+  c10::OptionalDeviceGuard guard(x.device());
+  Tensor idx = index.contiguous();
+  auto gp = gat_plan(idx, num_nodes, x.size(0));
+  gp->need_bwd(idx);
+  if (p > 0 || !fast) gp->need_posT(idx);
+  return gat_backward(*gp, gp->colT, gp->posT, el.contiguous(), er.contiguous(), x.contiguous(), grad, out, rmax, rden,
+                      rng_used, slope, p, fast);
+}
+
+// The same op over a CSR the caller already holds — the argument list of dgNN's GATConvFuse
+// (layers/conv/fusedgat_conv.py:121): rows of the CSR aggregate, no sort.  The plan is cached on row_ptr.
+struct CsrExtra {   // what besides row_ptr identifies the five-tensor structure
+  const void *p[4];
+  int64_t v[4];
+  bool operator==(const CsrExtra &o) const { return std::memcmp(this, &o, sizeof(CsrExtra)) == 0; }
+};
+static Cache<GraphPlan> &csr_cache() {
+  static Cache<GraphPlan> c(8);
+  return c;
+}
+static std::mutex g_csr_mu;
+static std::list<std::pair<std::weak_ptr<GraphPlan>, CsrExtra>> g_csr_extra;
+
+static Tensor own_i32(const Tensor &t) { return t.scalar_type() == at::kInt ? t.clone().contiguous() : t.to(at::kInt).contiguous(); }
+static std::shared_ptr<SegPlan> plan_from_rowptr(const Tensor &rowptr, int64_t E) {
+  const Api &a = api_for(rowptr.device());
+  auto p = std::make_shared<SegPlan>();
+  p->N = rowptr.size(0) - 1;
+  p->E = E;
+  p->chunk = auto_chunk(E);
+  p->rowptr = rowptr.to(at::kLong).contiguous();
+  if (p->rowptr.data_ptr() == rowptr.data_ptr()) p->rowptr = p->rowptr.clone();   // the plan keeps its OWN copy
+  p->sorted = true;
+  p->max_len = p->N > 0 ? p->counts().max().item<int64_t>() : 0;
+  fill_long_rows(a, *p, stream_of(rowptr.device()));
+  p->uid = ++g_plans_built;
+  return p;
+}
+static std::shared_ptr<GraphPlan> csr_plan(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &col_ptr,
+                                           const Tensor &row_ind, const Tensor &permute) {
+  same_device({&row_ptr, &col_ind, &col_ptr, &row_ind, &permute});
+  const int64_t n_rows = row_ptr.size(0) - 1, n_cols = col_ptr.size(0) - 1, E = col_ind.size(0);
+  for (const Tensor *t : {&row_ptr, &col_ind, &col_ptr, &row_ind, &permute})
+    TORCH_CHECK(t->dim() == 1 && (t->scalar_type() == at::kInt || t->scalar_type() == at::kLong),
+                "GATConvFuse: the CSR / CSC tensors must be 1-D int32 / int64");
+  TORCH_CHECK(row_ind.size(0) == E && permute.size(0) == E, "GATConvFuse: col_ind, row_ind and permute must have one entry per edge");
+  TensorKey k = TensorKey::of(row_ptr, n_rows, n_cols);
+  CsrExtra ex{};
+  const Tensor *others[4] = {&col_ind, &col_ptr, &row_ind, &permute};
+  for (int i = 0; i < 4; ++i) {
+    ex.p[i] = others[i]->data_ptr();
+    ex.v[i] = static_cast<int64_t>(others[i]->_version());
+  }
+  if (auto hit = csr_cache().get(k)) {
+    std::lock_guard<std::mutex> g(g_csr_mu);
+    for (auto &e : g_csr_extra)
+      if (e.first.lock() == hit && e.second == ex) return hit;
+  }
+  check_range(col_ind, n_cols);
+  check_range(row_ind, n_rows);
+  check_range(permute, std::max<int64_t>(E, 1));
+  for (const Tensor *ptr : {&row_ptr, &col_ptr}) {   // one-off (per plan) host reads
+    Tensor p64 = ptr->to(at::kLong);
+    TORCH_CHECK(p64[0].item<int64_t>() == 0 && p64[-1].item<int64_t>() == E &&
+                    (p64.size(0) < 2 || !(p64.slice(0, 1) < p64.slice(0, 0, p64.size(0) - 1)).any().item<bool>()),
+                "GATConvFuse: a row pointer must rise from 0 to the number of edges (", E, ")");
+  }
+  auto gp = std::make_shared<GraphPlan>();
+  gp->N_dst = n_rows;
+  gp->N_src = n_cols;
+  gp->E = E;
+  gp->fwd = plan_from_rowptr(row_ptr, E);
+  gp->col = own_i32(col_ind);
+  gp->bwd = plan_from_rowptr(col_ptr, E);
+  gp->colT = own_i32(row_ind);
+  gp->posT = own_i32(permute);
+  gp->schedule();
+  csr_cache().put(row_ptr, k, gp);
+  {
+    std::lock_guard<std::mutex> g(g_csr_mu);
+    g_csr_extra.remove_if([](const std::pair<std::weak_ptr<GraphPlan>, CsrExtra> &e) { return e.first.expired(); });
+    g_csr_extra.emplace_back(gp, ex);
+  }
+  return gp;
+}
+static std::tuple<Tensor, Tensor, Tensor, Tensor, bool> gat_csr_forward_kernel(const Tensor &row_ptr, const Tensor &col_ind,
+                                                                              const Tensor &col_ptr, const Tensor &row_ind,
+                                                                              const Tensor &permute, const Tensor &el,
+                                                                              const Tensor &er, const Tensor &x, double slope,
+                                                                              double p) {
+  gat_check(el, er, x);
+  TORCH_CHECK(p >= 0.0 && p < 1.0, "dropout_rate must be in [0, 1)");
+  c10::OptionalDeviceGuard guard(x.device());
+  auto gp = csr_plan(row_ptr, col_ind, col_ptr, row_ind, permute);
+  return gat_forward(*gp, el, er, x, slope, p);
+}
+static std::tuple<Tensor, Tensor, Tensor> gat_csr_backward_kernel(const Tensor &row_ptr, const Tensor &col_ind,
+                                                                  const Tensor &col_ptr, const Tensor &row_ind,
+                                                                  const Tensor &permute, const Tensor &el, const Tensor &er,
+                                                                  const Tensor &x, const Tensor &grad, const Tensor &out,
+                                                                  const Tensor &rmax, const Tensor &rden,
+                                                                  const Tensor &rng_used, double slope, double p, bool fast) {
+  c10::OptionalDeviceGuard guard(x.device());
+  auto gp = csr_plan(row_ptr, col_ind, col_ptr, row_ind, permute);
+  return gat_backward(*gp, gp->colT, gp->posT, el.contiguous(), er.contiguous(), x.contiguous(), grad, out, rmax, rden,
+                      rng_used, slope, p, fast);
+}
+
+// y = dropout(relu(a + bias))                                                      (gcn_conv.py:105-106, models/gcn.py:55-59)
+static std::tuple<Tensor, Tensor> bias_act_forward_kernel(const Tensor &a_, const OptT_ &bias, bool relu, double p) {
+  Tensor a = a_.contiguous(), b = opt(bias);
+  same_device({&a, &b});
+  f32("a", a);
+  TORCH_CHECK(p >= 0.0 && p < 1.0, "p_drop must be in [0, 1)");
+  c10::OptionalDeviceGuard guard(a.device());
+  const Api &api = api_for(a.device());
+  const int64_t N = a.dim() > 0 ? a.size(0) : 1, K = N > 0 ? a.numel() / N : width_of(a.sizes());
+  if (b.defined()) {
+    f32("bias", b);
+    b = b.contiguous().reshape({-1});
+    TORCH_CHECK(b.numel() == K, "bias must hold one value per column");
+  }
+  Tensor y = at::empty_like(a), rng, used = at::empty({0}, a.options().dtype(at::kLong));
+  if (p > 0) {
+    rng = rng_state(a.device());
+    used = rng.clone();
+  }
+  check(api, api.ggl_bias_act_fwd(a.data_ptr<float>(), b.defined() ? b.data_ptr<float>() : nullptr, N, K, relu ? 1 : 0,
+                                  static_cast<float>(p), rng.defined() ? rng.data_ptr<int64_t>() : nullptr,
+                                  y.data_ptr<float>(), stream_of(a.device())));
+  return {y, used};
+}
+// (ga, gbias): the mask is rebuilt from y, the bias gradient reduced in the same pass (epilogue.hip)
+static std::tuple<Tensor, Tensor> bias_act_backward_kernel(const Tensor &g_, const Tensor &y, bool has_bias, bool relu, double p,
+                                                           const Tensor &rng_used) {
+  Tensor g = g_.contiguous();
+  c10::OptionalDeviceGuard guard(g.device());
+  const Api &api = api_for(g.device());
+  const int64_t N = g.dim() > 0 ? g.size(0) : 1, K = N > 0 ? g.numel() / N : width_of(g.sizes());
+  if (!relu && p <= 0 && !has_bias) return {g, Tensor()};
+  Tensor ga = at::empty_like(g), gb = has_bias ? at::empty({K}, g.options()) : Tensor();
+  const size_t wsb = api.ggl_bias_act_bwd_workspace_bytes(N, K);
+  Tensor ws = at::empty({static_cast<int64_t>(std::max<size_t>(wsb, 4))}, g.options().dtype(at::kByte));
+  check(api, api.ggl_bias_act_bwd(g.data_ptr<float>(), y.data_ptr<float>(), N, K, relu ? 1 : 0, static_cast<float>(p),
+                                  (p > 0 && rng_used.numel() == 2) ? rng_used.data_ptr<int64_t>() : nullptr,
+                                  ga.data_ptr<float>(), gb.defined() ? gb.data_ptr<float>() : nullptr, ws.data_ptr(), wsb,
+                                  stream_of(g.device())));
+  return {ga, gb.defined() ? gb : at::empty({0}, g.options())};
+}
+
+// y = dropout(relu(reduce_{j -> i} w x_j + add_i + bias)) in ONE kernel (reduce.hip MODE_SPMM_EPI): 2-D x, K % 4 == 0
+static std::tuple<Tensor, Tensor> spmm_epi_forward_kernel(const Tensor &index, const OptT_ &weight, const Tensor &x, bool mean,
+                                                          const OptT_ &add_, const OptT_ &bias_, bool relu, double p) {
+  c10::OptionalDeviceGuard guard(x.device());
+  SpArgs s = spmm_args(index, weight, x);
+  Tensor add = opt(add_), bias = opt(bias_);
+  same_device({&x, &add, &bias});
+  TORCH_CHECK(s.x.dim() == 2 && s.x.size(1) % 4 == 0, "spmm_epi_forward needs a 2-D x whose width is a multiple of 4");
+  TORCH_CHECK(p >= 0.0 && p < 1.0, "p_drop must be in [0, 1)");
+  const Api &a = api_for(x.device());
+  const int64_t K = s.x.size(1);
+  if (add.defined()) {
+    f32("add", add);
+    TORCH_CHECK(add.dim() == 2 && add.size(0) == s.gp->N_dst && add.size(1) == K, "add must be [destination rows, feature width]");
+    add = add.contiguous();
+  }
+  if (bias.defined()) {
+    f32("bias", bias);
+    bias = bias.contiguous().reshape({-1});
+    TORCH_CHECK(bias.numel() == K, "bias must hold one value per column");
+  }
+  const SegPlan &p_ = *s.gp->fwd;
+  Tensor y = at::empty({s.gp->N_dst, K}, s.x.options());
+  Tensor part = partial_for(a, p_, s.x, K, false);
+  ggl_segplan_t cs = p_.c(part);
+  Tensor keep, rng, used = at::empty({0}, s.x.options().dtype(at::kLong));
+  auto [wp, by_pos] = weights_for(a, *s.gp, p_, s.w, keep);
+  if (p > 0) {
+    rng = rng_state(x.device());
+    used = rng.clone();
+  }
+  check(a, a.ggl_spmm_epi_ex(&cs, s.gp->col.data_ptr<int32_t>(), wp, by_pos, s.x.data_ptr<float>(), K, K, y.data_ptr<float>(),
+                             K, 0, mean ? 1 : 0, add.defined() ? add.data_ptr<float>() : nullptr, add.defined() ? K : 0,
+                             bias.defined() ? bias.data_ptr<float>() : nullptr, relu ? 1 : 0, static_cast<float>(p),
+                             rng.defined() ? rng.data_ptr<int64_t>() : nullptr, 0, 0, 1, stream_of(x.device())));
+  return {y, used};
+}
+
+// relu(segment_{sum,mean}(x, ids, N) + add + bias) for f32 messages [E, K] in one kernel (sage_conv.py:100-108)
+static Tensor segment_epi_forward_kernel(const Tensor &x_, const Tensor &index, int64_t N, bool mean, const OptT_ &add_,
+                                         const OptT_ &bias_, bool relu) {
+  seg_args(x_, index);
+  Tensor x = x_.contiguous(), add = opt(add_), bias = opt(bias_);
+  same_device({&x, &add, &bias});
+  f32("msg", x);
+  TORCH_CHECK(x.dim() == 2, "segment_epi expects [E, K] messages");
+  c10::OptionalDeviceGuard guard(x.device());
+  const Api &a = api_for(x.device());
+  auto plan = seg_plan(index, N);
+  const int64_t K = x.size(1);
+  if (add.defined()) {
+    f32("add", add);
+    TORCH_CHECK(add.dim() == 2 && add.size(0) == N && add.size(1) == K, "add must be [num_segments, feature width]");
+    add = add.contiguous();
+  }
+  if (bias.defined()) {
+    f32("bias", bias);
+    bias = bias.contiguous().reshape({-1});
+    TORCH_CHECK(bias.numel() == K, "bias must hold one value per column");
+  }
+  Tensor y = at::empty({N, K}, x.options());
+  Tensor part = partial_for(a, *plan, x, K, false);
+  ggl_segplan_t cs = plan->c(part);
+  check(a, a.ggl_segment_epi(x.data_ptr<float>(), &cs, K, mean ? 1 : 0, add.defined() ? add.data_ptr<float>() : nullptr, 0,
+                             bias.defined() ? bias.data_ptr<float>() : nullptr, relu ? 1 : 0, 0.0f, nullptr,
+                             y.data_ptr<float>(), stream_of(x.device())));
+  return y;
+}
+
+// One sampled hop with fixed capacities and device-side sizes (sample.hip ggl_sample_hop; ops/sparse/cpu/sample.cpp:10-135):
+// nothing is read back, so a mini-batch step captures into one hipGraph.  Returns (rowptr [B_cap + 1], col [E_cap] int32
+// local ids, e_id [E_cap], n_id [S_cap], counts [3] = {nodes, edges, overflow}); first_pos is the caller's relabel scratch
+// (one int64 per graph node, all 2^62 on entry and on exit).
+static std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sample_hop_kernel(const Tensor &rowptr, const Tensor &col,
+                                                                            const Tensor &seeds, const Tensor &n_seeds,
+                                                                            int64_t num_nodes, int64_t fanout, int64_t e_cap,
+                                                                            int64_t s_cap, Tensor &first_pos) {
+  same_device({&rowptr, &col, &seeds, &n_seeds, &first_pos});
+  const Tensor *all5[5] = {&rowptr, &col, &seeds, &n_seeds, &first_pos};
+  for (const Tensor *t : all5)
+    TORCH_CHECK(t->scalar_type() == at::kLong && t->is_contiguous(), "sample_hop takes contiguous int64 tensors");
+  TORCH_CHECK(fanout > 0 && first_pos.numel() >= num_nodes && rowptr.numel() == num_nodes + 1, "bad sample_hop arguments");
+  c10::OptionalDeviceGuard guard(rowptr.device());
+  const Api &a = api_for(rowptr.device());
+  const int64_t b_cap = seeds.size(0);
+  auto i64 = rowptr.options();
+  Tensor out_rowptr = at::empty({b_cap + 1}, i64), out_col = at::empty({std::max<int64_t>(e_cap, 1)}, i64.dtype(at::kInt));
+  Tensor out_eid = at::empty({std::max<int64_t>(e_cap, 1)}, i64), out_nid = at::empty({s_cap}, i64), counts = at::empty({3}, i64);
+  const size_t wsb = a.ggl_sample_hop_workspace_bytes(b_cap, e_cap);
+  Tensor ws = at::empty({static_cast<int64_t>(wsb)}, i64.dtype(at::kByte));
+  Tensor rng = rng_state(rowptr.device());
+  check(a, a.ggl_sample_hop(rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(), seeds.data_ptr<int64_t>(),
+                            n_seeds.data_ptr<int64_t>(), b_cap, num_nodes, fanout, e_cap, s_cap, rng.data_ptr<int64_t>(),
+                            first_pos.data_ptr<int64_t>(), out_rowptr.data_ptr<int64_t>(), out_col.data_ptr<int32_t>(),
+                            out_eid.data_ptr<int64_t>(), out_nid.data_ptr<int64_t>(), counts.data_ptr<int64_t>(), ws.data_ptr(),
+                            wsb, stream_of(rowptr.device())));
+  return {out_rowptr, out_col, out_eid, out_nid, counts};
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Autograd: every formula re-dispatches (below the autograd key) to the ops above
 // ---------------------------------------------------------------------------------------------------------------
 template <typename Sig>
@@ -858,6 +1251,189 @@ static Tensor spmm_mean_autograd(const Tensor &i, const OptT &w, const Tensor &x
 static Tensor spmm_max_autograd(const Tensor &i, const OptT &w, const Tensor &x) { return SpMMFn<SpOp::Max>::apply(i, w, x); }
 static Tensor bspmm_sum_autograd(const Tensor &i, const Tensor &w, const Tensor &x) { return BSpMMFn::apply(i, w, x); }
 
+// ---- autograd of the fused route --------------------------------------------------------------------------------
+using GatFwdSig = std::tuple<Tensor, Tensor, Tensor, Tensor, bool>(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                                    double, int64_t, double);
+using GatBwdSig = std::tuple<Tensor, Tensor, Tensor>(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                     const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                     const Tensor &, double, int64_t, double, bool);
+struct GatFn : public torch::autograd::Function<GatFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &index, const Tensor &el, const Tensor &er, const Tensor &x,
+                        double slope, int64_t n, double p) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = op_handle<GatFwdSig>("ggl::gat_fused_forward");
+    auto r = op.call(index, el, er, x, slope, n, p);
+    ctx->save_for_backward({index, el, er, x, std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r)});
+    ctx->saved_data["slope"] = slope;
+    ctx->saved_data["n"] = n;
+    ctx->saved_data["p"] = p;
+    ctx->saved_data["fast"] = std::get<4>(r);
+    return std::get<0>(r);
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    static auto op = op_handle<GatBwdSig>("ggl::gat_fused_backward");
+    auto r = op.call(s[0], s[1], s[2], s[3], grads[0], s[4], s[5], s[6], s[7], ctx->saved_data["slope"].toDouble(),
+                     ctx->saved_data["n"].toInt(), ctx->saved_data["p"].toDouble(), ctx->saved_data["fast"].toBool());
+    return {Tensor(), std::get<0>(r), std::get<1>(r), std::get<2>(r), Tensor(), Tensor(), Tensor()};
+  }
+};
+static Tensor gat_fused_autograd(const Tensor &index, const Tensor &el, const Tensor &er, const Tensor &x, double slope,
+                                 c10::optional<int64_t> num_nodes, double p) {
+  gat_check(el, er, x);
+  const int64_t n = num_nodes.has_value() ? *num_nodes : x.size(0), C = x.size(2);
+  // 41 classes per head: one zero-padded copy keeps every walk on 16-byte slices (ops.py Engine.gat_fused); the pad
+  // channels aggregate to zero and are dropped — pad and slice are ordinary differentiable ops
+  if (C % 4 != 0 && C >= 8 && index.dim() == 2 && index.size(1) >= 8 * x.size(0)) {
+    Tensor xp = at::constant_pad_nd(x, {0, (4 - C % 4) % 4});
+    return GatFn::apply(index, el, er, xp, slope, n, p).slice(2, 0, C);
+  }
+  return GatFn::apply(index, el, er, x, slope, n, p);
+}
+
+using GatCsrFwdSig = std::tuple<Tensor, Tensor, Tensor, Tensor, bool>(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                                       const Tensor &, const Tensor &, const Tensor &,
+                                                                       const Tensor &, double, double);
+using GatCsrBwdSig = std::tuple<Tensor, Tensor, Tensor>(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                        const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                        const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                        const Tensor &, double, double, bool);
+struct GatCsrFn : public torch::autograd::Function<GatCsrFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &rp, const Tensor &ci, const Tensor &cp, const Tensor &ri,
+                        const Tensor &pm, const Tensor &el, const Tensor &er, const Tensor &x, double slope, double p) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = op_handle<GatCsrFwdSig>("ggl::gat_fused_csr_forward");
+    auto r = op.call(rp, ci, cp, ri, pm, el, er, x, slope, p);
+    ctx->save_for_backward({rp, ci, cp, ri, pm, el, er, x, std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r)});
+    ctx->saved_data["slope"] = slope;
+    ctx->saved_data["p"] = p;
+    ctx->saved_data["fast"] = std::get<4>(r);
+    return std::get<0>(r);
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    static auto op = op_handle<GatCsrBwdSig>("ggl::gat_fused_csr_backward");
+    auto r = op.call(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], grads[0], s[8], s[9], s[10], s[11],
+                     ctx->saved_data["slope"].toDouble(), ctx->saved_data["p"].toDouble(), ctx->saved_data["fast"].toBool());
+    return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), std::get<0>(r), std::get<1>(r), std::get<2>(r), Tensor(), Tensor()};
+  }
+};
+static Tensor gat_fused_csr_autograd(const Tensor &rp, const Tensor &ci, const Tensor &cp, const Tensor &ri, const Tensor &pm,
+                                     const Tensor &el, const Tensor &er, const Tensor &x, double slope, double p) {
+  gat_check(el, er, x);
+  const int64_t C = x.size(2);
+  if (C % 4 != 0 && C >= 8 && ci.size(0) >= 8 * x.size(0)) {
+    Tensor xp = at::constant_pad_nd(x, {0, (4 - C % 4) % 4});
+    return GatCsrFn::apply(rp, ci, cp, ri, pm, el, er, xp, slope, p).slice(2, 0, C);
+  }
+  return GatCsrFn::apply(rp, ci, cp, ri, pm, el, er, x, slope, p);
+}
+
+using BiasFwdSig = std::tuple<Tensor, Tensor>(const Tensor &, const OptT_ &, bool, double);
+using BiasBwdSig = std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, bool, bool, double, const Tensor &);
+struct BiasActFn : public torch::autograd::Function<BiasActFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &a, const OptT_ &bias, bool relu, double p) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = op_handle<BiasFwdSig>("ggl::bias_act_forward");
+    auto r = op.call(a, bias, relu, p);
+    ctx->save_for_backward({std::get<0>(r), std::get<1>(r)});
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["p"] = p;
+    ctx->saved_data["bias_shape"] = opt(bias).defined() ? opt(bias).sizes().vec() : std::vector<int64_t>{};
+    ctx->saved_data["has_bias"] = opt(bias).defined();
+    return std::get<0>(r);
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    static auto op = op_handle<BiasBwdSig>("ggl::bias_act_backward");
+    const bool hb = ctx->saved_data["has_bias"].toBool();
+    auto r = op.call(grads[0], s[0], hb, ctx->saved_data["relu"].toBool(), ctx->saved_data["p"].toDouble(), s[1]);
+    Tensor gb = hb ? std::get<1>(r).reshape(ctx->saved_data["bias_shape"].toIntVector()) : Tensor();
+    return {std::get<0>(r), gb, Tensor(), Tensor()};
+  }
+};
+static Tensor bias_act_autograd(const Tensor &a, const OptT_ &bias, bool relu, double p) { return BiasActFn::apply(a, bias, relu, p); }
+
+using EpiFwdSig = std::tuple<Tensor, Tensor>(const Tensor &, const OptT_ &, const Tensor &, bool, const OptT_ &, const OptT_ &, bool, double);
+struct SpMMEpiFn : public torch::autograd::Function<SpMMEpiFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &index, const OptT_ &weight, const Tensor &x, bool mean,
+                        const OptT_ &add, const OptT_ &bias, bool relu, double p) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = op_handle<EpiFwdSig>("ggl::spmm_epi_forward");
+    auto r = op.call(index, weight, x, mean, add, bias, relu, p);
+    ctx->save_for_backward({index, opt(weight), std::get<0>(r), std::get<1>(r)});
+    ctx->saved_data["mean"] = mean;
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["p"] = p;
+    ctx->saved_data["has_add"] = opt(add).defined();
+    ctx->saved_data["has_bias"] = opt(bias).defined();
+    ctx->saved_data["bias_shape"] = opt(bias).defined() ? opt(bias).sizes().vec() : std::vector<int64_t>{};
+    return std::get<0>(r);
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    static auto bop = op_handle<BiasBwdSig>("ggl::bias_act_backward");
+    const bool hb = ctx->saved_data["has_bias"].toBool();
+    auto r = bop.call(grads[0], s[2], hb, ctx->saved_data["relu"].toBool(), ctx->saved_data["p"].toDouble(), s[3]);
+    Tensor ga = std::get<0>(r);
+    OptT_ w = s[1].defined() ? OptT_(s[1]) : OptT_();
+    static auto sum_bwd = op_handle<SpSig>("ggl::spmm_sum_backward");
+    static auto mean_bwd = op_handle<SpSig>("ggl::spmm_mean_backward");
+    Tensor gx = ctx->saved_data["mean"].toBool() ? mean_bwd.call(s[0], w, ga) : sum_bwd.call(s[0], w, ga);
+    Tensor gb = hb ? std::get<1>(r).reshape(ctx->saved_data["bias_shape"].toIntVector()) : Tensor();
+    return {Tensor(), Tensor(), gx, Tensor(), ctx->saved_data["has_add"].toBool() ? ga : Tensor(), gb, Tensor(), Tensor()};
+  }
+};
+// one kernel for 16-byte rows; the reduce op followed by the adds and the epilogue pass otherwise (same values)
+static Tensor spmm_epi_autograd(const Tensor &index, const OptT_ &weight, const Tensor &x, bool mean, const OptT_ &add,
+                                const OptT_ &bias, bool relu, double p) {
+  if (x.dim() == 2 && x.size(1) % 4 == 0) return SpMMEpiFn::apply(index, weight, x, mean, add, bias, relu, p);
+  Tensor out = mean ? spmm_mean_autograd(index, weight, x) : spmm_sum_autograd(index, weight, x);
+  if (opt(add).defined()) out = out + *add;
+  return BiasActFn::apply(out, bias, relu, p);
+}
+
+struct SegEpiFn : public torch::autograd::Function<SegEpiFn> {
+  static Tensor forward(AutogradContext *ctx, const Tensor &x, const Tensor &index, int64_t N, bool mean, const OptT_ &add,
+                        const OptT_ &bias, bool relu) {
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = op_handle<Tensor(const Tensor &, const Tensor &, int64_t, bool, const OptT_ &, const OptT_ &, bool)>(
+        "ggl::segment_epi_forward");
+    Tensor y = op.call(x, index, N, mean, add, bias, relu);
+    ctx->save_for_backward({index, y});
+    ctx->saved_data["x_shape"] = x.sizes().vec();
+    ctx->saved_data["N"] = N;
+    ctx->saved_data["mean"] = mean;
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["has_add"] = opt(add).defined();
+    ctx->saved_data["has_bias"] = opt(bias).defined();
+    ctx->saved_data["bias_shape"] = opt(bias).defined() ? opt(bias).sizes().vec() : std::vector<int64_t>{};
+    return y;
+  }
+  static variable_list backward(AutogradContext *ctx, variable_list grads) {
+    auto s = ctx->get_saved_variables();
+    static auto bop = op_handle<BiasBwdSig>("ggl::bias_act_backward");
+    const bool hb = ctx->saved_data["has_bias"].toBool();
+    auto r = bop.call(grads[0], s[1], hb, ctx->saved_data["relu"].toBool(), 0.0, at::empty({0}, s[0].options()));
+    Tensor ga = std::get<0>(r);
+    auto shape = ctx->saved_data["x_shape"].toIntVector();
+    Tensor gx;
+    if (ctx->saved_data["mean"].toBool()) {
+      static auto op = op_handle<Tensor(const Tensor &, const Tensor &, int64_t, c10::IntArrayRef)>("ggl::segment_mean_backward");
+      gx = op.call(ga, s[0], ctx->saved_data["N"].toInt(), shape);
+    } else {
+      static auto op = op_handle<Tensor(const Tensor &, const Tensor &, c10::IntArrayRef)>("ggl::segment_sum_backward");
+      gx = op.call(ga, s[0], shape);
+    }
+    Tensor gb = hb ? std::get<1>(r).reshape(ctx->saved_data["bias_shape"].toIntVector()) : Tensor();
+    return {gx, Tensor(), Tensor(), Tensor(), ctx->saved_data["has_add"].toBool() ? ga : Tensor(), gb, Tensor()};
+  }
+};
+static Tensor segment_epi_autograd(const Tensor &x, const Tensor &index, int64_t N, bool mean, const OptT_ &add,
+                                   const OptT_ &bias, bool relu) {
+  return SegEpiFn::apply(x, index, N, mean, add, bias, relu);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Meta (shapes / dtypes only) and housekeeping ops
 // ---------------------------------------------------------------------------------------------------------------
@@ -879,9 +1455,61 @@ static std::tuple<Tensor, Tensor> bspmm_bwd_meta(const Tensor &, const Tensor &w
   return {at::empty_like(w), at::empty_like(x)};
 }
 
+static std::tuple<Tensor, Tensor, Tensor, Tensor, bool> gat_fwd_meta(const Tensor &, const Tensor &, const Tensor &er,
+                                                                     const Tensor &x, double, int64_t n, double) {
+  auto o = x.options();
+  return {at::empty({n, x.size(1), x.size(2)}, o), at::empty({n, x.size(1)}, o), at::empty({n, x.size(1)}, o),
+          at::empty({0}, o.dtype(at::kLong)), false};
+}
+static std::tuple<Tensor, Tensor, Tensor> gat_bwd_meta(const Tensor &, const Tensor &el, const Tensor &er, const Tensor &x,
+                                                       const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                       const Tensor &, double, int64_t, double, bool) {
+  return {at::empty_like(el), at::empty_like(er), at::empty_like(x)};
+}
+static Tensor gat_meta(const Tensor &, const Tensor &, const Tensor &, const Tensor &x, double, c10::optional<int64_t> n, double) {
+  return at::empty({n.has_value() ? *n : x.size(0), x.size(1), x.size(2)}, x.options());
+}
+static std::tuple<Tensor, Tensor, Tensor, Tensor, bool> gat_csr_fwd_meta(const Tensor &rp, const Tensor &, const Tensor &,
+                                                                         const Tensor &, const Tensor &, const Tensor &,
+                                                                         const Tensor &, const Tensor &x, double, double) {
+  const int64_t n = rp.size(0) - 1;
+  auto o = x.options();
+  return {at::empty({n, x.size(1), x.size(2)}, o), at::empty({n, x.size(1)}, o), at::empty({n, x.size(1)}, o),
+          at::empty({0}, o.dtype(at::kLong)), false};
+}
+static std::tuple<Tensor, Tensor, Tensor> gat_csr_bwd_meta(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                           const Tensor &, const Tensor &el, const Tensor &er, const Tensor &x,
+                                                           const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                           const Tensor &, double, double, bool) {
+  return {at::empty_like(el), at::empty_like(er), at::empty_like(x)};
+}
+static Tensor gat_csr_meta(const Tensor &rp, const Tensor &, const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                           const Tensor &, const Tensor &x, double, double) {
+  return at::empty({rp.size(0) - 1, x.size(1), x.size(2)}, x.options());
+}
+static std::tuple<Tensor, Tensor> bias_fwd_meta(const Tensor &a, const OptT_ &, bool, double) {
+  return {at::empty_like(a), at::empty({0}, a.options().dtype(at::kLong))};
+}
+static std::tuple<Tensor, Tensor> bias_bwd_meta(const Tensor &g, const Tensor &, bool hb, bool, double, const Tensor &) {
+  const int64_t N = g.dim() > 0 ? g.size(0) : 1;
+  return {at::empty_like(g), at::empty({hb && N > 0 ? g.numel() / N : 0}, g.options())};
+}
+static Tensor bias_meta(const Tensor &a, const OptT_ &, bool, double) { return at::empty_like(a); }
+static std::tuple<Tensor, Tensor> epi_fwd_meta(const Tensor &, const OptT_ &, const Tensor &x, bool, const OptT_ &, const OptT_ &,
+                                               bool, double) {
+  return {at::empty_like(x), at::empty({0}, x.options().dtype(at::kLong))};
+}
+static Tensor epi_meta(const Tensor &, const OptT_ &, const Tensor &x, bool, const OptT_ &, const OptT_ &, bool, double) {
+  return at::empty_like(x);
+}
+static Tensor seg_epi_meta(const Tensor &x, const Tensor &, int64_t N, bool, const OptT_ &, const OptT_ &, bool) {
+  return at::empty(out_shape(x, N), x.options());
+}
+
 static void clear_caches() {
   seg_cache().clear();
   graph_cache().clear();
+  csr_cache().clear();
 }
 static std::vector<int64_t> plan_stats() {
   return {static_cast<int64_t>(g_plans_built.load()), static_cast<int64_t>(g_plan_hits.load())};
@@ -906,6 +1534,34 @@ TORCH_LIBRARY(ggl, m) {
   m.def("spmm_max_arg(Tensor index, Tensor? weight, Tensor x) -> (Tensor, Tensor)");
   m.def("spmm_max_backward(Tensor index, Tensor? weight, Tensor grad, Tensor arg) -> Tensor");
   m.def("bspmm_sum_backward(Tensor index, Tensor weight, Tensor x, Tensor grad) -> (Tensor, Tensor)");
+  // the fused route: edge-softmax + aggregate (COO edge list / the caller's CSR = dgNN's GATConvFuse), the layer epilogue
+  // alone and inside the aggregate's store, one static-shape sampler hop
+  m.def("gat_fused(Tensor index, Tensor el, Tensor er, Tensor x, float negative_slope=0.2, int? num_nodes=None, "
+        "float dropout_rate=0.0) -> Tensor");
+  m.def("gat_fused_forward(Tensor index, Tensor el, Tensor er, Tensor x, float negative_slope, int num_nodes, "
+        "float dropout_rate) -> (Tensor, Tensor, Tensor, Tensor, bool)");
+  m.def("gat_fused_backward(Tensor index, Tensor el, Tensor er, Tensor x, Tensor grad, Tensor out, Tensor rowmax, "
+        "Tensor rowden, Tensor rng_used, float negative_slope, int num_nodes, float dropout_rate, bool fast) -> "
+        "(Tensor, Tensor, Tensor)");
+  m.def("gat_fused_csr(Tensor row_ptr, Tensor col_ind, Tensor col_ptr, Tensor row_ind, Tensor permute, Tensor el, "
+        "Tensor er, Tensor x, float negative_slope=0.2, float dropout_rate=0.0) -> Tensor");
+  m.def("gat_fused_csr_forward(Tensor row_ptr, Tensor col_ind, Tensor col_ptr, Tensor row_ind, Tensor permute, Tensor el, "
+        "Tensor er, Tensor x, float negative_slope, float dropout_rate) -> (Tensor, Tensor, Tensor, Tensor, bool)");
+  m.def("gat_fused_csr_backward(Tensor row_ptr, Tensor col_ind, Tensor col_ptr, Tensor row_ind, Tensor permute, Tensor el, "
+        "Tensor er, Tensor x, Tensor grad, Tensor out, Tensor rowmax, Tensor rowden, Tensor rng_used, float negative_slope, "
+        "float dropout_rate, bool fast) -> (Tensor, Tensor, Tensor)");
+  m.def("bias_act(Tensor a, Tensor? bias, bool relu, float p_drop) -> Tensor");
+  m.def("bias_act_forward(Tensor a, Tensor? bias, bool relu, float p_drop) -> (Tensor, Tensor)");
+  m.def("bias_act_backward(Tensor grad, Tensor y, bool has_bias, bool relu, float p_drop, Tensor rng_used) -> (Tensor, Tensor)");
+  m.def("spmm_epi(Tensor index, Tensor? weight, Tensor x, bool mean=False, Tensor? add=None, Tensor? bias=None, "
+        "bool relu=False, float p_drop=0.0) -> Tensor");
+  m.def("spmm_epi_forward(Tensor index, Tensor? weight, Tensor x, bool mean, Tensor? add, Tensor? bias, bool relu, "
+        "float p_drop) -> (Tensor, Tensor)");
+  m.def("segment_epi(Tensor x, Tensor index, int N, bool mean=True, Tensor? add=None, Tensor? bias=None, bool relu=False) -> Tensor");
+  m.def("segment_epi_forward(Tensor x, Tensor index, int N, bool mean, Tensor? add, Tensor? bias, bool relu) -> Tensor");
+  m.def("sample_hop(Tensor rowptr, Tensor col, Tensor seeds, Tensor n_seeds, int num_nodes, int fanout, int e_cap, int s_cap, "
+        "Tensor(a!) first_pos) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def("reseed() -> ()", ggl_torch::reseed);
   m.def("clear_caches() -> ()", ggl_torch::clear_caches);
   m.def("plan_stats() -> int[]", ggl_torch::plan_stats);
 }
@@ -927,6 +1583,15 @@ TORCH_LIBRARY(ggl, m) {
     m.impl("spmm_max_arg", ggl_torch::spmm_max_arg_kernel);                    \
     m.impl("spmm_max_backward", ggl_torch::spmm_max_backward_kernel);          \
     m.impl("bspmm_sum_backward", ggl_torch::bspmm_sum_backward_kernel);        \
+    m.impl("gat_fused_forward", ggl_torch::gat_fused_forward_kernel);          \
+    m.impl("gat_fused_backward", ggl_torch::gat_fused_backward_kernel);        \
+    m.impl("gat_fused_csr_forward", ggl_torch::gat_csr_forward_kernel);        \
+    m.impl("gat_fused_csr_backward", ggl_torch::gat_csr_backward_kernel);      \
+    m.impl("bias_act_forward", ggl_torch::bias_act_forward_kernel);            \
+    m.impl("bias_act_backward", ggl_torch::bias_act_backward_kernel);          \
+    m.impl("spmm_epi_forward", ggl_torch::spmm_epi_forward_kernel);            \
+    m.impl("segment_epi_forward", ggl_torch::segment_epi_forward_kernel);      \
+    m.impl("sample_hop", ggl_torch::sample_hop_kernel);                        \
   }
 GGL_BACKEND(CPU)
 GGL_BACKEND(CUDA)
@@ -939,6 +1604,11 @@ TORCH_LIBRARY_IMPL(ggl, Autograd, m) {
   m.impl("spmm_mean", ggl_torch::spmm_mean_autograd);
   m.impl("spmm_max", ggl_torch::spmm_max_autograd);
   m.impl("bspmm_sum", ggl_torch::bspmm_sum_autograd);
+  m.impl("gat_fused", ggl_torch::gat_fused_autograd);
+  m.impl("gat_fused_csr", ggl_torch::gat_fused_csr_autograd);
+  m.impl("bias_act", ggl_torch::bias_act_autograd);
+  m.impl("spmm_epi", ggl_torch::spmm_epi_autograd);
+  m.impl("segment_epi", ggl_torch::segment_epi_autograd);
 }
 
 TORCH_LIBRARY_IMPL(ggl, Meta, m) {
@@ -957,4 +1627,17 @@ TORCH_LIBRARY_IMPL(ggl, Meta, m) {
   m.impl("spmm_max_arg", ggl_torch::spmm_max_arg_meta);
   m.impl("spmm_max_backward", ggl_torch::spmm_max_bwd_meta);
   m.impl("bspmm_sum_backward", ggl_torch::bspmm_bwd_meta);
+  m.impl("gat_fused", ggl_torch::gat_meta);
+  m.impl("gat_fused_forward", ggl_torch::gat_fwd_meta);
+  m.impl("gat_fused_backward", ggl_torch::gat_bwd_meta);
+  m.impl("gat_fused_csr", ggl_torch::gat_csr_meta);
+  m.impl("gat_fused_csr_forward", ggl_torch::gat_csr_fwd_meta);
+  m.impl("gat_fused_csr_backward", ggl_torch::gat_csr_bwd_meta);
+  m.impl("bias_act", ggl_torch::bias_meta);
+  m.impl("bias_act_forward", ggl_torch::bias_fwd_meta);
+  m.impl("bias_act_backward", ggl_torch::bias_bwd_meta);
+  m.impl("spmm_epi", ggl_torch::epi_meta);
+  m.impl("spmm_epi_forward", ggl_torch::epi_fwd_meta);
+  m.impl("segment_epi", ggl_torch::seg_epi_meta);
+  m.impl("segment_epi_forward", ggl_torch::seg_epi_meta);
 }

@@ -1710,3 +1710,138 @@ def check_neighbor_sample(fn, dev, oracle):
             assert np.array_equal(nodes[f_hi:f_hi + len(new)], new), "new nodes ascending"
             f_lo, f_hi = f_hi, f_hi + len(new)
         assert at == len(edges)
+
+
+def check_cpp_fused_route(ops, eng, dev, oracle=None):
+    """torch.ops.ggl.{gat_fused, gat_fused_csr, bias_act, spmm_epi, segment_epi, sample_hop} (registered from C++,
+    csrc/torch/ggl_torch.cpp) against the ctypes Engine on the same kernel library: values and every gradient equal
+    bit for bit (same kernels, same launch policy), dropout included when both RNG states are seeded alike."""
+    g = torch.Generator().manual_seed(41)
+    N, E = 90, 2500
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :700] = 5                                   # a hub row (longer than the plan's threshold of 256)
+    ei = ei.to(dev)
+
+    def tri(H, C):
+        return (torch.randn(N, H, C, generator=g).to(dev), torch.randn(N, H, generator=g).to(dev),
+                torch.randn(N, H, generator=g).to(dev), torch.randn(N, H, C, generator=g).to(dev))
+
+    for H, C, p in ((4, 8, 0.0), (8, 8, 0.0), (2, 5, 0.0), (8, 41, 0.0), (3, 12, 0.0), (4, 8, 0.4), (2, 5, 0.3)):
+        x, el, er, go = tri(H, C)
+        res = []
+        for which in ("engine", "cpp"):
+            torch.manual_seed(1234)
+            eng.reseed() if which == "engine" else ops.reseed()
+            xa, ela, era = (t.clone().requires_grad_(True) for t in (x, el, er))
+            if which == "engine":
+                y = eng.gat_fused(ei, ela, era, xa, 0.2, N, p, True)
+            else:
+                y = ops.gat_fused(ei, ela, era, xa, 0.2, N, p)
+            y.backward(go)
+            res.append((y.detach(), xa.grad, ela.grad, era.grad))
+        for a, b, nm in zip(res[0], res[1], ("out", "gx", "gel", "ger")):
+            assert torch.equal(a, b), f"gat_fused {H}x{C} p={p}: {nm} differs from the engine's"
+    # the caller's CSR (dgNN's argument list): rows aggregate, no sort
+    gp = eng.graph_plan(ei, N)
+    five = (gp.fwd.rowptr.clone(), gp.col.clone(), gp.bwd.rowptr.clone(), gp.colT.clone(), gp.posT.clone())
+    x, el, er, go = tri(4, 8)
+    xa, ela, era = (t.clone().requires_grad_(True) for t in (x, el, er))
+    ya = eng.gat_fused(eng.graph_plan_from_csr(*five), ela, era, xa, 0.2, N, 0.0, True)
+    ya.backward(go)
+    for call in range(2):                              # the second call hits the C++ side's CSR plan cache
+        xb, elb, erb = (t.clone().requires_grad_(True) for t in (x, el, er))
+        yb = ops.gat_fused_csr(*five, elb, erb, xb, 0.2, 0.0)
+        yb.backward(go)
+        assert torch.equal(ya.detach(), yb.detach()) and torch.equal(xa.grad, xb.grad) and torch.equal(ela.grad, elb.grad) \
+            and torch.equal(era.grad, erb.grad), f"gat_fused_csr call {call}"
+    # the layer epilogue alone
+    a = torch.randn(N, 24, generator=g).to(dev)
+    b = torch.randn(24, generator=g).to(dev)
+    go2 = torch.randn(N, 24, generator=g).to(dev)
+    for bias, relu, p in ((b, True, 0.0), (None, True, 0.0), (b, False, 0.0), (b, True, 0.5), (None, False, 0.25)):
+        res = []
+        for which in ("engine", "cpp"):
+            torch.manual_seed(77)
+            eng.reseed() if which == "engine" else ops.reseed()
+            aa = a.clone().requires_grad_(True)
+            bb = bias.clone().requires_grad_(True) if bias is not None else None
+            y = eng.bias_act(aa, bb, relu, p, True) if which == "engine" else ops.bias_act(aa, bb, relu, p)
+            y.backward(go2)
+            res.append((y.detach(), aa.grad, bb.grad if bb is not None else None))
+        for u, v in zip(res[0], res[1]):
+            assert (u is None and v is None) or torch.equal(u, v), ("bias_act", relu, p)
+    # ... and in the aggregate's store
+    w = torch.rand(E, generator=g).to(dev)
+    for K, mean, use_add, use_b, relu, p in ((24, False, False, True, True, 0.0), (24, True, True, True, True, 0.0),
+                                               (24, False, True, False, False, 0.3), (7, False, True, True, True, 0.0),
+                                               (7, True, False, True, False, 0.0)):
+        xk = torch.randn(N, K, generator=g).to(dev)
+        addk = torch.randn(N, K, generator=g).to(dev) if use_add else None
+        bk = torch.randn(K, generator=g).to(dev) if use_b else None
+        gok = torch.randn(N, K, generator=g).to(dev)
+        res = []
+        for which in ("engine", "cpp"):
+            torch.manual_seed(99)
+            eng.reseed() if which == "engine" else ops.reseed()
+            xx = xk.clone().requires_grad_(True)
+            ad = addk.clone().requires_grad_(True) if addk is not None else None
+            bb = bk.clone().requires_grad_(True) if bk is not None else None
+            if which == "engine":
+                y = eng.spmm_epi(eng.graph_plan(ei, N), w, xx, "mean" if mean else "sum", ad, bb, relu, p, True)
+            else:
+                y = ops.spmm_epi(ei, w, xx, mean, ad, bb, relu, p)
+            y.backward(gok)
+            res.append((y.detach(), xx.grad, ad.grad if ad is not None else None, bb.grad if bb is not None else None))
+        for u, v in zip(res[0], res[1]):
+            assert (u is None and v is None) or torch.equal(u, v), ("spmm_epi", K, mean, use_add, use_b, relu, p)
+    msg = torch.randn(E, 12, generator=g).to(dev)
+    ids = ei[1].contiguous()
+    addn = torch.randn(N, 12, generator=g).to(dev)
+    bn = torch.randn(12, generator=g).to(dev)
+    gon = torch.randn(N, 12, generator=g).to(dev)
+    for mean in (True, False):
+        res = []
+        for which in ("engine", "cpp"):
+            m_ = msg.clone().requires_grad_(True)
+            ad, bb = addn.clone().requires_grad_(True), bn.clone().requires_grad_(True)
+            y = eng.segment_epi(m_, ids, N, "mean" if mean else "sum", ad, bb, True) if which == "engine" \
+                else ops.segment_epi(m_, ids, N, mean, ad, bb, True)
+            y.backward(gon)
+            res.append((y.detach(), m_.grad, ad.grad, bb.grad))
+        for u, v in zip(res[0], res[1]):
+            assert torch.equal(u, v), ("segment_epi", mean)
+    # one static-shape sampler hop: same kernels, same {seed, offset} -> the same block
+    from gammagl_amd.ops import _ptr
+
+    plan = eng.seg_plan(ids, N)
+    rowptr = plan.rowptr
+    col = ei[0] if plan.perm is None else ei[0][plan.perm.long()]
+    seeds = torch.arange(0, 40, 3, device=dev)
+    b_cap, fan = int(seeds.shape[0]), 4
+    e_cap, s_cap = b_cap * fan, b_cap + b_cap * fan
+    n_seeds = torch.full((1,), b_cap - 2, dtype=torch.int64, device=dev)     # two padding slots
+    outs = []
+    for which in ("engine", "cpp"):
+        torch.manual_seed(5)
+        first_pos = torch.full((N,), 1 << 62, dtype=torch.int64, device=dev)
+        if which == "engine":
+            eng.reseed()
+            o_rp = torch.empty(b_cap + 1, dtype=torch.int64, device=dev)
+            o_col = torch.empty(e_cap, dtype=torch.int32, device=dev)
+            o_eid = torch.empty(e_cap, dtype=torch.int64, device=dev)
+            o_nid = torch.empty(s_cap, dtype=torch.int64, device=dev)
+            cnt = torch.empty(3, dtype=torch.int64, device=dev)
+            wsb = eng.lib.ggl_sample_hop_workspace_bytes(b_cap, e_cap)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            eng._check(eng.lib.ggl_sample_hop(_ptr(rowptr), _ptr(col.contiguous()), _ptr(seeds), _ptr(n_seeds), b_cap, N, fan, e_cap,
+                                              s_cap, _ptr(eng._rng_state(torch.device(dev))), _ptr(first_pos), _ptr(o_rp), _ptr(o_col),
+                                              _ptr(o_eid), _ptr(o_nid), _ptr(cnt), _ptr(ws), wsb, eng._stream(torch.device(dev))))
+            outs.append((o_rp, o_col, o_eid, o_nid, cnt))
+        else:
+            ops.reseed()
+            outs.append(ops.sample_hop(rowptr, col.contiguous(), seeds, n_seeds, N, fan, e_cap, s_cap, first_pos))
+        assert bool((first_pos == (1 << 62)).all()), "the relabel scratch comes back clean"
+    nn, ne, ovf = outs[0][4].tolist()
+    assert outs[1][4].tolist() == [nn, ne, ovf] and ovf == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1][:ne], outs[1][1][:ne]) \
+        and torch.equal(outs[0][2][:ne], outs[1][2][:ne]) and torch.equal(outs[0][3][:nn], outs[1][3][:nn])

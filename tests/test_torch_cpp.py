@@ -212,6 +212,35 @@ def test_dispatcher_contracts(cpp):
     assert out.requires_grad and not arg.requires_grad and arg.dtype == torch.int64
 
 
+def test_fused_route_registered_from_cpp(cpp):
+    """gat_fused / gat_fused_csr / bias_act / spmm_epi / segment_epi / sample_hop as C++ dispatcher ops: bit-identical to
+    the ctypes Engine on the host build (values, gradients, dropout masks under the same seed), dispatcher contracts."""
+    import gammagl_amd
+
+    ops = cpp.ops
+    pc.check_cpp_fused_route(ops, gammagl_amd.host_engine(), torch.device("cpu"))
+    g = torch.Generator().manual_seed(8)
+    N, E, H, C = 20, 150, 2, 4
+    ei = torch.randint(0, N, (2, E), generator=g)
+    x, el, er = torch.randn(N, H, C, generator=g), torch.randn(N, H, generator=g), torch.randn(N, H, generator=g)
+    utils = ("test_schema", "test_faketensor", "test_autograd_registration")
+    torch.library.opcheck(ops.gat_fused.default, (ei, el.clone().requires_grad_(True), er, x.clone().requires_grad_(True), 0.2, N, 0.0),
+                          test_utils=utils)
+    torch.library.opcheck(ops.bias_act.default, (torch.randn(N, 8, generator=g).requires_grad_(True), torch.randn(8, generator=g), True, 0.0),
+                          test_utils=utils)
+    torch.library.opcheck(ops.spmm_epi.default, (ei, torch.rand(E, generator=g), torch.randn(N, 8, generator=g).requires_grad_(True),
+                                                 False, None, torch.randn(8, generator=g), True, 0.0), test_utils=utils)
+    torch.library.opcheck(ops.segment_epi.default, (torch.randn(E, 8, generator=g).requires_grad_(True), ei[1].contiguous(), N, True,
+                                                    None, None, True), test_utils=utils)
+    # error types: the reference's predicates
+    with pytest.raises(RuntimeError):
+        ops.gat_fused(ei, el.double(), er, x, 0.2, N, 0.0)
+    with pytest.raises(RuntimeError):
+        ops.gat_fused(ei, el, er, x, 0.2, N, 1.0)
+    with pytest.raises(IndexError):
+        ops.gat_fused(ei + N, el, er, x, 0.2, N, 0.0)
+
+
 def test_visible_to_torchscript_without_python(cpp, tmp_path):
     """A scripted function calling the op serialises and runs from the saved archive: the call goes dispatcher -> C++,
     there is no Python callable behind the op to pickle (the Python-registered ops cannot do this)."""

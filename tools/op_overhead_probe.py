@@ -66,6 +66,36 @@ def main():
 
         res = [timed(lambda: fwd(spmm, x)), timed(lambda: fb(spmm, x)), timed(lambda: fwd(seg, msg)), timed(lambda: fb(seg, msg))]
         print(f"{name:45s} " + " ".join(f"{v:10.1f}" for v in res))
+    # the fused route (round 4: registered from C++ as well)
+    H, Cc = 8, 8
+    xg = torch.randn(a.nodes, H, Cc, generator=g, device=dev)
+    el, er = torch.randn(a.nodes, H, generator=g, device=dev), torch.randn(a.nodes, H, generator=g, device=dev)
+    act = torch.randn(a.nodes, a.width, generator=g, device=dev)
+    bias = torch.randn(a.width, generator=g, device=dev)
+    gp = eng.graph_plan(ei, a.nodes)
+    fused = {
+        "engine (ctypes, direct)": (lambda t: eng.gat_fused(ei, el, er, t, 0.2, a.nodes, 0.0, True),
+                                    lambda t: eng.bias_act(t, bias, True, 0.0, True),
+                                    lambda t: eng.spmm_epi(gp, w, t, "sum", None, bias, True, 0.0, True)),
+        "torch.ops.gammagl_amd (Python-registered)": (lambda t: P.gat_fused(ei, el, er, t, 0.2, a.nodes, 0.0),
+                                                      lambda t: P.bias_act(t, bias, True, 0.0), None),
+        "torch.ops.ggl (C++-registered)": (lambda t: C.gat_fused(ei, el, er, t, 0.2, a.nodes, 0.0),
+                                           lambda t: C.bias_act(t, bias, True, 0.0),
+                                           lambda t: C.spmm_epi(ei, w, t, False, None, bias, True, 0.0)),
+    }
+    print(f"\n{'route':45s} {'gat fwd':>10s} {'gat f+b':>10s} {'biasact fwd':>11s} {'biasact f+b':>11s} {'epi fwd':>10s} {'epi f+b':>10s}")
+    for name, (gat, ba, epi) in fused.items():
+        def fwd(f, t):
+            with torch.no_grad():
+                f(t)
+
+        def fb(f, t):
+            tt = t.detach().requires_grad_(True)
+            f(tt).sum().backward()
+
+        res = [timed(lambda: fwd(gat, xg)), timed(lambda: fb(gat, xg)), timed(lambda: fwd(ba, act)), timed(lambda: fb(ba, act))]
+        res += [timed(lambda: fwd(epi, x)), timed(lambda: fb(epi, x))] if epi is not None else [float("nan")] * 2
+        print(f"{name:45s} " + " ".join(f"{v:10.1f}" for v in res))
 
 
 if __name__ == "__main__":
