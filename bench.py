@@ -562,13 +562,52 @@ def main():
             raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
         torch.cuda.set_device(local_rank)
         dev, backend = torch.device("cuda", local_rank), "nccl"
+    stage = {"name": "start"}
+
+    def diagnostic(err):
+        """N > 1 only: what failed and where, as ONE JSON line per failing rank (the first multi-GPU run of this code is
+        the driver's: a bare traceback from rank 5 of 8 says little).  `stage` = the last step this rank had reached."""
+        import traceback
+
+        line = {"diagnostic": True, "metric": "bench.py did not produce a measurement", "stage": stage["name"], "rank": rank,
+                "world": world, "backend": backend, "error": f"{type(err).__name__}: {err}"[:3000],
+                "traceback_tail": traceback.format_exc()[-1500:],
+                "halo_exchange": os.environ.get("GGL_HALO_A2A", "a2a"),
+                "env": {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK", "NCCL_DEBUG",
+                                                        "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME", "HIP_VISIBLE_DEVICES")},
+                "hint": "GGL_HALO_A2A=p2p switches the halo exchange from all_to_all_single to grouped isend / irecv; "
+                        "NCCL_DEBUG=INFO prints RCCL's own account to stderr"}
+        print(json.dumps(line), flush=True)
+
     if world > 1:
         import torch.distributed as dist
 
-        if emul:
-            dist.init_process_group(backend)
-        else:
-            dist.init_process_group(backend, device_id=dev)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # RCCL's error text on stderr, not just an error code
+        try:
+            stage["name"] = "init_process_group"
+            if emul:
+                dist.init_process_group(backend)
+            else:
+                dist.init_process_group(backend, device_id=dev)
+            # the first collectives, on their own: an all-reduce, then the uneven all-to-all-v the halo exchange is made of
+            stage["name"] = "first all_reduce"
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            assert int(probe.item()) == world, f"all_reduce of ones over {world} ranks returned {probe.item()}"
+            stage["name"] = "first uneven all_to_all_single"
+            send = torch.full((sum(range(1, world + 1)), 4), float(rank), device=dev)
+            splits_in = list(range(1, world + 1))
+            splits_out = [rank + 1] * world
+            recv = torch.empty((sum(splits_out), 4), device=dev)
+            dist.all_to_all_single(recv, send, splits_out, splits_in)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            want = torch.arange(world, device=dev, dtype=torch.float32).repeat_interleave(rank + 1)
+            assert torch.equal(recv[:, 0], want), "uneven all_to_all_single delivered the wrong rows"
+            stage["name"] = "benchmark body"
+        except Exception as err:  # noqa: BLE001
+            diagnostic(err)
+            raise
 
     torch.set_float32_matmul_precision(args.matmul_precision)
     tuned = None
@@ -593,7 +632,12 @@ def main():
 
     want_cpu = world == 1 and not args.no_cpu_baseline and not emul
     args.keep_host_graph = want_cpu and kind == "gcn" and args.workload != "tiny"
-    out, ctx = RUNNERS[kind](args, dev, rank, world, eng=eng)
+    try:
+        out, ctx = RUNNERS[kind](args, dev, rank, world, eng=eng)
+    except Exception as err:  # noqa: BLE001
+        if world > 1:
+            diagnostic(err)
+        raise
     out["engine"] = "host-emulation (launcher test, not a measurement)" if emul else "hip"
     out["config"]["tuned_gemm_selection"] = tuned
     out["config"]["matmul_precision"] = args.matmul_precision + (" (IEEE f32)" if args.matmul_precision == "highest"

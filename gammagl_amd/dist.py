@@ -38,6 +38,7 @@ from .dense import wgrad
 from .ops import _ptr
 
 HALO_CHUNKS = int(os.environ.get("GGL_HALO_CHUNKS", "0"))  # 0 = automatic (4 at K >= 256, 2 at K >= 128)
+A2A_MODE = os.environ.get("GGL_HALO_A2A", "a2a")            # "a2a": all_to_all_single | "p2p": grouped isend / irecv per peer
 
 
 def balanced_bounds(dst, num_nodes, world):
@@ -54,6 +55,18 @@ class _Done:
     """Stand-in for a collective's work handle where nothing travels (dry runs)."""
 
     def wait(self):
+        return True
+
+
+class _Works:
+    """The work handles of one grouped point-to-point exchange behind the single wait() an all-to-all's handle has."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
         return True
 
 
@@ -224,6 +237,24 @@ class PartitionedGraph:
         if self.dry:  # nothing travels: the receive buffer keeps whatever it holds (finite values for timing)
             out.zero_()
             return out, _Done()
+        if A2A_MODE == "p2p":
+            # the same exchange as explicit grouped point-to-point transfers (ncclGroupStart; ncclSend / ncclRecv per
+            # peer; ncclGroupEnd — what SURVEY.md §8e sketches): an A/B switch for the first real multi-GPU run, where
+            # all_to_all_single's uneven-split path over xGMI is untested (GGL_HALO_A2A=p2p)
+            ops, o0, i0 = [], 0, 0
+            me = dist.get_rank(self.group)
+            for peer, (no, ni) in enumerate(zip(out_splits, in_splits)):
+                if peer == me:
+                    if no:
+                        out[o0:o0 + no].copy_(inp[i0:i0 + ni])
+                elif no or ni:
+                    gpeer = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+                    if ni:
+                        ops.append(dist.P2POp(dist.isend, inp[i0:i0 + ni], gpeer, group=self.group))
+                    if no:
+                        ops.append(dist.P2POp(dist.irecv, out[o0:o0 + no], gpeer, group=self.group))
+                o0, i0 = o0 + no, i0 + ni
+            return out, (_Works(dist.batch_isend_irecv(ops)) if ops else _Done())
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
         return out, work
 

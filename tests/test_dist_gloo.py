@@ -89,6 +89,17 @@ def _worker(rank, world, port, tmp):
         full.backward(go)
         torch.testing.assert_close(out.detach(), full.detach()[pg.lo:pg.hi], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(hl.grad, hf.grad[pg.lo:pg.hi], rtol=1e-5, atol=1e-5)
+        # the same exchange as grouped point-to-point transfers (GGL_HALO_A2A=p2p: the A/B switch for the first real
+        # multi-GPU run): same rows, same gradients
+        import gammagl_amd.dist as gdist
+        gdist.A2A_MODE = "p2p"
+        try:
+            hp = h[pg.lo:pg.hi].clone().requires_grad_(True)
+            outp = pg.aggregate(hp)
+            outp.backward(go[pg.lo:pg.hi])
+            assert torch.equal(outp.detach(), out.detach()) and torch.equal(hp.grad, hl.grad)
+        finally:
+            gdist.A2A_MODE = "a2a"
         # wide features: the exchange is pipelined in 4 (K = 256) / 2 (K = 136) column chunks
         from gammagl_amd.dist import _HaloAggregate
         assert len(_HaloAggregate._chunks(256)) == 4 and len(_HaloAggregate._chunks(136)) == 2
