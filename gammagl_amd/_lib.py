@@ -105,6 +105,13 @@ SIGNATURES = {
     "ggl_block_transpose": (c_int, [_V, _V, c_int64, c_int64, c_int64, _V, _V, _V, c_size_t, _V]),
     "ggl_set_option": (c_int, [c_char_p, c_int64]),
     "ggl_get_option": (c_int64, [c_char_p]),
+    "ggl_policy_chunk": (c_int64, [c_int64]),
+    "ggl_policy_spmm_width": (c_int64, [c_int, c_int64, c_int64, c_int64]),
+    "ggl_policy_head_channels": (c_int64, [c_int64, c_int64, c_int64]),
+    "ggl_policy_mean_bwd_prescale": (c_int, [c_int64, c_int64]),
+    "ggl_policy_gradw_sorted": (c_int, [c_int64]),
+    "ggl_policy_xcd_run_rows": (c_int64, [c_int64, ctypes.c_double]),
+    "ggl_policy_row_order": (c_int, [POINTER(c_int64), POINTER(c_int64)]),
     "ggl_calib_stream": (c_int, [_V, _V, c_int64, c_int, _V]),
     "ggl_time_spmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V, c_int, POINTER(c_float)]),
 }

@@ -14,6 +14,15 @@
 
 namespace ggl {
 
+// the stage barrier: only the LDS tile is shared, so the fences name the LDS address space alone — __syncthreads() is a
+// full workgroup-scope release, which on gfx9 waits for EVERY outstanding memory operation of the wave (vmcnt(0)): the
+// producers' index prefetch of the next stage drained at every stage (round 4, see hubf32.hip)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int kHubStage = 256;              // elements per LDS half = producer threads (one element each)
 constexpr int kHubCols = 64;                // columns per slab = consumer lanes
 constexpr int kHubBlock = kWave + kHubStage;  // wavefront 0 consumes, wavefronts 1-4 produce
@@ -132,19 +141,19 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
     int64_t src = src_of(0);
     int64_t nxt = nst > 1 ? src_of(1) : -1;
     fill(src, 0);
-    __syncthreads();
+    lds_barrier();
     for (int64_t st = 0; st < nst; ++st) {
       src = nxt;
       nxt = st + 2 < nst ? src_of(st + 2) : -1;
       if (st + 1 < nst) fill(src, (int)((st + 1) & 1));
-      __syncthreads();
+      lds_barrier();
     }
     return;
   }
   // ---- consumer: one column per lane, the elements of a stage in order; the LDS reads of 8 elements are issued
   // together, the adds stay the reference's serial chain
   HubAcc<T> run;
-  __syncthreads();
+  lds_barrier();
   for (int64_t st = 0; st < nst; ++st) {
     const int b = (int)(st & 1);
     if (lane < ncol) {
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *_
       }
       for (; e < cnt; ++e) run.add(buf[b][e][lane]);
     }
-    __syncthreads();
+    lds_barrier();
   }
   typename TT<T>::A acc = run.value();
   if (lane < ncol) {

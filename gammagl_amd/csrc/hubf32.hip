@@ -23,7 +23,6 @@
 
 namespace ggl {
 
-constexpr int kHfCols = 64;                          // columns per slab = consumer lanes
 constexpr int kHfProd = 8;                           // producer wavefronts
 constexpr int kHfDepth = 4;                          // stages of gathers in flight per producer (and of ids ahead of them)
 constexpr int kHfBlock = kWave * (1 + kHfProd);      // wavefront 0 consumes
@@ -35,6 +34,10 @@ constexpr int kHfBlock = kWave * (1 + kHfProd);      // wavefront 0 consumes
 //            configuration where "long" starts at 257 elements (arxiv-sized graph: 0.347 ms against 0.386 with PER = 4;
 //            chunked 0.290) — profiles/r4_hub_exact_timing.txt.
 constexpr int64_t kHfHeavyFrom = 4096;               // average long-row length from which PER = 4 is launched
+// LOG_LPE = log2 of the lanes that move one element's slab: 4 -> 16 lanes x 16 bytes = 64-column slabs, four elements per
+// load instruction; 2 -> 4 lanes = 16-column slabs, SIXTEEN elements per load instruction — rows of K <= 16 columns
+// (class scores, attention logits, degree-like sums), where a 64-column slab left 14 of every 16 producer lanes idle:
+// gspmm K = 7 on the products-sized graph 1.98 ms chunked -> 3.01 ms with 64-column slabs -> see profiles/r4_hub_exact_timing.txt.
 
 // The stage barrier.  __syncthreads() is a workgroup-scope release + acquire fence around s_barrier, and on gfx9 the
 // release waits for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)) — the producers' gathers of the
@@ -74,10 +77,12 @@ template <int PER> struct HfIds { int32_t row[PER], wi[PER]; };       // source 
 
 // VEC4: K % 4 == 0, 16-byte aligned base and row stride — a lane moves its four columns as one 16-byte load.
 // WPC (multi-head weights only): the head changes inside a quad (C % 4 != 0) — a weight per column.
-template <int MODE, bool VEC4, bool WPC, int PER>
+template <int MODE, bool VEC4, bool WPC, int PER, int LOG_LPE>
 __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args a) {
-  constexpr int kHfPer = PER, kHfStage = kHfProd * PER * 4;
-  __shared__ float buf[2][kHfStage][kHfCols];        // 2 x 32 KiB (PER = 4) / 2 x 16 KiB (PER = 2)
+  constexpr int kLpe = 1 << LOG_LPE, kEpl = kWave / kLpe;          // lanes per element, elements per load instruction
+  constexpr int kHfCols = kLpe * 4;                                 // columns per slab
+  constexpr int kHfPer = PER, kHfStage = kHfProd * PER * kEpl;      // elements per LDS half
+  __shared__ float buf[2][kHfStage][kHfCols];        // 2 x 32 KiB (PER = 4, 64 columns) ... 2 x 16 KiB
   constexpr int NW = WPC ? 4 : 1;
   const int64_t slabs = (a.K + kHfCols - 1) / kHfCols;
   const int64_t j = block_id() / slabs, slab = block_id() - j * slabs;
@@ -91,10 +96,10 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
   const int64_t nstp = (nst + 3) & ~(int64_t)3;      // stages incl. the padding of the last group of four (see below)
   if (tid >= kWave) {
     // ---- producers ------------------------------------------------------------------------------------------------
-    const int pw = (tid >> 6) - 1, eg = lane >> 4, piece = lane & 15;
+    const int pw = (tid >> 6) - 1, eg = lane >> LOG_LPE, piece = lane & (kLpe - 1);
     const bool live = piece * 4 < ncol;
     const int cl = live ? piece * 4 : 0;                        // first of this lane's four columns inside the slab
-    const int e0 = pw * (kHfPer * 4) + eg;                      // this lane's elements of a stage: e0 + 4 i
+    const int e0 = pw * (kHfPer * kEpl) + eg;                   // this lane's elements of a stage: e0 + kEpl i
     const float *xs = a.x + c0 + cl;
     int64_t hd[NW];                                             // head of each weight this lane applies
 #pragma unroll
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
     auto load_idx = [&](HfIds<PER> &t, int64_t st) {                  // ids of stage st (positions clamped into the row)
 #pragma unroll
       for (int i = 0; i < kHfPer; ++i) {
-        int64_t p = beg + st * kHfStage + e0 + 4 * i;
+        int64_t p = beg + st * kHfStage + e0 + kEpl * i;
         p = p < end ? p : end - 1;
         if (MODE == HUB_SEG) t.row[i] = (int32_t)p;
         else if (MODE == HUB_SEG_PERM) t.row[i] = a.perm[p];
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
           v.w = __fmul_rn(wv.w[i][WPC ? 3 : 0], v.w);
         }
         // every lane parks at its own columns: elements past the row's end and columns past the slab's end are never read
-        *reinterpret_cast<float4 *>(&buf[b][e0 + 4 * i][piece * 4]) = v;
+        *reinterpret_cast<float4 *>(&buf[b][e0 + kEpl * i][piece * 4]) = v;
       }
     };
     static_assert(kHfDepth == 4, "the stage loop below is unrolled for four slots");
@@ -243,19 +248,24 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *f
     s = side->stream;
     *forked = true;
   }
-  const int64_t slabs = ceil_div(a.K, (int64_t)kHfCols);
+  const bool narrow = a.K <= 16;                       // 16-column slabs, 4 lanes per element
+  const int64_t slabs = ceil_div(a.K, (int64_t)(narrow ? 16 : 64));
   const int64_t grid = a.n_long * slabs;
   const bool vec4 = a.K % 4 == 0 && a.x_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0;
   const bool seg = a.col == nullptr, has_w = !seg && a.w != nullptr;
   const bool w_perm = has_w && !a.w_by_pos && a.perm != nullptr;
   const bool heads = has_w && a.C > 0, wpc = heads && a.C % 4 != 0;
   const bool heavy = a.avg_long_len >= kHfHeavyFrom;
-#define GGL_HF(M, W)                                                                           \
-  do {                                                                                         \
-    if (vec4 && heavy) GGL_LAUNCH((hub_rows_f32_kernel<M, true, W, 4>), grid, kHfBlock, s, a);       \
-    else if (vec4) GGL_LAUNCH((hub_rows_f32_kernel<M, true, W, 2>), grid, kHfBlock, s, a);           \
-    else if (heavy) GGL_LAUNCH((hub_rows_f32_kernel<M, false, W, 4>), grid, kHfBlock, s, a);         \
-    else GGL_LAUNCH((hub_rows_f32_kernel<M, false, W, 2>), grid, kHfBlock, s, a);                    \
+#define GGL_HF2(M, W, V)                                                                          \
+  do {                                                                                             \
+    if (narrow) GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 2, 2>), grid, kHfBlock, s, a);            \
+    else if (heavy) GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 4, 4>), grid, kHfBlock, s, a);        \
+    else GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 2, 4>), grid, kHfBlock, s, a);                   \
+  } while (0)
+#define GGL_HF(M, W)                                   \
+  do {                                                 \
+    if (vec4) GGL_HF2(M, W, true);                     \
+    else GGL_HF2(M, W, false);                         \
   } while (0)
   if (seg) {
     if (a.perm) GGL_HF(HUB_SEG_PERM, false); else GGL_HF(HUB_SEG, false);
@@ -269,6 +279,7 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *f
     if (w_perm) GGL_HF(HUB_BSPMM_WP, true); else GGL_HF(HUB_BSPMM_W, true);
   }
 #undef GGL_HF
+#undef GGL_HF2
   GGL_LAUNCH_CHECK();
   if (*forked) GGL_HIP_CHECK(hipEventRecord(side->join, side->stream));
   return GGL_OK;

@@ -311,6 +311,41 @@ extern "C" int64_t ggl_get_option(const char *name) {
   return -1;
 }
 
+// ---- host policy, one copy (see the header) ----------------------------------------------------------------------------
+extern "C" int64_t ggl_policy_chunk(int64_t E) {
+  static const int64_t forced = env_i64("GGL_LONG_ROW", 0);
+  if (forced > 0) return forced;
+  int64_t c = 4096;
+  while (c > 256 && c * (256 * 32) > E) c >>= 1;
+  return c;
+}
+extern "C" int64_t ggl_policy_spmm_width(int reduce, int64_t K, int64_t E, int64_t N_in) {
+  if (K <= 0 || E < 8 * N_in) return K;
+  if (reduce == 0) {
+    if (K > 256 && K % 64 != 0) return K + (64 - K % 64);
+    if (K % 4 != 0 && K >= 8) return K + (4 - K % 4);
+    return K;
+  }
+  if (K > 128 && K % 4 != 0) return K + (4 - K % 4);
+  return K;
+}
+extern "C" int64_t ggl_policy_head_channels(int64_t C, int64_t E, int64_t N_in) {
+  return (C % 4 != 0 && C >= 8 && E >= 8 * N_in) ? C + (4 - C % 4) : C;
+}
+extern "C" int ggl_policy_mean_bwd_prescale(int64_t E, int64_t N_in) { return E >= 4 * N_in ? 1 : 0; }
+extern "C" int ggl_policy_gradw_sorted(int64_t C) { return (C % 4 == 0 && C > 16) ? 1 : 0; }
+extern "C" int64_t ggl_policy_xcd_run_rows(int64_t E, double locality) {
+  static const int64_t forced = env_i64("GGL_XCD_RUN_ROWS", -1);
+  if (forced >= 0) return forced;
+  return (E >= ((int64_t)1 << 22) && locality > 0.5) ? 2048 : 0;
+}
+extern "C" int ggl_policy_row_order(int64_t *window_host, int64_t *heavy_host) {
+  static const int64_t window = env_i64("GGL_ROW_ORDER_WINDOW", 2048);
+  if (window_host) *window_host = window;
+  if (heavy_host) *heavy_host = 1024;
+  return GGL_OK;
+}
+
 extern "C" size_t ggl_plan_workspace_bytes(int64_t E, int64_t N) {
   if (E < 0 || N < 0) return 0;
   size_t b = 256;                                        // flags

@@ -14,8 +14,10 @@
 // per op, same formulas as the reference's (segment_sum.cpp:43-54, segment_mean.cpp:44-63, segment_max.cpp:48-61,
 // gspmm.cpp:57-80,...).  Meta: shapes only.
 //
-// What lives here besides the registrations is the HOST POLICY of the op library, the same one gammagl_amd/ops.py
-// applies (the two are checked against each other bit for bit, tests/test_torch_cpp.py):
+// What lives here besides the registrations is the host side of the op library, the same one gammagl_amd/ops.py
+// implements (the two are checked against each other bit for bit, tests/test_torch_cpp.py).  The launch DECISIONS —
+// thresholds, padded widths, which walk a gradient takes — are not written twice: both hosts ask the kernel library
+// (ggl_policy_*, include/ggl_mpops.h); what each host owns is the plumbing around them:
 //   * plan cache keyed on (storage, offset, shape, version, N) of the id tensor, entries die with the storage;
 //   * long-row threshold = f(E) (auto_chunk), row hand-out order in id windows, XCD runs for graphs with locality;
 //   * rows of K % 4 != 0 / K > 256 && K % 64 != 0 floats aggregate on one padded copy;
@@ -59,7 +61,9 @@ using torch::autograd::variable_list;
   X(ggl_gat_partial_bytes) X(ggl_gat_fused_fwd) X(ggl_gat_fused_bwd_dst) X(ggl_gat_fused_bwd_src)                      \
   X(ggl_gat_fast_supported) X(ggl_gat_fast_fwd) X(ggl_gat_fast_bwd) X(ggl_bias_act_fwd)                                \
   X(ggl_bias_act_bwd_workspace_bytes) X(ggl_bias_act_bwd) X(ggl_spmm_epi_ex) X(ggl_segment_epi)                        \
-  X(ggl_sample_hop_workspace_bytes) X(ggl_sample_hop)
+  X(ggl_sample_hop_workspace_bytes) X(ggl_sample_hop)                                                                \
+  X(ggl_policy_chunk) X(ggl_policy_spmm_width) X(ggl_policy_head_channels) X(ggl_policy_mean_bwd_prescale)            \
+  X(ggl_policy_gradw_sorted) X(ggl_policy_xcd_run_rows) X(ggl_policy_row_order)
 
 struct Api {
   void *handle = nullptr;
@@ -148,15 +152,7 @@ static int64_t env_int(const char *name, int64_t dflt) {
 // ---------------------------------------------------------------------------------------------------------------
 // Plans (struct ggl_segplan + the tensors that own its arrays)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int64_t kMaxChunk = 4096, kMinChunk = 256, kResidentWaves = 256 * 32;   // MI355X: 256 CUs x 32 wavefronts
-
-static int64_t auto_chunk(int64_t E) {   // the largest power of two <= E / resident waves, in [256, 4096]
-  static const int64_t forced = env_int("GGL_LONG_ROW", 0);
-  if (forced > 0) return forced;
-  int64_t c = kMaxChunk;
-  while (c > kMinChunk && c * kResidentWaves > E) c >>= 1;
-  return c;
-}
+static int64_t auto_chunk(const Api &a, int64_t E) { return a.ggl_policy_chunk(E); }   // (GGL_LONG_ROW is read there)
 
 static Tensor row_order_of(const Tensor &counts);
 
@@ -207,11 +203,12 @@ static std::atomic<uint64_t> g_plans_built{0}, g_plan_hits{0};
 
 // rows by descending length inside windows of consecutive ids, the heavy ones first (ops.py Engine._row_order)
 static Tensor row_order_of(const Tensor &counts) {
-  static const int64_t W = env_int("GGL_ROW_ORDER_WINDOW", 2048);
+  int64_t W = 2048, heavy = 1024;
+  api_for(counts.device()).ggl_policy_row_order(&W, &heavy);
   const int64_t N = counts.size(0);
   if (W <= 0 || N <= W) return at::argsort(counts, /*stable=*/true, 0, /*descending=*/true).to(at::kInt);
   Tensor ar = at::arange(N, counts.options());
-  Tensor group = at::where(counts >= 1024, at::zeros_like(ar), at::floor_divide(ar, W) + 1);
+  Tensor group = at::where(counts >= heavy, at::zeros_like(ar), at::floor_divide(ar, W) + 1);
   Tensor key = at::bitwise_or(at::bitwise_left_shift(group, 32),
                               (int64_t(1) << 31) - counts.clamp_max((int64_t(1) << 31) - 1));
   return at::argsort(key, /*stable=*/true).to(at::kInt);
@@ -240,7 +237,7 @@ static std::shared_ptr<SegPlan> build_plan(const Tensor &ids_in, int64_t N) {
   auto p = std::make_shared<SegPlan>();
   p->N = N;
   p->E = ids.size(0);
-  p->chunk = auto_chunk(p->E);
+  p->chunk = auto_chunk(a, p->E);
   auto i64 = ids.options().dtype(at::kLong);
   p->rowptr = at::empty({N + 1}, i64);
   Tensor perm = at::empty({std::max<int64_t>(p->E, 1)}, i64.dtype(at::kInt));
@@ -369,9 +366,9 @@ struct GraphPlan {
     return near.to(at::kFloat).mean().item<double>();
   }
   void schedule() {   // XCD runs where the node order carries locality (ops.py GraphPlan._schedule)
-    static const int64_t knob = env_int("GGL_XCD_RUN_ROWS", -1);
-    int64_t run = knob;
-    if (run < 0) run = (E >= (int64_t(1) << 22) && locality() > 0.5) ? 2048 : 0;
+    const Api &a = api_for(fwd->rowptr.device());
+    const bool need = a.ggl_policy_xcd_run_rows(E, 1.0) > 0 || a.ggl_policy_xcd_run_rows(E, 0.0) > 0;
+    const int64_t run = a.ggl_policy_xcd_run_rows(E, need ? locality() : 0.0);   // (locality() is one host read)
     fwd->xcd_run = run;
     if (bwd) bwd->xcd_run = run;
   }
@@ -511,15 +508,13 @@ static std::pair<Tensor, Tensor> spmm_fwd(SpOp op, GraphPlan &gp, const SegPlan 
   const Api &a = api_for(dev);
   int64_t K = 1;
   for (int64_t d = 1; d < x.dim(); ++d) K *= x.size(d);
-  const bool summing = op == SpOp::Sum || op == SpOp::Mean;
-  if (summing && x.dim() == 2 && p.E >= 8 * x.size(0)) {
-    int64_t pad = 0;
-    if (K > 256 && K % 64 != 0) pad = (64 - K % 64) % 64;      // whole cache lines per 64-column block
-    else if (K % 4 != 0 && K >= 8) pad = (4 - K % 4) % 4;      // 16-byte rows for the float4 kernels
-    if (pad > 0) {
-      Tensor xp = at::constant_pad_nd(x, {0, pad});
+  if ((op == SpOp::Sum || op == SpOp::Mean || op == SpOp::Max) && x.dim() == 2) {
+    // one zero-padded copy where the kernels want whole cache lines / 16-byte rows (ggl_policy_spmm_width; ops.py _spmm_fwd)
+    const int64_t Kp = a.ggl_policy_spmm_width(op == SpOp::Max ? 1 : 0, K, p.E, x.size(0));
+    if (Kp != K) {
+      Tensor xp = at::constant_pad_nd(x, {0, Kp - K});
       auto r = spmm_fwd(op, gp, p, col, w, xp, n_out, aux);
-      return {r.first.slice(1, 0, K).contiguous(), Tensor()};
+      return {r.first.slice(1, 0, K).contiguous(), r.second.defined() ? r.second.slice(1, 0, K).contiguous() : Tensor()};
     }
   }
   Tensor out = at::empty(out_shape(x, n_out), x.options());
@@ -540,7 +535,7 @@ static std::pair<Tensor, Tensor> spmm_fwd(SpOp op, GraphPlan &gp, const SegPlan 
       return {out, arg};
     }
     case SpOp::MeanBwd:
-      if (x.dim() == 2 && p.E >= 4 * x.size(0)) {
+      if (x.dim() == 2 && a.ggl_policy_mean_bwd_prescale(p.E, x.size(0))) {
         // the division depends on the destination row only: once per row, then the plain transposed SpMM-sum
         Tensor cnt = (aux.slice(0, 1) - aux.slice(0, 0, aux.size(0) - 1)).clamp_min(1).to(at::kFloat).unsqueeze(1);
         Tensor xs = x / cnt;
@@ -646,9 +641,8 @@ static Tensor spmm_max_kernel(const Tensor &i, const c10::optional<Tensor> &w, c
   return spmm_kernel(SpOp::Max, i, w, x);
 }
 
-static bool bspmm_pads(const GraphPlan &gp, const Tensor &x) {
-  const int64_t C = x.size(2);
-  return C % 4 != 0 && C >= 8 && gp.E >= 8 * x.size(0);
+static int64_t head_pad(const GraphPlan &gp, const Tensor &x) {   // channels to append per head (ggl_policy_head_channels)
+  return api_for(x.device()).ggl_policy_head_channels(x.size(2), gp.E, x.size(0)) - x.size(2);
 }
 static void bspmm_check(const Tensor &w, const Tensor &x) {
   TORCH_CHECK(x.dim() == 3, "bspmm expects x of shape [num_nodes, heads, channels]");
@@ -660,7 +654,8 @@ static Tensor bspmm_sum_kernel(const Tensor &index, const Tensor &weight, const 
   SpArgs s = spmm_args(index, weight, x);
   bspmm_check(s.w, s.x);
   const int64_t C = s.x.size(2);
-  Tensor xin = bspmm_pads(*s.gp, s.x) ? at::constant_pad_nd(s.x, {0, (4 - C % 4) % 4}) : s.x;
+  const int64_t hp = head_pad(*s.gp, s.x);
+  Tensor xin = hp > 0 ? at::constant_pad_nd(s.x, {0, hp}) : s.x;
   Tensor out = bspmm_fwd(*s.gp, *s.gp->fwd, s.gp->col, s.w, xin, s.gp->N_dst);
   return xin.size(2) == C ? out : out.slice(2, 0, C).contiguous();
 }
@@ -749,14 +744,14 @@ static std::tuple<Tensor, Tensor> bspmm_sum_backward_kernel(const Tensor &index,
   Tensor w = weight.contiguous();
   auto gp = bwd_plan(index, x_in.size(0));
   const int64_t C0 = x_in.size(2), H = x_in.size(1);
-  const int64_t pad = bspmm_pads(*gp, x_in) ? (4 - C0 % 4) % 4 : 0;
+  const int64_t pad = head_pad(*gp, x_in);
   Tensor x = (pad > 0 ? at::constant_pad_nd(x_in, {0, pad}) : x_in).contiguous();
   Tensor g = (pad > 0 ? at::constant_pad_nd(grad, {0, pad}) : grad).contiguous();
   const int64_t C = C0 + pad;
   Tensor gx = bspmm_fwd(*gp, *gp->bwd, gp->colT, w, g, gp->N_src);
   Tensor gw = at::empty_like(w);
   void *st = stream_of(g.device());
-  if (C % 4 == 0 && C > 16) {   // along the destination-sorted plan, strips staged through LDS (edgedot.hip)
+  if (a.ggl_policy_gradw_sorted(C)) {   // along the destination-sorted plan, strips staged through LDS (edgedot.hip)
     gp->need_rowidx(index);
     const size_t sb = a.ggl_bspmm_grad_w_sorted_scratch_bytes(gp->E, gp->N_dst, H, C);
     Tensor scratch = sb > 0 ? at::empty({static_cast<int64_t>(sb / 4)}, g.options()) : Tensor();
@@ -797,10 +792,6 @@ static void reseed() {
   g_rng.clear();
 }
 
-static bool gat_pads(const GraphPlan &gp, const Tensor &x) {   // 41 classes per head -> 44: 16-byte slices in every walk
-  const int64_t C = x.size(2);
-  return C % 4 != 0 && C >= 8 && gp.E >= 8 * x.size(0);
-}
 static void gat_check(const Tensor &el, const Tensor &er, const Tensor &x) {
   same_device({&el, &er, &x});
   f32("el", el); f32("er", er); f32("x", x);
@@ -927,7 +918,7 @@ static std::shared_ptr<SegPlan> plan_from_rowptr(const Tensor &rowptr, int64_t E
   auto p = std::make_shared<SegPlan>();
   p->N = rowptr.size(0) - 1;
   p->E = E;
-  p->chunk = auto_chunk(E);
+  p->chunk = auto_chunk(a, E);
   p->rowptr = rowptr.to(at::kLong).contiguous();
   if (p->rowptr.data_ptr() == rowptr.data_ptr()) p->rowptr = p->rowptr.clone();   // the plan keeps its OWN copy
   p->sorted = true;
@@ -1284,8 +1275,9 @@ static Tensor gat_fused_autograd(const Tensor &index, const Tensor &el, const Te
   const int64_t n = num_nodes.has_value() ? *num_nodes : x.size(0), C = x.size(2);
   // 41 classes per head: one zero-padded copy keeps every walk on 16-byte slices (ops.py Engine.gat_fused); the pad
   // channels aggregate to zero and are dropped — pad and slice are ordinary differentiable ops
-  if (C % 4 != 0 && C >= 8 && index.dim() == 2 && index.size(1) >= 8 * x.size(0)) {
-    Tensor xp = at::constant_pad_nd(x, {0, (4 - C % 4) % 4});
+  const int64_t Cp = index.dim() == 2 ? api_for(x.device()).ggl_policy_head_channels(C, index.size(1), x.size(0)) : C;
+  if (Cp != C) {
+    Tensor xp = at::constant_pad_nd(x, {0, Cp - C});
     return GatFn::apply(index, el, er, xp, slope, n, p).slice(2, 0, C);
   }
   return GatFn::apply(index, el, er, x, slope, n, p);
@@ -1322,8 +1314,9 @@ static Tensor gat_fused_csr_autograd(const Tensor &rp, const Tensor &ci, const T
                                      const Tensor &el, const Tensor &er, const Tensor &x, double slope, double p) {
   gat_check(el, er, x);
   const int64_t C = x.size(2);
-  if (C % 4 != 0 && C >= 8 && ci.size(0) >= 8 * x.size(0)) {
-    Tensor xp = at::constant_pad_nd(x, {0, (4 - C % 4) % 4});
+  const int64_t Cp = api_for(x.device()).ggl_policy_head_channels(C, ci.size(0), x.size(0));
+  if (Cp != C) {
+    Tensor xp = at::constant_pad_nd(x, {0, Cp - C});
     return GatCsrFn::apply(rp, ci, cp, ri, pm, el, er, xp, slope, p).slice(2, 0, C);
   }
   return GatCsrFn::apply(rp, ci, cp, ri, pm, el, er, x, slope, p);

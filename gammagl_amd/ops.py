@@ -33,8 +33,6 @@ _DTYPE_CODE = {
 _FLOAT_DTYPES = (torch.float16, torch.bfloat16, torch.float32, torch.float64)
 
 DEFAULT_CHUNK = int(os.environ.get("GGL_LONG_ROW", "0"))  # 0 = automatic, see Engine.auto_chunk
-MAX_CHUNK, MIN_CHUNK = 4096, 256
-RESIDENT_WAVES = 256 * 32  # MI355X: 256 CUs x 32 wavefronts in flight
 
 
 def _ptr(t):
@@ -154,8 +152,9 @@ class GraphPlan:
         and runs of heavy rows unbalance the XCDs), hence the test (profiles/r3_xcd_run_swizzle.txt)."""
         eng = self.engine
         run = int(eng.xcd_run_rows)
-        if run < 0:       # automatic
-            run = 2048 if (self.E >= (1 << 22) and self.locality() > 0.5) else 0
+        if run < 0:       # automatic: the library's rule on this plan's locality (locality() is one host read)
+            need = int(eng.lib.ggl_policy_xcd_run_rows(self.E, 1.0)) > 0 or int(eng.lib.ggl_policy_xcd_run_rows(self.E, 0.0)) > 0
+            run = int(eng.lib.ggl_policy_xcd_run_rows(self.E, self.locality() if need else 0.0))
         self.fwd.xcd_run = run
         if self._bwd is not None:
             self._bwd.xcd_run = run
@@ -304,11 +303,13 @@ class Engine:
         self.hub16_overlap = True   # ... launched on a side stream beside the walk over the other rows (A/B switch)
         self._side = {}
         self.mean_bwd_prescale = True  # spmm mean backward = rows pre-divided by their count + plain SpMM-sum (A/B switch)
-        self.row_order_window = int(os.environ.get("GGL_ROW_ORDER_WINDOW", "2048"))   # see _row_order (0 = global sort)
-        self.row_order_heavy = 1024
-        self.xcd_run_rows = int(os.environ.get("GGL_XCD_RUN_ROWS", "-1"))   # -1 = per graph (GraphPlan._schedule), 0 = off
+        # the launch policy's constants come from the kernel library (ggl_policy_*, include/ggl_mpops.h): ONE copy for this
+        # host and the C++ one (csrc/torch/ggl_torch.cpp); the attributes below are A/B overrides for tests and probes
+        win, heavy = ctypes.c_int64(0), ctypes.c_int64(0)
+        lib.ggl_policy_row_order(ctypes.byref(win), ctypes.byref(heavy))
+        self.row_order_window, self.row_order_heavy = int(win.value), int(heavy.value)   # see _row_order (0 = global sort)
+        self.xcd_run_rows = -1   # -1 = per graph (ggl_policy_xcd_run_rows on the plan's locality), >= 0 forces it
         self.gradw_sorted = True    # bspmm weight gradient along the sorted plan with LDS-staged strips (A/B switch)
-        self.gradw_sorted_min_c = 16   # ... for heads wider than this many channels (narrow strips: thread-per-item)
         self._make_functions()
 
     def clear_caches(self):
@@ -375,18 +376,11 @@ class Engine:
         if lo < 0 or hi >= n:
             raise IndexError(f"node id out of range [0, {n})")
 
-    @staticmethod
-    def auto_chunk(E):
-        """Long-row threshold for a plan of E elements.  One wavefront walks a row (or a chunk of a long
-        row) serially, so the longest unsplit walk is the critical path of a launch: 4096 elements is
-        best when the launch is many waves deep (products-sized: E / 4096 >> resident waves) but on an
-        arxiv-sized graph it leaves the chip waiting for a few hubs (measured K=256 SpMM-sum 0.685 ms at
-        4096 vs 0.284 ms at 256, profiles/r1_arxiv_chunk_sweep.txt).  Rule: the largest power of two
-        <= E / RESIDENT_WAVES, clamped to [256, 4096]."""
-        c = MAX_CHUNK
-        while c > MIN_CHUNK and c * RESIDENT_WAVES > E:
-            c >>= 1
-        return c
+    def auto_chunk(self, E):
+        """Long-row threshold for a plan of E elements: `ggl_policy_chunk` (include/ggl_mpops.h) — the ONE copy of the
+        rule both hosts use (the largest power of two <= E / resident wavefronts, clamped to [256, 4096]:
+        profiles/r1_arxiv_chunk_sweep.txt)."""
+        return int(self.lib.ggl_policy_chunk(int(E)))
 
     def build_plan(self, ids, N, chunk=None):
         """Sort `ids` (int64 [E]) into a SegPlan.  Synchronous; run once per edge list."""
@@ -658,22 +652,17 @@ class Engine:
         """op in sum/mean/max/mean_bwd/max_bwd.  x [N_in, *]; returns out [n_out, *] (+argsrc)."""
         dev = x.device
         K = int(math.prod(x.shape[1:]))
-        if op in ("sum", "mean") and x.dim() == 2 and K > 256 and K % 64 != 0 and plan.E >= 8 * x.shape[0]:
-            # rows wider than 256 columns that are not whole cache lines (602 Reddit features: 2408-byte rows): the
-            # 64-column blocks of such a matrix straddle lines (a 256-byte slice touches 2.9 lines on average instead
-            # of 2).  One copy padded to a multiple of 64 columns makes every block two aligned lines
-            # (products-sized graph, K = 602: 55 -> 42 ms, copies included); the pad columns sum to zero and are dropped.
-            xp = torch.nn.functional.pad(x, (0, (-K) % 64))
-            out, _ = self._spmm_fwd(op, plan, col, w, xp, n_out, perm_override, aux)
-            return out[:, :K].contiguous(), None
-        if op in ("sum", "mean") and x.dim() == 2 and K % 4 != 0 and K >= 8 and plan.E >= 8 * x.shape[0]:
-            # class-count widths (47, 41, 7 ...): rows of 4K bytes are not 16-byte aligned, so the float4
-            # kernel cannot read them.  One padded copy of x (N*K floats) is far cheaper than walking E
-            # rows with dword loads (products-sized graph, K = 47: 9.3 -> 5.8 ms); the sums of the real
-            # columns are unchanged, the pad columns are dropped.
-            xp = torch.nn.functional.pad(x, (0, (-K) % 4))
-            out, _ = self._spmm_fwd(op, plan, col, w, xp, n_out, perm_override, aux)
-            return out[:, :K].contiguous(), None
+        if op in ("sum", "mean", "max") and x.dim() == 2:
+            # ggl_policy_spmm_width (include/ggl_mpops.h): rows wider than 256 columns that are not whole cache lines
+            # (602 Reddit features) -> a multiple of 64 for the 64-column blocks (products-sized K = 602: 55 -> 42 ms);
+            # class-count widths (47, 41, 7 ...) -> a multiple of 4 for the float4 kernels (K = 47: 9.3 -> 5.8 ms); the
+            # max walk of wide rows that are not 16-byte pieces -> a multiple of 4 (K = 602: 69 -> 60 ms).  One
+            # zero-padded copy of x; the pad columns (values and argmax) are dropped.
+            Kp = int(self.lib.ggl_policy_spmm_width(1 if op == "max" else 0, K, plan.E, int(x.shape[0])))
+            if Kp != K:
+                xp = torch.nn.functional.pad(x, (0, Kp - K))
+                out, arg = self._spmm_fwd(op, plan, col, w, xp, n_out, perm_override, aux)
+                return out[:, :K].contiguous(), (arg[:, :K].contiguous() if arg is not None else None)
         out = torch.empty((n_out,) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
         st = self._stream(dev)
         part = self._partial(plan, torch.float32, K, op == "max", dev)
@@ -692,7 +681,7 @@ class Engine:
                                        _ptr(out), _ptr(arg), st))
             return out, arg
         elif op == "mean_bwd":
-            if self.mean_bwd_prescale and x.dim() == 2 and plan.E >= 4 * x.shape[0]:
+            if self.mean_bwd_prescale and x.dim() == 2 and self.lib.ggl_policy_mean_bwd_prescale(plan.E, int(x.shape[0])):
                 # gx[src] += (g[dst] / count[dst]) * w (spmm_mean_cpu.cpp:90-100): the division depends on the
                 # destination row only, so it is done ONCE per row (the same rounded divide on the same operands) and
                 # the walk is the plain transposed SpMM-sum — no per-edge degree lookup (a random 16-byte read, i.e. one
@@ -891,7 +880,7 @@ class Engine:
                 gw = torch.empty_like(w)
                 # a plan built from the caller's CSR has no COO edge list to walk (gp.index is None): it always takes the
                 # sorted route, whose plain kernel covers any channel count
-                if gp.index is None or (eng.gradw_sorted and C % 4 == 0 and C > eng.gradw_sorted_min_c):
+                if gp.index is None or (eng.gradw_sorted and eng.lib.ggl_policy_gradw_sorted(C)):
                     # along the destination-sorted forward plan, strips staged through LDS (edgedot.hip): the g rows
                     # of a batch are a handful of rows, only x[src] is a random gather — and a coalesced one
                     sb = eng.lib.ggl_bspmm_grad_w_sorted_scratch_bytes(gp.E, gp.N_dst, H, C)
@@ -1326,10 +1315,11 @@ class Engine:
         if weight is None or weight.dim() != 2 or weight.shape[1] != x.shape[1]:
             raise RuntimeError("bspmm expects weight of shape [num_edges, heads]")
         C = int(x.shape[2])
-        if C % 4 != 0 and C >= 8 and gp.E >= 8 * x.shape[0]:
+        Cp = int(self.lib.ggl_policy_head_channels(C, gp.E, int(x.shape[0])))
+        if Cp != C:
             # odd channel counts (41 classes per head ...): one zero-padded copy of x keeps the row walks and the
             # per-edge weight-gradient dots on 16-byte slices; the pad channels sum to zero and are dropped
-            xp = torch.nn.functional.pad(x, (0, (-C) % 4))
+            xp = torch.nn.functional.pad(x, (0, Cp - C))
             return self.BSpMMSum.apply(gp, weight, xp.contiguous())[:, :, :C]
         return self.BSpMMSum.apply(gp, weight, x)
 
@@ -1345,10 +1335,11 @@ class Engine:
         if not 0.0 <= p < 1.0:
             raise ValueError("dropout_rate must be in [0, 1)")
         C = int(x.shape[2])
-        if C % 4 != 0 and C >= 8 and gp.E >= 8 * x.shape[0]:
+        Cp = int(self.lib.ggl_policy_head_channels(C, gp.E, int(x.shape[0])))
+        if Cp != C:
             # e.g. 41 classes per head: one zero-padded copy of x ([N,H,44]) keeps every walk on 16-byte slices
             # (Reddit-sized, 8 x 41: forward 50 -> 20 ms); the pad channels aggregate to zero and are dropped
-            xp = torch.nn.functional.pad(x, (0, (-C) % 4))
+            xp = torch.nn.functional.pad(x, (0, Cp - C))
             out = self.GATFused.apply(gp, el.contiguous(), er.contiguous(), xp.contiguous(), negative_slope, p)
             return out[:, :, :C]
         return self.GATFused.apply(gp, el.contiguous(), er.contiguous(), x.contiguous(),

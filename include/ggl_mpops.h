@@ -433,6 +433,38 @@ int ggl_block_transpose(const int64_t *rowptr, const int32_t *col, int64_t N_dst
 int ggl_set_option(const char *name, int64_t value);
 int64_t ggl_get_option(const char *name);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host policy, ONE copy (round 4).  Two hosts drive these kernels — gammagl_amd/ops.py (ctypes) and
+ * gammagl_amd/csrc/torch/ggl_torch.cpp (TORCH_LIBRARY) — and both must take the same launch decisions (they are checked
+ * against each other bit for bit).  The decisions live here, measured constants and their reasons included; the hosts
+ * only ask.  Pure host functions, no device access.
+ * ---------------------------------------------------------------------------------------------- */
+/* long-row threshold (= elements per chunk) of a plan of E elements: the largest power of two <= E / (256 CUs x 32
+ * resident wavefronts), clamped to [256, 4096] — one wavefront walks a row serially, so on a small graph a 4096-element
+ * walk is the whole launch (arxiv-sized K = 256 SpMM: 0.685 ms at 4096, 0.284 ms at 256).  GGL_LONG_ROW overrides. */
+int64_t ggl_policy_chunk(int64_t E);
+/* width a 2-D f32 matrix [N_in, K] is zero-padded to before an SpMM over E edges (== K: as it is).  reduce: 0 = sum /
+ * mean, 1 = max.  sum / mean: K > 256 not a multiple of 64 -> next multiple of 64 (whole cache lines per 64-column
+ * block: products-sized K = 602 55 -> 42 ms); K % 4 != 0, K >= 8 -> next multiple of 4 (16-byte rows: K = 47 9.3 -> 5.8 ms);
+ * max: K > 128 with K % 4 != 0 -> next multiple of 4 (K = 602 69 -> 60 ms).  Only where the copy is paid back:
+ * E >= 8 N_in. */
+int64_t ggl_policy_spmm_width(int reduce, int64_t K, int64_t E, int64_t N_in);
+/* channels per head a [N_in, H, C] tensor is zero-padded to for bspmm / the fused GAT (41 classes -> 44) */
+int64_t ggl_policy_head_channels(int64_t C, int64_t E, int64_t N_in);
+/* 1: the spmm-mean backward divides the rows of g by their count ONCE and runs the plain transposed SpMM-sum (same
+ * bits; products-sized K = 256 23.0 -> 15.5 ms) — where a row has edges to amortise the pass over g: E >= 4 N_in */
+int ggl_policy_mean_bwd_prescale(int64_t E, int64_t N_in);
+/* 1: the bspmm weight gradient walks the destination-sorted plan with LDS-staged strips (edgedot.hip); 0: one thread
+ * per (edge, head) in COO order (heads of <= 16 channels, or channel counts that are not multiples of 4) */
+int ggl_policy_gradw_sorted(int64_t C);
+/* rows per XCD run of a plan (0: round-robin blocks) given the share of its edges whose endpoints lie within N / 64 ids
+ * of each other: 2048 for E >= 2^22 and locality > 0.5 (planted-community graph in cluster order: K = 256 13.4 ->
+ * 10.8 ms; R-MAT orders lose 7-8 % with it).  GGL_XCD_RUN_ROWS overrides. */
+int64_t ggl_policy_xcd_run_rows(int64_t E, double locality);
+/* the row hand-out order: rows of >= *heavy elements first, longest first; the rest by length inside windows of
+ * *window consecutive ids (0: one global sort).  GGL_ROW_ORDER_WINDOW overrides the window. */
+int ggl_policy_row_order(int64_t *window_host, int64_t *heavy_host);
+
 /* Measurement aid (bench.py's roofline leg): a grid-stride pass over `n_vec4` 16-byte vectors of `src`, 16 bytes per
  * lane and four independent loads in flight — mode 0: read-only (every wavefront folds what it read into ONE float of
  * `dst`, which must hold at least 65536 floats), mode 1: copy to `dst`.  The rate it reaches is "what a streaming kernel

@@ -1845,3 +1845,37 @@ def check_cpp_fused_route(ops, eng, dev, oracle=None):
     assert outs[1][4].tolist() == [nn, ne, ovf] and ovf == 0
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1][:ne], outs[1][1][:ne]) \
         and torch.equal(outs[0][2][:ne], outs[1][2][:ne]) and torch.equal(outs[0][3][:nn], outs[1][3][:nn])
+
+
+def check_round4_paths(eng, dev, oracle):
+    """Paths added in round 4: 16-byte lanes for int32 / int64 messages (K >= 16 / 8, aligned) and the zero-padded copy
+    the gspmm-max walk takes for wide rows that are not 16-byte pieces (K > 128, K % 4 != 0) — values, argmax (through the
+    gradient) and the backward walk, bit for bit against the oracle."""
+    rng = np.random.default_rng(77)
+    N, E = 37, 900
+    ids = rng.integers(0, N, size=E).astype(np.int64)
+    ids[:300] = 4
+    it = to_t(ids, dev)
+    for dt, widths in ((np.int32, (16, 64, 100, 17)), (np.int64, (8, 32, 50, 7))):
+        for K in widths:
+            x = rng.integers(-1000, 1000, size=(E, K)).astype(dt)
+            xt = to_t(x, dev)
+            assert_same(to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids, N), f"{dt.__name__} sum K{K}")
+            assert_same(to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids, N), f"{dt.__name__} mean K{K}")
+            mx, arg = eng.segment_max_with_arg(xt, it, N)
+            omx, oarg = oracle.segment_max(x, ids, N)
+            assert_same(to_np(mx), omx, f"{dt.__name__} max K{K}")
+            assert_same(to_np(arg), oarg, f"{dt.__name__} argmax K{K}")
+    N, E = 30, 600
+    for K in (130, 201, 602):
+        index = np.stack([rng.integers(0, N, size=E), rng.integers(0, N, size=E)]).astype(np.int64)
+        index[1, :200] = 2
+        w = rng.standard_normal(E).astype(np.float32)
+        x = (rng.integers(-4, 5, size=(N, K)) * 0.25).astype(np.float32)        # ties for the argmax
+        go = rng.standard_normal((N, K)).astype(np.float32)
+        xt = to_t(x, dev).requires_grad_(True)
+        y = eng.c_spmm_max(to_t(index, dev), to_t(w, dev), xt)
+        y.backward(to_t(go, dev))
+        oy, oarg = oracle.spmm_max_fwd(index, w, x)
+        assert_same(to_np(y), oy, f"spmm max K{K} (padded walk)")
+        np.testing.assert_allclose(to_np(xt.grad), oracle.spmm_max_bwd(index, w, go, oarg), rtol=1e-5, atol=1e-5)

@@ -154,3 +154,7 @@ def test_weight_dtype_guard(eng):
 
 def test_static_shape_block_sampler(eng, oracle):
     pc.check_block_sampler(eng, DEV, oracle)
+
+
+def test_int_vector_lanes_and_padded_max_walk(eng, oracle):
+    pc.check_round4_paths(eng, DEV, oracle)

@@ -989,3 +989,7 @@ def test_multi_hop_neighbor_sample(eng, dev, oracle):
     from gammagl_amd.compat import _sparse_cuda
 
     pc.check_neighbor_sample(_sparse_cuda.cuda_torch_neighbor_sample, dev, oracle)
+
+
+def test_int_vector_lanes_and_padded_max_walk(eng, dev, oracle):
+    pc.check_round4_paths(eng, dev, oracle)
