@@ -583,7 +583,9 @@ def run_sage(args, dev, rank, world, eng=None):
     t_gen = time.perf_counter() - t0
     batches = [torch.randperm(n, generator=g, device=dev)[:B].contiguous() for _ in range(max(args.steps, 1))]
     seeds = batches[0].clone()
-    graphed = world == 1 and getattr(args, "hipgraph", "auto") != "off"   # (off: the offline GEMM selection pass)
+    # world == 1: the whole step is one hipGraph; replicas: two graphs around the eager gradient all-reduce
+    # (SAGEBlockTrainer.capture); --hipgraph off: everything eager (the offline GEMM selection pass)
+    graphed = getattr(args, "hipgraph", "auto") != "off" and dev.type == "cuda"
     if graphed:
         tr.capture(x, y, seeds)
 
@@ -627,8 +629,9 @@ def run_sage(args, dev, rank, world, eng=None):
            "config": {"workload": f"sage-minibatch: products-sized R-MAT N={n}, E={int(ei.shape[1])}, GraphSAGE {f_in}->"
                                   f"{args.hidden}->{n_cls}, SAGEConv(mean), {B} seeds/batch/GPU, fan-out [25,10]; a step = "
                                   f"sample 2 hops on the device + gather + fwd + bwd + Adam"
-                                  + (" as ONE replayed hipGraph" if graphed else
-                                     (", eager launches" if world == 1 else ", eager replicas + gradient all-reduce")),
+                                  + (" as ONE replayed hipGraph" if graphed and world == 1 else
+                                     (", two replayed hipGraphs around the replicas' eager gradient all-reduce" if graphed else
+                                      (", eager launches" if world == 1 else ", eager replicas + gradient all-reduce"))),
                       "seeds_per_s": world * B * args.steps / dt, "block_valid_src_rows_edges": valid,
                       "block_capacities": [list(c) for c in caps], "overflowed_hops": bs.overflow_count(),
                       "parallelism": f"{world} replica(s)", "setup_s": round(t_gen, 2), "loss": float(loss)},

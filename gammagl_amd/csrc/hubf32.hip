@@ -255,7 +255,9 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *f
   const bool seg = a.col == nullptr, has_w = !seg && a.w != nullptr;
   const bool w_perm = has_w && !a.w_by_pos && a.perm != nullptr;
   const bool heads = has_w && a.C > 0, wpc = heads && a.C % 4 != 0;
-  const bool heavy = a.avg_long_len >= kHfHeavyFrom;
+  // (a weight per column costs 48 more registers per lane at PER = 4: those rare shapes — heads whose channel count is
+  //  not a multiple of 4 — take the light configuration, which does not spill)
+  const bool heavy = a.avg_long_len >= kHfHeavyFrom && !(a.C > 0 && a.C % 4 != 0 && a.w != nullptr);
 #define GGL_HF2(M, W, V)                                                                          \
   do {                                                                                             \
     if (narrow) GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 2, 2>), grid, kHfBlock, s, a);            \

@@ -268,6 +268,32 @@ class PartitionedGraph:
         return _HaloAggregate.apply(h, self, bias, bool(relu), p, bool(halo_included))
 
 
+def _chunked_when_partitioned(fn):
+    """Run one forward / backward of a partitioned aggregate with the f32 hub rows CHUNKED (library option
+    `exact_long_rows` = 0 for the duration, restored afterwards).  A row of a partitioned graph is the sum of two launches —
+    its local-source edges, then its halo-source edges added on top — so the reference's serial order is out of reach
+    whatever a single launch does, and the serial hub walk (hubf32.hip) would only cost: a hub row keeps all its in-edges
+    on its owner rank, so its ~0.7 ms add chain per 64-column launch does not shrink with P while everything else does
+    (products-sized 8-way share: 18.0 ms per step with it, 17.4 chunked; profiles/r4_products_dry8_*).  One-GPU graphs
+    (pg.comm False) keep the exact walk."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *args):
+        pg = next((a for a in args if isinstance(a, PartitionedGraph)), None) or getattr(ctx, "pg", None)
+        if pg is None or not pg.comm:
+            return fn(ctx, *args)
+        lib = pg.eng.lib
+        old = int(lib.ggl_get_option(b"exact_long_rows"))
+        lib.ggl_set_option(b"exact_long_rows", 0)
+        try:
+            return fn(ctx, *args)
+        finally:
+            lib.ggl_set_option(b"exact_long_rows", old)
+
+    return wrapped
+
+
 class _HaloAggregate(torch.autograd.Function):
     @staticmethod
     def _pad4(t):
@@ -288,6 +314,7 @@ class _HaloAggregate(torch.autograd.Function):
         return [(i * w, (i + 1) * w) for i in range(n)]
 
     @staticmethod
+    @_chunked_when_partitioned
     def forward(ctx, h, pg, bias, relu, p_drop, pre=False):
         eng = pg.eng
         pre = bool(pre and pg.comm)      # halo rows already in place: NO collective, whether or not this rank has a halo
@@ -346,6 +373,7 @@ class _HaloAggregate(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_chunked_when_partitioned
     def backward(ctx, g):
         pg = ctx.pg
         eng = pg.eng
@@ -410,6 +438,7 @@ class _ConstInputLayer(torch.autograd.Function):
     (products-sized graph, 8 ranks: 0.6 ms of GEMM instead of 1.7 GB over xGMI per step)."""
 
     @staticmethod
+    @_chunked_when_partitioned
     def forward(ctx, x_cat, w, pg, bias, relu, p_drop, pad_out):
         eng, nl = pg.eng, pg.n_local
         dev = x_cat.device
@@ -439,6 +468,7 @@ class _ConstInputLayer(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_chunked_when_partitioned
     def backward(ctx, g):
         pg = ctx.pg
         eng, nl = pg.eng, pg.n_local

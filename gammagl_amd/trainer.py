@@ -1,6 +1,8 @@
 """Training-step harness: what examples/gcn/gcn_trainer.py:51-117 does per
 epoch — SemiSpvzLoss (forward, gather train rows, softmax cross-entropy) + TrainOneStep (backward,
 Adam with weight decay) — in plain torch around the gammagl_amd layers."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -146,12 +148,89 @@ class SAGEBlockTrainer:
         self.opt.step()
         return loss.detach()
 
+    # ---- replicas (world > 1): the step as TWO hipGraphs around the one collective ---------------------------------
+    def _grads_to_flat(self):
+        o = 0
+        for p in self._params:
+            n = p.numel()
+            self._flat[o:o + n].copy_(p.grad.reshape(-1))
+            o += n
+
+    def _flat_to_grads(self):
+        self._flat.div_(self.world)
+        o = 0
+        for p in self._params:
+            n = p.numel()
+            p.grad.copy_(self._flat[o:o + n].view_as(p.grad))
+            o += n
+
+    def _front(self, x, y, seeds):
+        """sample + gather + forward + loss + backward + the gradients flattened into one persistent buffer"""
+        self.net.train()
+        self.opt.zero_grad(set_to_none=True)
+        n_id, blocks, _ = self.sampler.sample(seeds, caps=self.caps)
+        logits = self.net(x.index_select(0, n_id), blocks)
+        loss = F.cross_entropy(logits[: seeds.shape[0]], y.index_select(0, seeds))
+        loss.backward()
+        self._grads_to_flat()
+        return loss.detach()
+
+    def _back(self):
+        """the averaged gradients back into place + Adam"""
+        self._flat_to_grads()
+        self.opt.step()
+
     def capture(self, x, y, seeds, warmup=3):
-        """Record step(x, y, seeds) into a hipGraph.  Afterwards: seeds.copy_(new_batch); trainer.replay()."""
-        if self.world > 1:
-            raise RuntimeError("capture() records a single-replica step; with world > 1 call step() per batch")
-        self.graph = GraphedStep(lambda: self.step(x, y, seeds), warmup=warmup)
+        """Record step(x, y, seeds) into a hipGraph.  Afterwards: seeds.copy_(new_batch); trainer.replay().
+
+        world > 1 (replicas): RCCL collectives do not record on this stack (profiles/r3_rccl_capture_attempt.txt, re-tried
+        in round 4: profiles/r4_rccl_capture_retry.txt), so the step becomes TWO graphs with the one collective between
+        them — [sample, gather, forward, loss, backward, flatten gradients] | all-reduce (eager, ~300 KB) | [unflatten,
+        Adam] — instead of ~190 eager launches per batch; both graphs share one memory pool (the second reads the
+        gradient tensors the first one's backward allocated)."""
+        if self.world == 1:
+            self.graph = GraphedStep(lambda: self.step(x, y, seeds), warmup=warmup)
+            return self.graph
+        import torch.distributed as dist
+
+        self._params = [p for p in self.net.parameters()]
+        self._flat = torch.zeros(sum(p.numel() for p in self._params), device=x.device, dtype=torch.float32)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):      # plans, sampler scratch, Adam state, RCCL channels exist before capture
+                self._front(x, y, seeds)
+                dist.all_reduce(self._flat, group=self.group)
+                self._back()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if os.environ.get("GGL_SAGE_ONE_GRAPH", "0") == "1":
+            # opt-in: the collective INSIDE the graph.  With a pre-warmed communicator (the warm-up steps above) an RCCL
+            # all-reduce does record and replay on this stack (profiles/r4_rccl_capture_retry.txt, tools/rccl_capture_retry.py);
+            # round 3's crash was the halo step's uneven all-to-all-v.  Not the default: verified on a one-rank group only.
+            self._g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g1, capture_error_mode="thread_local"):
+                self._loss = self._front(x, y, seeds)
+                dist.all_reduce(self._flat, group=self.group)
+                self._back()
+            self.graph = lambda: (self._g1.replay(), self._loss)[1]
+            return self.graph
+        pool = torch.cuda.graph_pool_handle()
+        self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1, pool=pool):
+            self._loss = self._front(x, y, seeds)
+        with torch.cuda.graph(self._g2, pool=pool):
+            self._back()
+        self.graph = self._replay_replica
         return self.graph
+
+    def _replay_replica(self):
+        import torch.distributed as dist
+
+        self._g1.replay()
+        dist.all_reduce(self._flat, group=self.group)
+        self._g2.replay()
+        return self._loss
 
     def replay(self):
         return self.graph()
