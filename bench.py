@@ -32,6 +32,16 @@ its own share of the graph (gammagl_amd.synth.rmat_partitioned): no rank holds t
   setup.py:50 never defines its OpenMP macro): ONE full-size K=256 aggregate of the benchmark graph itself
   (~35 s); `torch_fallback` = the reference's pure-torch formulation (mpops/torch.py:16-18,335-342) on an
   edge sample of the SAME graph, all host threads, median of 3;
+* parity (N = 1): the HIP aggregate on the SAME graph, weights and features the cpu_baseline leg just ran the reference on,
+  compared by oracle/parity.py (`rows_bit_exact_frac`, `max_rel_err`); the run exits 3 when it is outside the criterion;
+* secondary (default command only): one full line (value, ms_per_step, roofline, cpu_baseline, parity) per remaining
+  BASELINE config — arxiv, reddit-gat, sage-minibatch, papers-share — from child processes with short step counts;
+* roofline fields are recomputable from the line: `traffic` = fabric-side bytes (FETCH_SIZE / WRITE_SIZE, Infinity-Cache
+  hits included) of the row walk + the hub walk beside it, corrections calibrated IN THIS RUN on launches of known byte
+  counts (`pmc_calibration`); `frac_of_peak`, `frac_of_achievable` (against the streaming read this part reaches, timed
+  here), `alg_frac` (SURVEY §8d's no-reuse bytes / time / peak: may exceed 1), `frac` = min(frac_of_peak, 1);
+* N > 1: the first collectives run on their own and a failing rank prints ONE diagnostic JSON line (stage, error, env);
+  GGL_HALO_A2A=p2p switches the halo exchange to grouped isend / irecv;
 * other workloads (--workload): arxiv | tiny | products-planted (a graph with community structure, random ids vs
   partition.cluster_order) | papers-share (config 5: one rank's share of the 8-way papers100M-sized partition on
   one GPU) | reddit-gat (config 3) | sage-minibatch (config 4) — same JSON shape;

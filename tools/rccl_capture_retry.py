@@ -78,6 +78,29 @@ def main():
             print(f"FAILED   mode={mode}: rc {r.returncode} ({'signal ' + str(-r.returncode) if r.returncode < 0 else 'exception'}): {tail}")
 
 
+A2A_CHILD = CHILD.replace("""    buf.mul_(2.0)
+    dist.all_reduce(buf)
+    buf.add_(1.0)""", """    buf.mul_(2.0)
+    out = torch.empty_like(buf)
+    dist.all_to_all_single(out, buf, [buf.numel()], [buf.numel()])
+    buf.copy_(out).add_(1.0)""").replace("for _ in range(5):\n    dist.all_reduce(buf)", """for _ in range(5):
+    o2 = torch.empty_like(buf); dist.all_to_all_single(o2, buf, [buf.numel()], [buf.numel()])""").replace(
+    "with torch.cuda.stream(s):\n    dist.all_reduce(buf)", "with torch.cuda.stream(s):\n    o3 = torch.empty_like(buf); dist.all_to_all_single(o3, buf, [buf.numel()], [buf.numel()])").replace(
+    "CAPTURED mode=%s:", "CAPTURED all_to_all_single (split sizes given) mode=%s:").replace("2(2x+1)+1", "2(2x+1)+1, the exchange with itself being the identity")
+
+
+def a2a():
+    for mode in ("thread_local",):
+        r = subprocess.run([sys.executable, "-c", A2A_CHILD, mode], capture_output=True, text=True, timeout=180,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        out = [ln for ln in r.stdout.splitlines() if ln.startswith("CAPTURED")]
+        if r.returncode == 0 and out:
+            print(out[-1])
+        else:
+            tail = (r.stderr.strip().splitlines() or ["<no stderr>"])[-1][:300]
+            print(f"FAILED   all_to_all_single mode={mode}: rc {r.returncode} ({'signal ' + str(-r.returncode) if r.returncode < 0 else 'exception'}): {tail}")
+
+
 def sage():
     r = subprocess.run([sys.executable, "-c", SAGE_CHILD], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GGL_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -91,4 +114,5 @@ def sage():
 
 if __name__ == "__main__":
     main()
+    a2a()
     sage()
