@@ -698,8 +698,8 @@ def main():
             achievable = cal_t["stream_read"]["GBps"]
             rf["achievable"] = {"stream_read_GBps": cal_t["stream_read"]["GBps"], "stream_copy_GBps": cal_t["stream_copy"]["GBps"],
                                 "gather256_GBps": cal_t["gather256"]["GBps"],
-                                "note": "bytes moved / hipEvent time (best of 3) of benchmarks.calibration_launches: a 1 GiB "
-                                        "16 B/lane streaming read, the same copied, a 256-byte-row gather through a random "
+                                "note": "bytes moved / hipEvent time (best of 3) of benchmarks.calibration_launches: a 4 GiB "
+                                        "16 B/lane streaming read, 2 GiB copied, a 256-byte-row gather through a random "
                                         "permutation; frac_of_achievable uses the streaming READ (the aggregate is ~95 % reads)"}
             if kind not in KERNEL_OF:
                 set_traffic(rf, None, "no counter pass for this workload", achievable)

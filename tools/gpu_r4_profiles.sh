@@ -3,7 +3,7 @@
 O=gpurun_out/${1:-r4j}; mkdir -p $O
 R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-( timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "reference_order or int_vector or long_row" ) > $O/pytest_subset.log 2>&1; tail -2 $O/pytest_subset.log
+
 prof() {  # name, bench args...
   name=$1; shift
   rm -rf /tmp/prof_$name
