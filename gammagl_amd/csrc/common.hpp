@@ -80,6 +80,7 @@ __device__ __forceinline__ int64_t grid_threads() { return (int64_t)gridDim.x * 
 struct Options {
   int64_t unroll = 4;        // neighbour loads in flight per lane in the f32 fast path (4 or 8)
   int64_t unroll_narrow = 16; // ... and where a row owns <= 4 lanes (K <= 16 floats): 4 or 16
+  int64_t unroll_narrow_max = 0;  // ... for max too (A/B knob: lost with 64-bit argmax registers in round 1; re-measured in round 4)
   // 1 = give each XCD a contiguous range of row blocks (private-L2 locality).  OFF by default: measured
   // on MI355X (profiles/kbench_r1.txt) it changes nothing on a randomly ordered graph and is 4x SLOWER
   // on a degree-ordered one (one XCD inherits all the hub rows); round-robin is the load balancer.

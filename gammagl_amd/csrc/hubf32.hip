@@ -21,6 +21,8 @@
 // gather latency.  The bytes are the ones the chunked walk moved (each element's slab once).
 #include "common.hpp"
 
+#include <mutex>
+
 namespace ggl {
 
 constexpr int kHfProd = 8;                           // producer wavefronts
@@ -219,12 +221,18 @@ struct HubSide {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   bool ok = false;
+  // two host threads (the caller's and an autograd worker) may launch through here: the fork .. join-record sequence of
+  // one call must not interleave with another's (the events are shared).  A later call's join record sits behind this
+  // call's hub launch in the side stream's FIFO, so waiting on it can only over-wait.
+  std::mutex mu;
 };
 static HubSide *hub_side() {
   static HubSide sides[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   HubSide &s = sides[dev];
+  static std::mutex create_mu;
+  std::lock_guard<std::mutex> g(create_mu);
   if (!s.ok) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -242,7 +250,9 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *f
   if (a.n_long <= 0 || a.K <= 0) return GGL_OK;
   hipStream_t s = stream;
   HubSide *side = beside ? hub_side() : nullptr;
+  std::unique_lock<std::mutex> lock;
   if (side != nullptr) {
+    lock = std::unique_lock<std::mutex>(side->mu);
     GGL_HIP_CHECK(hipEventRecord(side->fork, stream));
     GGL_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
     s = side->stream;

@@ -42,6 +42,7 @@ Options &options() {
     Options t;
     t.unroll = env_i64("GGL_UNROLL", t.unroll);
     t.unroll_narrow = env_i64("GGL_UNROLL_NARROW", t.unroll_narrow);
+    t.unroll_narrow_max = env_i64("GGL_UNROLL_NARROW_MAX", t.unroll_narrow_max);
     t.xcd_swizzle = env_i64("GGL_XCD_SWIZZLE", t.xcd_swizzle);
     t.force_generic = env_i64("GGL_FORCE_GENERIC", t.force_generic);
     t.ragged4 = env_i64("GGL_RAGGED4", t.ragged4);
@@ -278,6 +279,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   Options &o = options();
   if (!strcmp(name, "unroll")) o.unroll = value;
   else if (!strcmp(name, "unroll_narrow")) o.unroll_narrow = value;
+  else if (!strcmp(name, "unroll_narrow_max")) o.unroll_narrow_max = value;
   else if (!strcmp(name, "xcd_swizzle")) o.xcd_swizzle = value;
   else if (!strcmp(name, "force_generic")) o.force_generic = value;
   else if (!strcmp(name, "ragged4")) o.ragged4 = value;
@@ -297,6 +299,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   Options &o = options();
   if (!strcmp(name, "unroll")) return o.unroll;
   if (!strcmp(name, "unroll_narrow")) return o.unroll_narrow;
+  if (!strcmp(name, "unroll_narrow_max")) return o.unroll_narrow_max;
   if (!strcmp(name, "xcd_swizzle")) return o.xcd_swizzle;
   if (!strcmp(name, "force_generic")) return o.force_generic;
   if (!strcmp(name, "ragged4")) return o.ragged4;

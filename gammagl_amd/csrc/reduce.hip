@@ -697,7 +697,7 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
                    kBlock, stream, GGL_RR_ARGS);
       }
     }
-  } else if (!RAG && OP != OP_MAX && d.logL <= 2 && options().unroll_narrow > 4) {
+  } else if (!RAG && (OP != OP_MAX || options().unroll_narrow_max) && d.logL <= 2 && options().unroll_narrow > 4) {
     // narrow rows (<= 4 lanes per row, K <= 16 floats): a lane moves 16 bytes per element, so the walk is
     // latency-bound; 16 elements in flight per lane instead of 4 (Reddit-sized segment_sum: K = 1
     // 1.73 -> 1.23 ms, K = 8 2.56 -> 2.12 ms, profiles/r1_smallk_probe.txt).  Not for max: its int64
@@ -846,6 +846,8 @@ template <int OP> static bool ragged16_ok(const ReduceArgs &a) {
   return (OP != OP_MAX || a.K >= 72 || options().ragged_max) && !options().force_generic && options().ragged4 && a.K >= 12;
 }
 
+template <int OP> static bool narrow16(const ReduceArgs &a) { return a.K <= 8 || (OP == OP_MAX && a.K <= 16); }
+
 template <int OP>
 static int launch_seg(int dtype, const ReduceArgs &a, hipStream_t stream) {
   switch (dtype) {
@@ -853,12 +855,16 @@ static int launch_seg(int dtype, const ReduceArgs &a, hipStream_t stream) {
     case GGL_F64:
       if (wide_ok(a, 2)) return launch_typed<double, 2, OP, MODE_SEG, false>(a, stream);
       return launch_typed<double, 1, OP, MODE_SEG, false>(a, stream);
+    // 16-bit rows of <= 8 columns (max: <= 16) walk with ONE element per lane: eight per lane would leave 1-2 lanes per
+    // row, i.e. 32-64 rows of very different lengths serialised inside one wavefront (products-sized graph, f16:
+    // K = 8 sum 4.64 -> 2.93 ms, max 5.90 -> 3.01; K = 16 max 5.27 -> 3.81; from K = 24 up the 16-byte lanes win —
+    // profiles/r4_narrow16_probe.txt).  Same summation order either way: same bits.
     case GGL_F16:
-      if (wide_ok(a, 8)) return launch_typed<f16_t, 8, OP, MODE_SEG, false>(a, stream);
+      if (wide_ok(a, 8) && !narrow16<OP>(a)) return launch_typed<f16_t, 8, OP, MODE_SEG, false>(a, stream);
       if (ragged16_ok<OP>(a)) return launch_typed<f16_t, 8, OP, MODE_SEG, false, true>(a, stream);
       return launch_typed<f16_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_BF16:
-      if (wide_ok(a, 8)) return launch_typed<bf16_t, 8, OP, MODE_SEG, false>(a, stream);
+      if (wide_ok(a, 8) && !narrow16<OP>(a)) return launch_typed<bf16_t, 8, OP, MODE_SEG, false>(a, stream);
       if (ragged16_ok<OP>(a)) return launch_typed<bf16_t, 8, OP, MODE_SEG, false, true>(a, stream);
       return launch_typed<bf16_t, 1, OP, MODE_SEG, false>(a, stream);
     case GGL_U8: return launch_typed<uint8_t, 1, OP, MODE_SEG, false>(a, stream);
