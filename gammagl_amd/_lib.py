@@ -25,6 +25,7 @@ class SegPlanC(ctypes.Structure):
         ("rowptr", c_void_p), ("perm", c_void_p), ("long_rows", c_void_p), ("chunk_ptr", c_void_p),
         ("n_long", c_int64), ("n_chunks", c_int64), ("chunk", c_int64), ("partial", c_void_p),
         ("N", c_int64), ("E", c_int64), ("row_order", c_void_p), ("xcd_run_rows", c_int64),
+        ("long_order", c_void_p),
     ]
 
 

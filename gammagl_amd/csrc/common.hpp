@@ -137,6 +137,7 @@ struct HubF32Args {
   int64_t H, C;             // C > 0: multi-head weights w[wi * H + column / C]
   const int64_t *rowptr;
   const int32_t *long_rows;
+  const int32_t *long_order;   // positions in long_rows, longest row first (or NULL)
   int64_t n_long;
   int64_t K;                // columns of this launch (a column block of a wider matrix: x points at its first column)
   float *partial;           // [n_long, K]

@@ -87,8 +87,11 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
   __shared__ float buf[2][kHfStage][kHfCols];        // 2 x 32 KiB (PER = 4, 64 columns) ... 2 x 16 KiB
   constexpr int NW = WPC ? 4 : 1;
   const int64_t slabs = (a.K + kHfCols - 1) / kHfCols;
-  const int64_t j = block_id() / slabs, slab = block_id() - j * slabs;
-  if (j >= a.n_long) return;
+  const int64_t jb = block_id() / slabs, slab = block_id() - jb * slabs;
+  if (jb >= a.n_long) return;
+  // the grid is walked longest row first (ggl_segplan.long_order): the longest add chain bounds the launch, so it starts
+  // with the first workgroups; its partial row still sits at its position j in long_rows
+  const int64_t j = a.long_order ? (int64_t)a.long_order[jb] : jb;
   const int64_t row = a.long_rows[j];
   const int64_t beg = a.rowptr[row], end = a.rowptr[row + 1], len = end - beg;   // (a long row: len > 0)
   const int64_t c0 = slab * kHfCols;

@@ -603,6 +603,7 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   const int32_t *long_rows;
   const int64_t *chunk_ptr;
   const int32_t *row_order;
+  const int32_t *long_order;
   int64_t xcd_run_rows;
   int64_t n_long, n_chunks;
   void *partial;
@@ -672,6 +673,7 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
       h.C = (MODE == MODE_BSPMM) ? a.C : 0;
       h.rowptr = a.rowptr;
       h.long_rows = a.long_rows;
+      h.long_order = a.long_order;
       h.n_long = a.n_long;
       h.K = a.K;
       h.partial = static_cast<float *>(a.partial);
@@ -893,6 +895,7 @@ static int fill_plan(ReduceArgs &a, const ggl_segplan_t *plan, int dtype, int64_
   a.long_rows = plan->long_rows;
   a.chunk_ptr = plan->chunk_ptr;
   a.row_order = plan->row_order;
+  a.long_order = plan->long_order;
   a.xcd_run_rows = plan->xcd_run_rows;
   a.n_long = plan->n_long;
   a.n_chunks = plan->n_chunks;

@@ -166,7 +166,7 @@ struct SegPlan {
   int64_t N = 0, E = 0, chunk = 0, n_long = 0, n_chunks = 0, max_len = 0, xcd_run = 0;
   bool sorted = false;
   uint64_t uid = 0;
-  Tensor rowptr, perm, long_rows, chunk_ptr;
+  Tensor rowptr, perm, long_rows, chunk_ptr, long_order;
   // the row hand-out order is a scheduling aid worth ~100 us of sorting: computed when the plan is launched a SECOND
   // time, so a plan used once (a fresh edge list per mini-batch) never pays for it (ops.py SegPlan.c_struct)
   mutable Tensor row_order;
@@ -194,6 +194,7 @@ struct SegPlan {
     }
     s.row_order = row_order.defined() ? row_order.data_ptr<int32_t>() : nullptr;
     s.xcd_run_rows = xcd_run;
+    s.long_order = (lng && long_order.defined()) ? long_order.data_ptr<int32_t>() : nullptr;
     return s;
   }
   Tensor counts() const { return rowptr.slice(0, 1) - rowptr.slice(0, 0, N); }
@@ -227,6 +228,8 @@ static void fill_long_rows(const Api &a, SegPlan &p, void *st) {
   p.chunk_ptr = at::empty({nl + 1}, p.rowptr.options());
   check(a, a.ggl_plan_long_fill(p.rowptr.data_ptr<int64_t>(), p.N, p.chunk, nl, p.long_rows.data_ptr<int32_t>(),
                                 p.chunk_ptr.data_ptr<int64_t>(), lws.data_ptr(), lwb, st));
+  if (nl > 0)   // the serial hub walk starts its longest rows first (ggl_segplan.long_order; ops.py Engine._long_order)
+    p.long_order = at::argsort(p.counts().index_select(0, p.long_rows.to(at::kLong)), /*stable=*/true, 0, /*descending=*/true).to(at::kInt);
 }
 
 static std::shared_ptr<SegPlan> build_plan(const Tensor &ids_in, int64_t N) {

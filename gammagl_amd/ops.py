@@ -43,7 +43,7 @@ class SegPlan:
     """Destination-sorted view of one id vector (struct ggl_segplan + the tensors that own it)."""
 
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
-                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run", "order_fn", "uses", "wperm")
+                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run", "order_fn", "uses", "wperm", "long_order")
 
     def c_struct(self, partial=None, perm_override=None, unsplit=False, skip_long=False):
         """`unsplit`: present the plan without its long-row table, every row walked in one piece.
@@ -51,6 +51,7 @@ class SegPlan:
         of the launch (ggl_segment_hub16 fills them in)."""
         perm = self.perm if perm_override is None else perm_override
         n_long = 0 if (unsplit or skip_long) else self.n_long
+        lo = getattr(self, "long_order", None)
         fn = getattr(self, "order_fn", None)
         if fn is not None:
             # the row hand-out order is a scheduling aid worth ~100 us of sorting: a plan that is used ONCE (a fresh
@@ -69,7 +70,8 @@ class SegPlan:
             chunk=((1 << 62) if unsplit else self.chunk),
             partial=(partial.data_ptr() if partial is not None else None), N=self.N, E=self.E,
             row_order=(self.row_order.data_ptr() if self.row_order is not None else None),
-            xcd_run_rows=int(getattr(self, "xcd_run", 0) or 0))
+            xcd_run_rows=int(getattr(self, "xcd_run", 0) or 0),
+            long_order=(lo.data_ptr() if (n_long and lo is not None) else None))
 
     def counts(self):
         return self.rowptr[1:] - self.rowptr[:-1]
@@ -403,7 +405,7 @@ class Engine:
         p.is_sorted, p.max_len = bool(is_sorted.value), int(max_len.value)
         p.perm = None if p.is_sorted else perm[:E]
         p.n_long = p.n_chunks = 0
-        p.long_rows = p.chunk_ptr = None
+        p.long_rows = p.chunk_ptr = p.long_order = None
         if p.max_len > chunk:
             lwb = self.lib.ggl_plan_long_workspace_bytes(N)
             lws = torch.empty(lwb, dtype=torch.uint8, device=dev)
@@ -416,12 +418,22 @@ class Engine:
             self._check(self.lib.ggl_plan_long_fill(_ptr(p.rowptr), N, chunk, p.n_long,
                                                     _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws),
                                                     lwb, st))
+            p.long_order = self._long_order(p)
         # scheduling aid: rows by descending length inside id windows, see _row_order / ggl_segplan.row_order —
         # computed when the plan is launched a second time (SegPlan.c_struct)
         p.row_order, p.uses, p.order_fn = None, 0, (self._row_order if N > 1 else None)
         self.stats["plans_built"] += 1
         p.uid = self.stats["plans_built"]
         return p
+
+    @staticmethod
+    def _long_order(p):
+        """positions in `long_rows` by descending row length (ggl_segplan.long_order): the serial hub walk starts its
+        longest add chains first.  No host read."""
+        if not p.n_long:
+            return None
+        lens = (p.rowptr[1:] - p.rowptr[:-1])[p.long_rows.long()]
+        return torch.argsort(lens, descending=True, stable=True).to(torch.int32)
 
     def _row_order(self, counts):
         """The order rows are handed to lane groups in (kernels where several rows share a wavefront): rows of similar
@@ -451,7 +463,7 @@ class Engine:
         p.perm, p.is_sorted = None, True
         p.max_len = int(max_len) if max_len is not None else (int(p.counts().max()) if p.N > 0 else 0)
         p.n_long = p.n_chunks = 0
-        p.long_rows = p.chunk_ptr = None
+        p.long_rows = p.chunk_ptr = p.long_order = None
         if p.max_len > p.chunk:
             st = self._stream(dev)
             lwb = self.lib.ggl_plan_long_workspace_bytes(p.N)
@@ -464,6 +476,7 @@ class Engine:
             p.chunk_ptr = torch.empty(p.n_long + 1, dtype=torch.int64, device=dev)
             self._check(self.lib.ggl_plan_long_fill(_ptr(p.rowptr), p.N, p.chunk, p.n_long,
                                                     _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws), lwb, st))
+            p.long_order = self._long_order(p)
         p.row_order, p.uses, p.order_fn = None, 0, (self._row_order if p.N > 1 else None)
         self.stats["plans_built"] += 1
         p.uid = self.stats["plans_built"]

@@ -88,6 +88,9 @@ typedef struct ggl_segplan {
   int64_t xcd_run_rows;     /* > 0: the node order carries locality — hand each XCD runs of this many consecutive row
                                slots (its private L2 then serves one neighbourhood instead of 1/8 of every one);
                                0: the library default (round-robin).  Scheduling only (ABI 5). */
+  const int32_t *long_order; /* [n_long] positions in long_rows by descending row length, or NULL: the order in which the
+                               serial hub walk (hubf32.hip) starts its rows — longest first, so that the one add chain
+                               nobody can shorten runs under everything else.  Scheduling only (ABI 6). */
 } ggl_segplan_t;
 
 /* bytes of workspace ggl_plan_build needs */
