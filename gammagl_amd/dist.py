@@ -38,6 +38,7 @@ from .dense import wgrad
 from .ops import _ptr
 
 HALO_CHUNKS = int(os.environ.get("GGL_HALO_CHUNKS", "0"))  # 0 = automatic (4 at K >= 256, 2 at K >= 128)
+DIST_EXACT = os.environ.get("GGL_DIST_EXACT", "1") == "1"   # 0: partitioned aggregates walk their hub rows chunk by chunk (A/B)
 A2A_MODE = os.environ.get("GGL_HALO_A2A", "a2a")            # "a2a": all_to_all_single | "p2p": grouped isend / irecv per peer
 
 
@@ -269,19 +270,18 @@ class PartitionedGraph:
 
 
 def _chunked_when_partitioned(fn):
-    """Run one forward / backward of a partitioned aggregate with the f32 hub rows CHUNKED (library option
-    `exact_long_rows` = 0 for the duration, restored afterwards).  A row of a partitioned graph is the sum of two launches —
-    its local-source edges, then its halo-source edges added on top — so the reference's serial order is out of reach
-    whatever a single launch does, and the serial hub walk (hubf32.hip) would only cost: a hub row keeps all its in-edges
-    on its owner rank, so its ~0.7 ms add chain per 64-column launch does not shrink with P while everything else does
-    (products-sized 8-way share: 18.0 ms per step with it, 17.4 chunked; profiles/r4_products_dry8_*).  One-GPU graphs
-    (pg.comm False) keep the exact walk."""
+    """A/B switch (GGL_DIST_EXACT=0): run one forward / backward of a partitioned aggregate with the f32 hub rows CHUNKED
+    (library option `exact_long_rows` = 0 for the duration, restored afterwards).  A row of a partitioned graph is the sum of
+    two launches — its local-source edges, then its halo-source edges added on top — so the reference's serial order is out
+    of reach there whatever a single launch does; the serial hub walk (hubf32.hip) is kept anyway because since it
+    starts its longest rows first it is the FASTER walk: products-sized dry shares 17.05 -> 15.94 ms per step at P = 8,
+    29.5 -> 27.1 at P = 4 (profiles/r4_dry_share_knobs.txt; before the longest-first order it cost 0.6 ms at P = 8)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(ctx, *args):
         pg = next((a for a in args if isinstance(a, PartitionedGraph)), None) or getattr(ctx, "pg", None)
-        if pg is None or not pg.comm:
+        if pg is None or not pg.comm or DIST_EXACT:
             return fn(ctx, *args)
         lib = pg.eng.lib
         old = int(lib.ggl_get_option(b"exact_long_rows"))
