@@ -101,13 +101,14 @@ template <typename T, bool V16>
 __global__ __launch_bounds__(kHubBlock) void hub_rows16_kernel(const uint16_t *__restrict__ x,
                                                                const int32_t *__restrict__ perm,
                                                                const int64_t *__restrict__ rowptr,
-                                                               const int32_t *__restrict__ long_rows, int64_t n_long,
+                                                               const int32_t *__restrict__ long_rows,
+                                                               const int32_t *__restrict__ long_order, int64_t n_long,
                                                                int64_t K, int64_t slabs, int mean,
                                                                uint16_t *__restrict__ out) {
   __shared__ uint16_t buf[2][kHubStage][kHubCols];   // 2 x 32 KiB
-  const int64_t j = block_id() / slabs, slab = block_id() - j * slabs;
-  if (j >= n_long) return;
-  const int64_t row = long_rows[j];
+  const int64_t jb = block_id() / slabs, slab = block_id() - jb * slabs;
+  if (jb >= n_long) return;
+  const int64_t row = long_rows[long_order ? (int64_t)long_order[jb] : jb];   // longest row first (ggl_segplan.long_order)
   const int64_t beg = rowptr[row], end = rowptr[row + 1], len = end - beg;
   const int64_t c0 = slab * kHubCols;
   const int ncol = (int)((K - c0) < kHubCols ? (K - c0) : kHubCols);   // (V16: a multiple of 8)
@@ -205,7 +206,7 @@ extern "C" int ggl_segment_hub16(int dtype, int mean, const void *x, const ggl_s
   const bool v16 = K % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
 #define GGL_HUB16(T, V)                                                                                          \
   GGL_LAUNCH((hub_rows16_kernel<T, V>), grid, kHubBlock, s, static_cast<const uint16_t *>(x), plan->perm, plan->rowptr, \
-             plan->long_rows, plan->n_long, K, slabs, mean ? 1 : 0, static_cast<uint16_t *>(out))
+             plan->long_rows, plan->long_order, plan->n_long, K, slabs, mean ? 1 : 0, static_cast<uint16_t *>(out))
   if (dtype == GGL_F16) {
     if (v16) GGL_HUB16(f16_t, true); else GGL_HUB16(f16_t, false);
   } else {
