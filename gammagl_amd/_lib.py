@@ -15,7 +15,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_host.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SegPlanC(ctypes.Structure):
@@ -26,6 +26,7 @@ class SegPlanC(ctypes.Structure):
         ("n_long", c_int64), ("n_chunks", c_int64), ("chunk", c_int64), ("partial", c_void_p),
         ("N", c_int64), ("E", c_int64), ("row_order", c_void_p), ("xcd_run_rows", c_int64),
         ("long_order", c_void_p),
+        ("max_len", c_int64),
     ]
 
 

@@ -202,6 +202,10 @@ def _time_steps(trainer, data, args, dev, world):
     x, y, train_local, n_train, _ = data
     step = lambda: trainer.step(x, y, train_local, n_train)   # noqa: E731
     trainer.graphed = _wants_graph(args, trainer.pg, dev, world)
+    trainer.halo_tune = None
+    if trainer.pg.comm and os.environ.get("GGL_HALO_TUNE", "1") != "0":
+        # untimed, before warm-up: how many column chunks the exchange runs in is measured here, not assumed
+        trainer.halo_tune = trainer.tune_halo_chunks(x, y, train_local, n_train)
     if trainer.graphed:
         trainer.capture(x, y, train_local, n_train, warmup=max(int(args.warmup), 3))
         step = trainer.replay
@@ -235,7 +239,7 @@ def _exchange_report(pg, trainer, data, args, dev, world, widths):
     iso, iso_total = [], 0.0
     P = max(pg.world, len(pg.send_splits)) if pg.dry else pg.world
     for K, per_step in widths:
-        chunks = _HaloAggregate._chunks(K)
+        chunks = _HaloAggregate._chunks(K, pg)
         ms = {}
         for direction, (n_out, n_in, osp, isp) in (("fwd", (pg.n_halo, pg.n_send, pg.recv_splits, pg.send_splits)),
                                                    ("bwd", (pg.n_send, pg.n_halo, pg.send_splits, pg.recv_splits))):
@@ -258,6 +262,7 @@ def _exchange_report(pg, trainer, data, args, dev, world, widths):
         iso_total += per_step * (ms["fwd"] + ms["bwd"]) / 2
     for key in [k_ for k_ in pg._bufs if k_[0] == "probe"]:
         del pg._bufs[key]
+    rep["halo_chunks"] = getattr(trainer, "halo_tune", None)   # measured before warm-up (DistGCNTrainer.tune_halo_chunks)
     rep["a2a_isolated"] = iso
     rep["a2a_isolated_ms_per_step"] = iso_total
     rep["overlap_frac"] = (1.0 - rep["halo_exposed_ms"] / iso_total) if iso_total > 0 and not pg.dry else None

@@ -53,6 +53,7 @@ Options &options() {
     t.max_grid_x = env_i64("GGL_MAX_GRID_X", t.max_grid_x);
     t.exact_long_rows = env_i64("GGL_EXACT_LONG_ROWS", t.exact_long_rows);
     t.exact_side_stream = env_i64("GGL_EXACT_SIDE_STREAM", t.exact_side_stream);
+    t.exact_long_max = env_i64("GGL_EXACT_LONG_MAX", t.exact_long_max);
     return t;
   }();
   return o;
@@ -291,6 +292,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "max_grid_x")) o.max_grid_x = value > 0 ? value : 1;
   else if (!strcmp(name, "exact_long_rows")) o.exact_long_rows = value;
   else if (!strcmp(name, "exact_side_stream")) o.exact_side_stream = value;
+  else if (!strcmp(name, "exact_long_max")) o.exact_long_max = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
 }
@@ -311,6 +313,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "max_grid_x")) return o.max_grid_x;
   if (!strcmp(name, "exact_long_rows")) return o.exact_long_rows;
   if (!strcmp(name, "exact_side_stream")) return o.exact_side_stream;
+  if (!strcmp(name, "exact_long_max")) return o.exact_long_max;
   return -1;
 }
 

@@ -604,6 +604,7 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   const int64_t *chunk_ptr;
   const int32_t *row_order;
   const int32_t *long_order;
+  int64_t max_len;
   int64_t xcd_run_rows;
   int64_t n_long, n_chunks;
   void *partial;
@@ -646,14 +647,17 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
   bool exact = false, forked = false;
   // (positions travel as int32 in the hub kernel's registers, like the plan's own perm entries)
   if constexpr (exact_long_mode<T, OP, MODE>())
-    exact = a.n_long > 0 && options().exact_long_rows != 0 && a.E < ((int64_t)1 << 31);
+    exact = a.n_long > 0 && options().exact_long_rows != 0 && a.E < ((int64_t)1 << 31) &&
+            (options().exact_long_max <= 0 || a.max_len <= options().exact_long_max);   // (one add chain of 10^7 elements: no)
 #ifdef GGL_EMULATE
-  if (exact) {   // the host build walks a row with one thread anyway: no chunks at all is the serial order
+  // the host build walks a row with one thread anyway: no chunks at all IS the reference's serial order — for every
+  // summing mode and dtype (f64 and the backward walks included), not only the ones the GPU's hub kernel covers
+  if (OP != OP_MAX && a.n_long > 0 && options().exact_long_rows != 0) {
     a.n_long = 0; a.n_chunks = 0;
     d.n_long = 0; d.n_chunks = 0;
     d.chunk = (int64_t)1 << 62;
-    exact = false;
   }
+  exact = false;
 #endif
   if (a.n_long > 0)
     GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
@@ -896,6 +900,7 @@ static int fill_plan(ReduceArgs &a, const ggl_segplan_t *plan, int dtype, int64_
   a.chunk_ptr = plan->chunk_ptr;
   a.row_order = plan->row_order;
   a.long_order = plan->long_order;
+  a.max_len = plan->max_len;
   a.xcd_run_rows = plan->xcd_run_rows;
   a.n_long = plan->n_long;
   a.n_chunks = plan->n_chunks;

@@ -195,6 +195,7 @@ struct SegPlan {
     s.row_order = row_order.defined() ? row_order.data_ptr<int32_t>() : nullptr;
     s.xcd_run_rows = xcd_run;
     s.long_order = (lng && long_order.defined()) ? long_order.data_ptr<int32_t>() : nullptr;
+    s.max_len = max_len;
     return s;
   }
   Tensor counts() const { return rowptr.slice(0, 1) - rowptr.slice(0, 0, N); }

@@ -155,6 +155,7 @@ class PartitionedGraph:
         self.n_send = int(self.send_idx.shape[0])
         self.send_plan = self.eng.seg_plan(self.send_idx, self.n_local) if self.n_send > 0 else None
         self._bufs = {}        # persistent exchange buffers, see _buf
+        self.halo_chunks = {}  # column chunks of the exchange measured on this machine: {"exchange": n, "const": n}
         self._const = {}       # [x_local ; x_halo] of tensors that never change, see with_halo
         self.profile = None    # set to {} to collect exchange statistics (bench.py, N > 1)
 
@@ -303,11 +304,16 @@ class _HaloAggregate(torch.autograd.Function):
         return t if k % 4 == 0 else torch.nn.functional.pad(t, (0, (-k) % 4))
 
     @staticmethod
-    def _chunks(K):
+    def _chunks(K, pg=None, kind="exchange"):
         """Feature-column chunks of the exchange: the all-to-all-v of chunk c+1 runs while the halo SpMM of
         chunk c computes (RCCL executes the queued collectives in order on its own stream; the compute
-        stream only waits for the chunk it is about to use)."""
-        n = HALO_CHUNKS if HALO_CHUNKS > 0 else (4 if K >= 256 else 2 if K >= 128 else 1)
+        stream only waits for the chunk it is about to use).  The chunks cost compute (four 64-wide halo walks run
+        at 60 % of one 256-wide walk: profiles/r4_dry_share_knobs.txt), so how many pay depends on the links: the
+        count is GGL_HALO_CHUNKS if set, else what `DistGCNTrainer.tune_halo_chunks` measured on this machine
+        (`pg.halo_chunks[kind]`, layers of 128 columns and more; `kind` "const" = the first layer, whose halo buffer
+        is filled by a GEMM and never travels), else 4 at K >= 256, 2 at K >= 128."""
+        tuned = pg.halo_chunks.get(kind) if (pg is not None and K >= 128) else None
+        n = HALO_CHUNKS if HALO_CHUNKS > 0 else tuned if tuned else (4 if K >= 256 else 2 if K >= 128 else 1)
         while n > 1 and K % (4 * n) != 0:
             n -= 1
         w = K // n
@@ -334,7 +340,7 @@ class _HaloAggregate(torch.autograd.Function):
             if pg.n_halo > 0:
                 works.append((0, K, h[pg.n_local:], _Done()))
         elif pg.comm:
-            for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
+            for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K, pg)):
                 send = pg._buf(("send", ci), pg.n_send, c1 - c0, h.dtype, dev)
                 if pg.n_send > 0:  # one kernel: rows of the column block straight into the send buffer
                     eng.gather_rows_into(h[:, c0:c1], pg.send_idx, send)
@@ -408,7 +414,7 @@ class _HaloAggregate(torch.autograd.Function):
             return (gh if K == ctx.k_orig else gh[:, :ctx.k_orig].contiguous()), None, gb, None, None, None
         works = []
         if pg.comm:
-            for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K)):
+            for ci, (c0, c1) in enumerate(_HaloAggregate._chunks(K, pg)):
                 ghalo = pg._buf(("halo", ci), pg.n_halo, c1 - c0, g.dtype, dev)
                 if pg.n_halo > 0:  # reads the column block of g in place (row stride passed down)
                     eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g[:, c0:c1], ghalo)
@@ -456,7 +462,7 @@ class _ConstInputLayer(torch.autograd.Function):
                               epi_K=K)
         else:
             eng.spmm_sum_into(pg.gp_loc.fwd, pg.gp_loc.col, pg.w_loc, h, out)
-        chunks = _HaloAggregate._chunks(K) if pg.n_halo > 0 else []
+        chunks = _HaloAggregate._chunks(K, pg, "const") if pg.n_halo > 0 else []
         for i, (c0, c1) in enumerate(chunks):
             hh = pg._buf(("halo", i), pg.n_halo, c1 - c0, torch.float32, dev)
             torch.mm(x_halo, wp[c0:c1].t(), out=hh)
@@ -495,7 +501,7 @@ class _ConstInputLayer(torch.autograd.Function):
             gl, _ = eng._spmm_fwd("sum", pg.gp_loc.bwd, pg.gp_loc.colT, pg.w_loc, g, nl)
             gw = wgrad(gl, x_loc)                                            # [K, f_in]
             del gl
-            for i, (c0, c1) in enumerate(_HaloAggregate._chunks(K) if pg.n_halo > 0 else []):
+            for i, (c0, c1) in enumerate(_HaloAggregate._chunks(K, pg, "const") if pg.n_halo > 0 else []):
                 gh = pg._buf(("halo", i), pg.n_halo, c1 - c0, torch.float32, dev)
                 eng.spmm_sum_into(pg.gp_halo.bwd, pg.gp_halo.colT, pg.w_halo, g[:, c0:c1], gh)
                 gw[c0:c1] += wgrad(gh, x_halo)
@@ -667,19 +673,77 @@ class DistGCNTrainer:
         self.opt.step()
         return loss.detach()
 
+    def tune_halo_chunks(self, x_local, y_local, train_local, n_train_global, candidates=(1, 2, 4), iters=2):
+        """MEASURE how many column chunks the halo exchange should run in, on this machine and this partition, instead
+        of assuming: each candidate runs `iters` forward + backward passes of the model (no optimizer step, gradients
+        dropped, the dropout stream put back afterwards: the training trajectory is unchanged — chunking never
+        changes a value, only when columns are computed), the slowest rank's time decides (a MAX all-reduce, so every
+        rank picks the same count — they must: the count is the number of collectives issued), first for the layers
+        that exchange, then for the constant-input first layer.  Call it on every rank, before `capture()`.
+        Returns {"exchange": n, "const": n, "ms": {...}}.  GGL_HALO_CHUNKS set: nothing is measured."""
+        pg = self.pg
+        out = {"exchange": None, "const": None, "ms": {}}
+        if HALO_CHUNKS > 0 or not pg.comm:
+            return out
+        dev = x_local.device
+        on_gpu = dev.type == "cuda"
+        real = pg.world > 1 and not pg.dry
+        rng = pg.eng._rng_state(dev)
+        rng_saved = rng.clone() if rng is not None else None
+
+        def fb():
+            self.net.train()
+            self.opt.zero_grad(set_to_none=True)
+            logits = self.net(x_local, pg)
+            (F.cross_entropy(logits[train_local], y_local[train_local], reduction="sum") / n_train_global).backward()
+            self.net.join()
+
+        def timed():
+            fb()                                                  # buffers of this layout allocated, caches warm
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            if real:
+                dist.barrier(group=pg.group)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fb()
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            t = torch.tensor([(time.perf_counter() - t0) * 1e3 / iters], dtype=torch.float64, device=dev)
+            if real:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg.group)
+            return float(t.item())
+
+        for kind in ("exchange", "const"):
+            best = None
+            for n in candidates:
+                pg.halo_chunks[kind] = int(n)
+                ms = timed()
+                out["ms"][f"{kind}={n}"] = round(ms, 3)
+                if best is None or ms < best[0]:
+                    best = (ms, int(n))
+            pg.halo_chunks[kind] = out[kind] = best[1]
+        pg._bufs.clear()          # only the layout that won stays allocated
+        self.opt.zero_grad(set_to_none=True)
+        if rng_saved is not None:
+            rng.copy_(rng_saved)
+        return out
+
     def capture(self, x_local, y_local, train_local, n_train_global, warmup=3, collectives=False):
         """Record step(...) on these very tensors into one hipGraph (`capturable=True`); afterwards `replay()` runs a
         training step — the kernels never sync or allocate outside the graph's pool, the side stream's weight-gradient
         GEMMs and the dropout draws (state advanced on the device) are part of it.  Single-rank steps (and dry
-        partitions) only: a step that exchanges halos contains RCCL collectives, and recording those was TRIED and does
-        not work on this stack — torch 2.10 + ROCm 7.0.2 + RCCL 2.26.6 segfault inside hipStreamEndCapture when the
-        captured region holds an all-to-all-v (world-size-1 group on one MI355X, capture_error_mode="thread_local",
-        persistent exchange buffers: profiles/r3_rccl_capture_attempt.txt).  `collectives=True` (or
-        GGL_CAPTURE_COLLECTIVES=1) attempts it anyway, for a future stack; the eager N > 1 step is what bench.py times."""
+        partitions) by default.  A step that exchanges halos contains RCCL collectives: recording those crashed in round 3
+        (hipStreamEndCapture segfault, profiles/r3_rccl_capture_attempt.txt) because the communicator met its first
+        collective INSIDE the capture; with the communicator warmed by eager steps first — which `warmup` does — an
+        all-reduce and an all-to-all-v with split sizes record and replay correctly on this stack in "thread_local"
+        capture mode (torch 2.10 + ROCm 7.0 + RCCL, world-size-1 group on one MI355X: profiles/r4_rccl_capture_retry.txt).
+        That is one GPU's evidence, so the N > 1 capture stays opt-in: `collectives=True` or GGL_CAPTURE_COLLECTIVES=1;
+        the eager N > 1 step is what bench.py times."""
         want = collectives or os.environ.get("GGL_CAPTURE_COLLECTIVES") == "1"
         if self.pg.comm and not self.pg.dry and not want:
-            raise RuntimeError("this step exchanges halos through RCCL; recording collectives into a hipGraph crashes on "
-                               "this stack (see the docstring) — capture() is for single-rank steps")
+            raise RuntimeError("this step exchanges halos through RCCL; recording collectives into a hipGraph is opt-in "
+                               "(collectives=True / GGL_CAPTURE_COLLECTIVES=1, see the docstring)")
         from .trainer import GraphedStep
 
         self.graph = GraphedStep(lambda: self.step(x_local, y_local, train_local, n_train_global), warmup=warmup,

@@ -71,7 +71,8 @@ class SegPlan:
             partial=(partial.data_ptr() if partial is not None else None), N=self.N, E=self.E,
             row_order=(self.row_order.data_ptr() if self.row_order is not None else None),
             xcd_run_rows=int(getattr(self, "xcd_run", 0) or 0),
-            long_order=(lo.data_ptr() if (n_long and lo is not None) else None))
+            long_order=(lo.data_ptr() if (n_long and lo is not None) else None),
+            max_len=int(getattr(self, "max_len", 0) or 0))
 
     def counts(self):
         return self.rowptr[1:] - self.rowptr[:-1]

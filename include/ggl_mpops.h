@@ -39,7 +39,7 @@ extern "C" {
 /* 5 (round 3): + ggl_bspmm_grad_w_sorted[_scratch_bytes]; v4's number had not been raised for the symbols added
  * late in round 2 (ggl_sample_hop, ggl_block_transpose, ggl_gat_sh_*, ggl_segment_hub16*, ggl_spmm_col_blocks) */
 /* 6 (round 4): + ggl_calib_stream (bench.py's achievable-rate yardstick) */
-#define GGL_ABI_VERSION 6
+#define GGL_ABI_VERSION 7
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
 enum {
@@ -91,6 +91,11 @@ typedef struct ggl_segplan {
   const int32_t *long_order; /* [n_long] positions in long_rows by descending row length, or NULL: the order in which the
                                serial hub walk (hubf32.hip) starts its rows — longest first, so that the one add chain
                                nobody can shorten runs under everything else.  Scheduling only (ABI 6). */
+  int64_t max_len;          /* elements of the longest row (ggl_plan_build's *max_len_host), or 0 = unknown.  The serial hub
+                               walk adds a row's elements one after the other (~3.5 ns each): a plan whose longest row
+                               exceeds the option `exact_long_max` (2^21 elements; a star graph's centre) keeps the
+                               chunked walk — within rounding of the reference instead of its bits — rather than wait
+                               for one add chain (ABI 7). */
 } ggl_segplan_t;
 
 /* bytes of workspace ggl_plan_build needs */

@@ -434,6 +434,20 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
             x = (rng.standard_normal((E, 64)) * 3).astype(np.float32)
             np.testing.assert_allclose(to_np(eng.c_segment_sum(to_t(x, dev), to_t(ids, dev), N)),
                                        oracle.segment_sum(x, ids, N), rtol=1e-5, atol=1e-4)
+            chunked = to_np(eng.c_segment_sum(to_t(x, dev), to_t(ids, dev), N))
+        # ---- ... and a plan whose LONGEST row exceeds `exact_long_max` takes it (a star graph's centre would be one add
+        # chain of E elements): same bits as the switch above on the GPU; the host build never chunks a summing row
+        longest = eng.seg_plan(to_t(ids, dev), N).max_len
+        assert longest >= 2900
+        with option(eng, "exact_long_max", longest - 1):
+            capped = to_np(eng.c_segment_sum(to_t(x, dev), to_t(ids, dev), N))
+        with option(eng, "exact_long_max", longest):
+            exact = to_np(eng.c_segment_sum(to_t(x, dev), to_t(ids, dev), N))
+        assert_same(exact, oracle.segment_sum(x, ids, N), "exact_long_max at the longest row")
+        if dev != "cpu" and str(dev) != "cpu":
+            assert_same(capped, chunked, "exact_long_max below the longest row = the chunked walk")
+        else:
+            assert_same(capped, exact, "host build: one piece either way")
     finally:
         eng.chunk = old
         eng.clear_caches()

@@ -157,6 +157,27 @@ def _worker(rank, world, port, tmp):
         ptrs = {k: b.data_ptr() for k, b in pg._bufs.items()}
         t.step(xl, yl, loc, n_train)
         assert ptrs and ptrs == {k: b.data_ptr() for k, b in pg._bufs.items()}
+        # (d) the number of column chunks of the exchange is MEASURED (tune_halo_chunks): every rank ends up with the
+        # same counts (they are numbers of collectives), and the training trajectory — dropout draws included — is the
+        # one of a trainer that never tuned
+        Hw = 128
+        eng.reseed(123)
+        ta = DistGCNTrainer(pg, F, Hw, C, num_layers=3, drop_rate=0.5, seed=11, device="cpu")
+        la = [ta.step(xl, yl, loc, n_train).clone() for _ in range(2)]
+        eng.reseed(123)
+        tb = DistGCNTrainer(pg, F, Hw, C, num_layers=3, drop_rate=0.5, seed=11, device="cpu")
+        tuned = tb.tune_halo_chunks(xl, yl, loc, n_train, candidates=(1, 2), iters=1)
+        assert tuned["exchange"] in (1, 2) and tuned["const"] in (1, 2) and len(tuned["ms"]) == 4
+        assert pg.halo_chunks == {"exchange": tuned["exchange"], "const": tuned["const"]}
+        assert len(_HaloAggregate._chunks(Hw, pg)) == tuned["exchange"] and len(_HaloAggregate._chunks(48, pg)) == 1
+        picks = [None] * world
+        dist.all_gather_object(picks, (tuned["exchange"], tuned["const"]))
+        assert all(pk == picks[0] for pk in picks), picks
+        lb = [tb.step(xl, yl, loc, n_train).clone() for _ in range(2)]
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(la, lb)), (la, lb)
+        for pa, pb in zip(ta.net.parameters(), tb.net.parameters()):
+            assert torch.equal(pa.detach(), pb.detach())
+        pg.halo_chunks.clear()
         open(os.path.join(tmp, f"ok{rank}"), "w").close()
     finally:
         dist.destroy_process_group()

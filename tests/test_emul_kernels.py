@@ -107,6 +107,30 @@ def test_long_rows_in_the_reference_order(eng, oracle):
     pc.check_exact_long_rows(eng, DEV, oracle)
 
 
+def test_host_build_walks_every_summing_row_in_one_piece(eng, oracle):
+    """CPU tensors (the reference dispatches on x.is_cpu() too): no row of any summing mode is chunked, so f64 sums —
+    which the GPU's serial hub kernel does not cover — and the backward walks are the reference's bits as well."""
+    import numpy as np
+    old = eng.chunk
+    eng.chunk = 64
+    eng.clear_caches()
+    try:
+        rng = np.random.default_rng(5)
+        N, E = 40, 4000
+        ids = rng.integers(0, N, size=E).astype(np.int64)
+        ids[:2500] = 9
+        rng.shuffle(ids)
+        for K in (1, 5, 64):
+            x = rng.standard_normal((E, K)) * 3
+            xt, it = pc.to_t(x, DEV), pc.to_t(ids, DEV)
+            assert eng.seg_plan(it, N).n_long >= 1
+            pc.assert_same(pc.to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids, N), f"f64 host sum K{K}")
+            pc.assert_same(pc.to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids, N), f"f64 host mean K{K}")
+    finally:
+        eng.chunk = old
+        eng.clear_caches()
+
+
 def test_gat_fused_random(eng, oracle):
     pc.check_gat_random(eng, DEV, oracle)
 
