@@ -294,6 +294,9 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
   };
 
   int64_t p = beg;
+  // (requesting batch i + 1's indices behind batch i's rows — one memory round trip per batch instead of two dependent
+  //  ones — was tried in round 4 and buys nothing: products step 75.2-75.4 vs 75.1-75.8 ms, every shape of the op sweep
+  //  within noise or slower (max: the extra registers cost a wavefront of occupancy) — the walks are throughput-bound.)
   for (; p + U <= end; p += U) {
     int64_t xrow[U], who[U];
     float wv[U];
