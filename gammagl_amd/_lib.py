@@ -111,7 +111,7 @@ SIGNATURES = {
     "ggl_policy_spmm_width": (c_int64, [c_int, c_int64, c_int64, c_int64]),
     "ggl_policy_head_channels": (c_int64, [c_int64, c_int64, c_int64]),
     "ggl_policy_mean_bwd_prescale": (c_int, [c_int64, c_int64]),
-    "ggl_policy_gradw_sorted": (c_int, [c_int64]),
+    "ggl_policy_gradw_sorted": (c_int, [c_int64, c_int64]),
     "ggl_policy_xcd_run_rows": (c_int64, [c_int64, ctypes.c_double]),
     "ggl_policy_row_order": (c_int, [POINTER(c_int64), POINTER(c_int64)]),
     "ggl_calib_stream": (c_int, [_V, _V, c_int64, c_int, _V]),

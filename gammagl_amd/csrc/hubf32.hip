@@ -237,6 +237,8 @@ static HubSide *hub_side() {
   static std::mutex create_mu;
   std::lock_guard<std::mutex> g(create_mu);
   if (!s.ok) {
+    // (a high-priority queue for the hub walk was measured and changes nothing: products step 74.99 vs 75.05 ms, bspmm
+    //  16 x 16 forward 17.39 vs 17.56 — profiles/r4_negative_results.txt)
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;

@@ -339,7 +339,9 @@ extern "C" int64_t ggl_policy_head_channels(int64_t C, int64_t E, int64_t N_in) 
   return (C % 4 != 0 && C >= 8 && E >= 8 * N_in) ? C + (4 - C % 4) : C;
 }
 extern "C" int ggl_policy_mean_bwd_prescale(int64_t E, int64_t N_in) { return E >= 4 * N_in ? 1 : 0; }
-extern "C" int ggl_policy_gradw_sorted(int64_t C) { return (C % 4 == 0 && C > 16) ? 1 : 0; }
+extern "C" int ggl_policy_gradw_sorted(int64_t H, int64_t C) {
+  return (C % 4 == 0 && (C > 16 || (C > 8 && H * C >= 256))) ? 1 : 0;
+}
 extern "C" int64_t ggl_policy_xcd_run_rows(int64_t E, double locality) {
   static const int64_t forced = env_i64("GGL_XCD_RUN_ROWS", -1);
   if (forced >= 0) return forced;

@@ -755,7 +755,7 @@ static std::tuple<Tensor, Tensor> bspmm_sum_backward_kernel(const Tensor &index,
   Tensor gx = bspmm_fwd(*gp, *gp->bwd, gp->colT, w, g, gp->N_src);
   Tensor gw = at::empty_like(w);
   void *st = stream_of(g.device());
-  if (a.ggl_policy_gradw_sorted(C)) {   // along the destination-sorted plan, strips staged through LDS (edgedot.hip)
+  if (a.ggl_policy_gradw_sorted(H, C)) {   // along the destination-sorted plan, strips staged through LDS (edgedot.hip)
     gp->need_rowidx(index);
     const size_t sb = a.ggl_bspmm_grad_w_sorted_scratch_bytes(gp->E, gp->N_dst, H, C);
     Tensor scratch = sb > 0 ? at::empty({static_cast<int64_t>(sb / 4)}, g.options()) : Tensor();

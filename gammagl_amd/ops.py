@@ -894,7 +894,7 @@ class Engine:
                 gw = torch.empty_like(w)
                 # a plan built from the caller's CSR has no COO edge list to walk (gp.index is None): it always takes the
                 # sorted route, whose plain kernel covers any channel count
-                if gp.index is None or (eng.gradw_sorted and eng.lib.ggl_policy_gradw_sorted(C)):
+                if gp.index is None or (eng.gradw_sorted and eng.lib.ggl_policy_gradw_sorted(H, C)):
                     # along the destination-sorted forward plan, strips staged through LDS (edgedot.hip): the g rows
                     # of a batch are a handful of rows, only x[src] is a random gather — and a coalesced one
                     sb = eng.lib.ggl_bspmm_grad_w_sorted_scratch_bytes(gp.E, gp.N_dst, H, C)

@@ -463,8 +463,10 @@ int64_t ggl_policy_head_channels(int64_t C, int64_t E, int64_t N_in);
  * bits; products-sized K = 256 23.0 -> 15.5 ms) — where a row has edges to amortise the pass over g: E >= 4 N_in */
 int ggl_policy_mean_bwd_prescale(int64_t E, int64_t N_in);
 /* 1: the bspmm weight gradient walks the destination-sorted plan with LDS-staged strips (edgedot.hip); 0: one thread
- * per (edge, head) in COO order (heads of <= 16 channels, or channel counts that are not multiples of 4) */
-int ggl_policy_gradw_sorted(int64_t C);
+ * per (edge, head) in COO order — channel counts that are not multiples of 4, and heads of <= 16 channels unless they
+ * are 12 / 16 wide in a row of >= 256 columns (measured on the products-sized graph, forward + backward: 16 x 16
+ * 63.7 vs 67.5 ms; 32 x 8 the other way, 82.4 vs 67.0; 8 x 8 equal).  Takes (H, C) since ABI 7. */
+int ggl_policy_gradw_sorted(int64_t H, int64_t C);
 /* rows per XCD run of a plan (0: round-robin blocks) given the share of its edges whose endpoints lie within N / 64 ids
  * of each other: 2048 for E >= 2^22 and locality > 0.5 (planted-community graph in cluster order: K = 256 13.4 ->
  * 10.8 ms; R-MAT orders lose 7-8 % with it).  GGL_XCD_RUN_ROWS overrides. */

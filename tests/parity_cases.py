@@ -1178,7 +1178,8 @@ def check_bspmm_gradw_sorted(eng, dev, oracle):
                 eng.set_option("col_block_min_edges", 0)
                 eng.set_option("col_block_min_degree", 0)
             for (N, E, H, C) in ((50, 3000, 1, 256), (40, 900, 8, 44), (33, 700, 2, 136), (21, 500, 3, 20),
-                                 (64, 1500, 1, 300), (30, 257, 4, 32), (9, 1, 1, 64)):
+                                 (64, 1500, 1, 300), (30, 257, 4, 32), (9, 1, 1, 64),
+                                 (40, 1200, 16, 16), (25, 600, 32, 8), (25, 600, 8, 8)):   # wide rows of narrow heads
                 src = rng.integers(0, N, E)
                 dst = rng.integers(0, max(N - 5, 1), E)              # the last rows stay empty
                 dst[: E // 3] = 2                                      # a hub row
