@@ -205,7 +205,8 @@ def _time_steps(trainer, data, args, dev, world):
     trainer.halo_tune = None
     if trainer.pg.comm and os.environ.get("GGL_HALO_TUNE", "1") != "0":
         # untimed, before warm-up: how many column chunks the exchange runs in is measured here, not assumed
-        trainer.halo_tune = trainer.tune_halo_chunks(x, y, train_local, n_train)
+        trainer.halo_tune = trainer.tune_halo_chunks(x, y, train_local, n_train,
+                                                     iters=2 if trainer.pg.e_local < (1 << 27) else 1)
     if trainer.graphed:
         trainer.capture(x, y, train_local, n_train, warmup=max(int(args.warmup), 3))
         step = trainer.replay
