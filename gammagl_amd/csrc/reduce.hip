@@ -841,6 +841,29 @@ static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
   return GGL_OK;
 }
 
+// bspmm over the same 64-column blocks where a block lies INSIDE one head (the block width divides C): the kernels compute a
+// column's head as k / C with k counted from the block's first column, so the weight pointer moves to the block's head and
+// everything else is the strided launch above.  Products-sized graph, forward: 1 x 256 16.0 -> 14.8 ms.  Blocks of several
+// narrow heads were measured too and LOSE (16 x 16: 17.4 -> 18.2 ms, 32 x 8: 19.1 -> 22.7 — every block launch fetches the
+// edge's whole [H] weight row for the few heads it uses): those shapes stay one launch.
+static int launch_bspmm_cols(const ReduceArgs &a0, hipStream_t stream) {
+  int64_t bw = col_block_width(a0.E, a0.K, a0.N);
+  if (bw > 0 && a0.C % bw != 0) bw = 0;
+  if (bw <= 0 || a0.N <= 0 || !a0.w) return launch_f32<OP_SUM, MODE_BSPMM>(a0, stream);
+  for (int64_t c0 = 0; c0 < a0.K; c0 += bw) {
+    ReduceArgs a = a0;
+    a.K = (a0.K - c0) < bw ? (a0.K - c0) : bw;
+    a.x = static_cast<const float *>(a0.x) + c0;
+    a.out = static_cast<float *>(a0.out) + c0;
+    a.x_ld = a0.x_ld > 0 ? a0.x_ld : a0.K;
+    a.out_ld = a0.out_ld > 0 ? a0.out_ld : a0.K;
+    a.w = a0.w + c0 / a0.C;          // [., H] rows: the block's first head (H stays the row stride)
+    const int rc = launch_f32<OP_SUM, MODE_BSPMM>(a, stream);
+    if (rc) return rc;
+  }
+  return GGL_OK;
+}
+
 // 16-byte vector path usable: K a multiple of the vector width and every base pointer 16-byte aligned
 static bool wide_ok(const ReduceArgs &a, int vec) {
   return !options().force_generic && a.K % vec == 0 && aligned16(a.x) && aligned16(a.out) &&
@@ -1169,7 +1192,7 @@ extern "C" int ggl_bspmm_sum(const ggl_segplan_t *plan, const int32_t *col, cons
   if (rc) return rc;
   a.H = H;
   a.C = C;
-  return launch_f32<OP_SUM, MODE_BSPMM>(a, as_stream(stream));
+  return launch_bspmm_cols(a, as_stream(stream));
 }
 
 // ---- timing aid for bench.py's roofline leg ------------------------------------------------------

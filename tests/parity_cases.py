@@ -415,7 +415,7 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
                 ye = eng.spmm_epi(gp, wt, to_t(x, dev), "sum", bias=to_t(b, dev), relu=True)
                 assert_same(to_np(ye), np.maximum(want + b, 0).astype(np.float32), f"exact spmm epi K{K}")
         # ---- bspmm: per-head weights
-        for H, C in ((2, 8), (4, 16), (3, 5), (8, 32)):
+        for H, C in ((2, 8), (4, 16), (3, 5), (8, 32), (16, 16), (1, 256), (2, 128), (3, 128), (5, 24)):
             index = np.stack([rng.integers(0, N, size=E), hub_ids()]).astype(np.int64)
             index = np.ascontiguousarray(index[:, rng.permutation(E)])
             w = rng.standard_normal((E, H)).astype(np.float32)
@@ -428,6 +428,16 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
                 y.backward(to_t(go, dev))
                 assert_same(to_np(y), oracle.bspmm_sum_fwd(index, w, x), f"exact bspmm {H}x{C} call {call}")
                 assert_same(to_np(xt.grad), ogx, f"exact bspmm gx {H}x{C} call {call}")
+            # the 64-column-block launches (forced on this toy graph) where a block lies inside one head (1 x 256, 2 x 128,
+            # 3 x 128 with its 384 columns); one launch where it would span heads (16 x 16, 8 x 32) or not nest (5 x 24)
+            if H * C >= 128:
+                with option(eng, "col_block_min_edges", 0), option(eng, "col_block_min_degree", 0):
+                    wt, xt = to_t(w, dev).requires_grad_(True), to_t(x, dev).requires_grad_(True)
+                    y = eng.c_bspmm_sum(to_t(index, dev), wt, xt)
+                    y.backward(to_t(go, dev))
+                    assert_same(to_np(y), oracle.bspmm_sum_fwd(index, w, x), f"exact bspmm {H}x{C} column blocks")
+                    assert_same(to_np(xt.grad), ogx, f"exact bspmm gx {H}x{C} column blocks")
+                    assert_same(to_np(wt.grad), ogw, f"exact bspmm gw {H}x{C} column blocks")
         # ---- the A/B switch: the chunked walk is still there, within rounding
         with option(eng, "exact_long_rows", 0):
             ids = hub_ids()
