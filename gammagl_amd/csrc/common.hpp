@@ -90,7 +90,7 @@ struct Options {
   int64_t col_block_min_degree = 24;      // ... and only where a row averages at least this many edges (reuse to find)
   int64_t col_block_min_edges = 8000000;  // below this many edges the blocks are twice as wide (launch-bound graphs)
   int64_t ragged4 = 1;       // f32 rows that are not aligned float4s (K % 4 != 0): 4 floats per lane + ragged last lane
-  int64_t ragged_max = 0;    // ... for segment_max as well (A/B knob: lost with 64-bit argmax registers, re-measured with 32-bit ones)
+  int64_t ragged_max = 1;    // ... for segment_max as well (0 = the one-element-per-lane kernels of rounds 2-3: an A/B knob)
   // 0 = natural row order; 1 = length-sorted rows where several rows share a wavefront (balances
   // the lanes of a wave); 2 = also for the wave-per-row kernels (heavy rows first)
   int64_t row_order = 1;

@@ -159,72 +159,49 @@ GGL_INT_VECIO(int32_t, 4)
 GGL_INT_VECIO(int64_t, 2)
 #undef GGL_INT_VECIO
 
-// RAGGED f32 rows (K % 4 != 0, or a base / stride that is not 16-byte aligned): still four floats per lane.  A row of
-// 47 floats used to take the VEC = 1 kernels — one dword per lane, 64 lanes per row, and a wave-wide dword load
-// costs the texture addresser as many cycles as a dwordx4 one — at 3.3 TB/s where K = 48 runs at 5+.  Here lanes
-// 0 .. K/4 - 1 move 16 bytes from a 4-byte aligned address (global_load_dwordx4 needs dword alignment only) and the
-// last lane of the row moves the K % 4 floats that are left: `nv` = this lane's valid components.
+// RAGGED rows (K not a multiple of the vector width, or a base / stride that is not 16-byte aligned): still one 16-byte
+// access per lane.  A row of 47 floats used to take the VEC = 1 kernels — one dword per lane, 64 lanes per row, and a
+// wave-wide dword load costs the texture addresser as many cycles as a dwordx4 one — at 3.3 TB/s where K = 48 runs at 5+.
+// Here every lane moves 16 bytes from an element-aligned address (global_load_dwordx4 needs dword alignment only; the
+// backend emits it for the packed structs below: unaligned access mode), and the row's LAST lane, which would have
+// K % VEC elements left, moves back to own the row's last VEC columns instead (`ragged_base`): the columns it shares
+// with its neighbour are computed twice, by the same adds in the same order, and stored twice with the same bits.  No
+// narrow loads, no shifts, no selects — rounds 2-3 read the tail as up to three dword loads (f32) or one shifted
+// 16-byte load with eight 64-bit selects (16-bit rows: 110 registers, 4 wavefronts per SIMD where the aligned kernel
+// holds 8).  A ragged launch needs K >= VEC (checked at launch).
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
 template <typename S, int VEC, bool RAG> struct RowIO {
   static __device__ __forceinline__ void load(const S *__restrict__ p, S (&v)[VEC], int) { VecIO<S, VEC>::load(p, v); }
   static __device__ __forceinline__ void store(S *__restrict__ p, const S (&v)[VEC], int) { VecIO<S, VEC>::store(p, v); }
 };
 template <> struct RowIO<float, 4, true> {
-  static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[4], int nv) {
-    if (nv == 4) {
-      const F4U t = *reinterpret_cast<const F4U *>(p);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-      // (the 16-bit rows below read a ragged tail as ONE shifted 16-byte load; tried here too and it lost: the selects
-      // run on every lane of the wave, segment_sum [E, 47] f32 7.8 -> 9.8 ms, where three dword loads cost one lane)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = i < nv ? p[i] : 0.0f;
-    }
+  static __device__ __forceinline__ void load(const float *__restrict__ p, float (&v)[4], int) {
+    const F4U t = *reinterpret_cast<const F4U *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
-  static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[4], int nv) {
-    if (nv == 4) {
-      F4U t;
-      t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
-      *reinterpret_cast<F4U *>(p) = t;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < nv) p[i] = v[i];
-    }
+  static __device__ __forceinline__ void store(float *__restrict__ p, const float (&v)[4], int) {
+    F4U t;
+    t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+    *reinterpret_cast<F4U *>(p) = t;
   }
 };
-// ... and the same for the 16-bit float storage types: rows of K % 8 != 0 elements (47 classes: 94-byte rows) used to take
-// the VEC = 1 kernels, one 2-byte load per lane — a wave-load that moves 94 bytes; here lanes 0 .. K/8 - 1 move 16 bytes
-// from a 2-byte aligned address (the backend emits global_load_dwordx4 for the packed struct: unaligned access mode)
-// and the last lane of the row the K % 8 elements left over.  Same elements, same order of the same rounded adds.
 template <> struct RowIO<uint16_t, 8, true> {
-  static __device__ __forceinline__ void load(const uint16_t *__restrict__ p, uint16_t (&v)[8], int nv) {
-    // the row's last lane (nv < 8 elements left) reads the 16 bytes that END at the row's end and shifts: every lane of
-    // the wave issues exactly one load per element (a row is at least 8 elements wide on this path), where the ragged lane
-    // used to add up to seven 2-byte loads to every wave-wide load of the walk ([E, 47] f16: 20.1 -> 7.2 ms)
-    const int s = 8 - nv;
-    const uint4 t = *reinterpret_cast<const uint4 *>(reinterpret_cast<const H8U *>(p - s));
-    const uint64_t lo = (uint64_t)t.x | ((uint64_t)t.y << 32), hi = (uint64_t)t.z | ((uint64_t)t.w << 32);
+  static __device__ __forceinline__ void load(const uint16_t *__restrict__ p, uint16_t (&v)[8], int) {
+    const H8U t = *reinterpret_cast<const H8U *>(p);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = i + s;                                   // element j of the 8 loaded
-      const uint64_t w = j < 4 ? lo : hi;
-      v[i] = i < nv ? (uint16_t)(w >> (16 * (j & 3))) : (uint16_t)0;
-    }
+    for (int i = 0; i < 8; ++i) v[i] = t.v[i];
   }
-  static __device__ __forceinline__ void store(uint16_t *__restrict__ p, const uint16_t (&v)[8], int nv) {
-    if (nv == 8) {
-      H8U t;
+  static __device__ __forceinline__ void store(uint16_t *__restrict__ p, const uint16_t (&v)[8], int) {
+    H8U t;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t.v[i] = v[i];
-      *reinterpret_cast<H8U *>(p) = t;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < nv) p[i] = v[i];
-    }
+    for (int i = 0; i < 8; ++i) t.v[i] = v[i];
+    *reinterpret_cast<H8U *>(p) = t;
   }
 };
+// first column of the VEC a lane owns when its slot starts at column k0: the row's last VEC columns for the ragged tail
+template <int VEC, bool RAG> __device__ __forceinline__ int64_t ragged_base(int64_t K, int64_t k0) {
+  return (RAG && K - k0 < VEC) ? K - VEC : k0;
+}
 template <int VEC, bool RAG> __device__ __forceinline__ int valid_lanes(int64_t K, int64_t kk) {
   return RAG ? (int)((K - kk) < VEC ? (K - kk) : VEC) : VEC;
 }
@@ -492,7 +469,8 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
     const int64_t rbeg = rowptr[row], rend = rowptr[row + 1];
     const int64_t beg = rbeg + local * d.chunk;
     const int64_t end = (beg + d.chunk < rend) ? beg + d.chunk : rend;
-    for (int64_t kk = (int64_t)lane * VEC; kk < d.K; kk += (int64_t)kWave * VEC) {
+    for (int64_t k0 = (int64_t)lane * VEC; k0 < d.K; k0 += (int64_t)kWave * VEC) {
+      const int64_t kk = ragged_base<VEC, RAG>(d.K, k0);
       A acc[VEC];
       argreg_t arg[VEC];
       init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
@@ -531,7 +509,8 @@ __global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(type
   const int64_t beg = rowptr[row], end = rowptr[row + 1];
   const int64_t len = end - beg;
   if (len > d.chunk) return;  // long row: reduced by the chunk blocks above + long_final_kernel
-  for (int64_t kk = (int64_t)li * VEC; kk < d.K; kk += (int64_t)L * VEC) {
+  for (int64_t k0 = (int64_t)li * VEC; k0 < d.K; k0 += (int64_t)L * VEC) {
+    const int64_t kk = ragged_base<VEC, RAG>(d.K, k0);
     A acc[VEC];
     argreg_t arg[VEC];
     init_acc<T, VEC, OP>(acc, arg, d.arg_fill);
@@ -754,6 +733,7 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
     if (run_blocks >= 2 && d.nblocks >= 16 * run_blocks) d.swizzle = (int)run_blocks;
   }
   GGL_REQUIRE(d.nblocks < ((int64_t)1 << 30), GGL_EINVAL, "too many rows for one launch");
+  GGL_REQUIRE(!RAG || (a.K >= VEC && !a.accumulate), GGL_EINVAL, "ragged rows: K >= the lane vector, no accumulate");
   if (a.N <= 0 || a.K <= 0) return GGL_OK;
   if constexpr (!STATIC_IDX || RAG) {   // (the ragged kernels resolve the index mode at run time: one variant each)
     return launch_idx<T, VEC, OP, MODE, IDX_RUNTIME, RAG>(a, d, stream);
@@ -781,9 +761,12 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
   // Measured on the products-sized graph (profiles/r2_ragged_rows.txt; same bits): gspmm max K = 101 12.5 -> 8.8 ms,
   // K = 41 6.2 -> 5.5 ms, segment_sum [E, 47] 7.46 -> 7.22 ms; below 32 columns the VEC = 1 kernels with 16 loads in
   // flight win by 3x and wave-per-row widths (K > 128) lose 7 %, so only 32 <= K <= 128 takes it.
-  // (not segment_max: its int64 argmax registers make the 4-wide lanes slower there, [E, 47] 7.9 -> 9.1 ms)
+  // (segment_max too since the tail lane owns the row's last four columns instead of 1-3 narrow loads: [E, 47] 8.16 -> 7.64 ms;
+  //  with the narrow tail and 64-bit witnesses it lost, 7.9 -> 9.1)
   if constexpr (seg_like(MODE) || spmm_like(MODE)) {
-    if (!options().force_generic && options().ragged4 && a.K >= 32 && a.K <= 128 &&
+    // (not onto an existing result: the tail lane's shared columns would be seeded from `out` after its neighbour has
+    //  stored them wherever lanes do not run in lockstep — the host build — or a row takes more than one pass)
+    if (!options().force_generic && options().ragged4 && a.K >= 32 && a.K <= 128 && !a.accumulate &&
         (OP != OP_MAX || spmm_like(MODE) || options().ragged_max))
       return launch_typed<float, 4, OP, MODE, kStatic, true>(a, stream);
   }
@@ -873,9 +856,12 @@ static bool wide_ok(const ReduceArgs &a, int vec) {
 // 16-bit rows that are not made of aligned 16-byte pieces: eight elements per lane all the same (RowIO<uint16_t, 8, true>),
 // from 12 columns up (below that one lane per element with 16 loads in flight wins)
 template <int OP> static bool ragged16_ok(const ReduceArgs &a) {
-  // (max: from 72 columns up — [E, 100] f16 18.6 -> 12.9 ms, but [E, 47] 9.7 -> 10.4: eight witnesses per lane cost more than
-  //  the narrow loads there)
-  return (OP != OP_MAX || a.K >= 72 || options().ragged_max) && !options().force_generic && options().ragged4 && a.K >= 12;
+  // (max: above 16 columns, like the aligned rows — since the tail lane owns the row's last eight columns (58 registers
+  //  instead of 110) [E, 47] f16 max 9.51 -> 6.38 ms, bf16 9.38 -> 6.20, [E, 100] f16 12.8 -> 8.6; sums: f16 6.03 -> 5.16,
+  //  bf16 [E, 100] 10.3 -> 8.8.  With the shifted-load tail it took 72 columns for the maxima to win.)
+  return (OP != OP_MAX || a.K >= 72 || (options().ragged_max && a.K > 16)) && !options().force_generic && options().ragged4 &&
+         a.K >= 12 &&
+         !a.accumulate;
 }
 
 template <int OP> static bool narrow16(const ReduceArgs &a) { return a.K <= 8 || (OP == OP_MAX && a.K <= 16); }

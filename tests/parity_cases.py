@@ -1055,6 +1055,19 @@ def check_strided_accumulate(eng, dev, oracle):
                 eng.spmm_sum_into(gp.fwd, gp.col, w, xs, acc[:, c0:c1], accumulate=True)
                 torch.testing.assert_close(acc[:, c0:c1], base[:, c0:c1] + dense, rtol=1e-5, atol=1e-5)
                 assert torch.equal(acc[:, :c0], base[:, :c0]) and torch.equal(acc[:, c1:], base[:, c1:])
+            # ragged widths (47 columns out of a 50-wide matrix, rows that are not 16-byte pieces): written in place,
+            # and accumulated — the ragged kernels' tail lane shares columns with its neighbour, which an accumulate
+            # must not see twice (it takes the one-element-per-lane kernels)
+            xr = torch.randn(M, 50, generator=g).to(dev)
+            dense, _ = eng._spmm_fwd("sum", gp.fwd, gp.col, w, xr[:, 1:48].contiguous(), N)
+            outr = torch.full((N, 50), 7.0, device=dev)
+            eng.spmm_sum_into(gp.fwd, gp.col, w, xr[:, 1:48], outr[:, 2:49])
+            assert torch.equal(outr[:, 2:49], dense) and bool((outr[:, :2] == 7).all()) and bool((outr[:, 49:] == 7).all())
+            base = torch.randn(N, 50, generator=g).to(dev)
+            accr = base.clone()
+            eng.spmm_sum_into(gp.fwd, gp.col, w, xr[:, 1:48], accr[:, 2:49], accumulate=True)
+            torch.testing.assert_close(accr[:, 2:49], base[:, 2:49] + dense, rtol=1e-5, atol=1e-5)
+            assert torch.equal(accr[:, :2], base[:, :2]) and torch.equal(accr[:, 49:], base[:, 49:])
             # segment_sum over a strided message block, accumulated onto a column block
             ids = ei[1].contiguous()
             plan = eng.seg_plan(ids, N)
