@@ -203,10 +203,12 @@ def _time_steps(trainer, data, args, dev, world):
     step = lambda: trainer.step(x, y, train_local, n_train)   # noqa: E731
     trainer.graphed = _wants_graph(args, trainer.pg, dev, world)
     trainer.halo_tune = None
-    if trainer.pg.comm and os.environ.get("GGL_HALO_TUNE", "1") != "0":
-        # untimed, before warm-up: how many column chunks the exchange runs in is measured here, not assumed
-        trainer.halo_tune = trainer.tune_halo_chunks(x, y, train_local, n_train,
-                                                     iters=2 if trainer.pg.e_local < (1 << 27) else 1)
+    tune = os.environ.get("GGL_HALO_TUNE", "auto")
+    if trainer.pg.comm and tune != "0" and (tune == "1" or trainer.pg.e_local < (1 << 27)):
+        # untimed, before warm-up: how many column chunks the exchange runs in is measured here, not assumed.  (auto: not
+        # for shares of 2^27 edges and more — a papers100M-sized share holds 24 GB per exchange buffer and 0.56 s per
+        # pass; its defaults are the measured ones, and GGL_HALO_TUNE=1 asks for the measurement all the same)
+        trainer.halo_tune = trainer.tune_halo_chunks(x, y, train_local, n_train)
     if trainer.graphed:
         trainer.capture(x, y, train_local, n_train, warmup=max(int(args.warmup), 3))
         step = trainer.replay

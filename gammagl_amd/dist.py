@@ -718,6 +718,7 @@ class DistGCNTrainer:
             best = None
             for n in candidates:
                 pg.halo_chunks[kind] = int(n)
+                pg._bufs.clear()      # one layout's exchange buffers alive at a time (a candidate's are up to 2 x n_halo x K)
                 ms = timed()
                 out["ms"][f"{kind}={n}"] = round(ms, 3)
                 if best is None or ms < best[0]:
