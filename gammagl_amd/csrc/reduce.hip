@@ -439,8 +439,21 @@ __device__ __forceinline__ void finish_row(const RPtrs<typename TT<T>::S> &q, co
 // partial buffer; they carry the lowest block ids so the hub work is dispatched first and the tail
 // of the launch is made of short rows.  Blocks [chunk_blocks, chunk_blocks + nblocks) own rows.
 // long_final_kernel then combines the partials of each long row in chunk order.
+// Wavefronts per SIMD the register allocator is asked to leave room for (1 = no request).  The 16-bit 8-per-lane maxima
+// land a few registers above a step of the occupancy ladder (f16: 76, one wavefront below bf16's 72 — the backend keeps
+// two copies of the eight running maxima as live-outs of the divergent walk loop) and these walks are occupancy-bound
+// (profiles/r4_negative_results.txt): ask for the step — 72 registers and 24 bytes of scratch per lane outside the walk loop;
+// f16 segment_max on the products-sized graph K = 32 / 64 / 128: 4.97 / 5.05 / 7.75 -> 4.59 / 4.84 / 7.41 ms.
+template <typename T, int VEC, int OP, int U, bool RAG> constexpr int rr_min_waves() {
+  return (sizeof(typename TT<T>::S) == 2 && VEC == 8 && OP == OP_MAX && U == 4 && !RAG) ? 7 : 1;
+}
+#ifdef GGL_EMULATE
+#define GGL_RR_WAVES(T, VEC, OP, U, RAG)
+#else
+#define GGL_RR_WAVES(T, VEC, OP, U, RAG) __attribute__((amdgpu_waves_per_eu(rr_min_waves<T, VEC, OP, U, RAG>(), 8)))
+#endif
 template <typename T, int VEC, int OP, int MODE, int IDX, bool UNIFORM, int U, bool RAG = false>
-__global__ __launch_bounds__(kBlock) void row_reduce_kernel(GGL_RPTR_PARAMS(typename TT<T>::S),
+__global__ __launch_bounds__(kBlock) GGL_RR_WAVES(T, VEC, OP, U, RAG) void row_reduce_kernel(GGL_RPTR_PARAMS(typename TT<T>::S),
                                                             const int32_t *__restrict__ row_order,
                                                             const int32_t *__restrict__ long_rows,
                                                             const int64_t *__restrict__ chunk_ptr,
