@@ -143,6 +143,7 @@ struct HubF32Args {
   int64_t K;                // columns of this launch (a column block of a wider matrix: x points at its first column)
   float *partial;           // [n_long, K]
   int64_t avg_long_len;     // average length of the long rows (picks the stage size)
+  int f64;                  // segment sums of doubles: x / x_ld / K / partial in 4-byte WORDS (2 per element), see hubf32.hip
 };
 int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *forked);
 int hub_f32_join(hipStream_t stream);

@@ -1,4 +1,4 @@
-// gammagl_amd/csrc/hubf32.hip — hub rows of the f32 sums IN THE REFERENCE'S SERIAL ORDER (GPU build only: LDS + barriers).
+// gammagl_amd/csrc/hubf32.hip — hub rows of the f32 (and f64 segment) sums IN THE REFERENCE'S SERIAL ORDER (GPU build only: LDS + barriers).
 //
 // The reference adds a row's elements one after the other (spmm_sum_cpu.cpp:29-39: for e in edge order:
 // out[dst] += w[e] * x[src]; segment_sum_cpu.cpp:47-56 likewise), every add rounded to f32.  The row kernel of
@@ -79,12 +79,16 @@ template <int PER> struct HfIds { int32_t row[PER], wi[PER]; };       // source 
 
 // VEC4: K % 4 == 0, 16-byte aligned base and row stride — a lane moves its four columns as one 16-byte load.
 // WPC (multi-head weights only): the head changes inside a quad (C % 4 != 0) — a weight per column.
-template <int MODE, bool VEC4, bool WPC, int PER, int LOG_LPE>
+// F64 (segment sums of doubles: the two segment modes, no weights): the producers move the row as 4-byte words — a row of
+// K doubles is a row of 2 K words, `a.K` / `a.x_ld` / `a.x` arrive in words — and only the consumer knows better: a lane
+// owns a DOUBLE (two adjacent words of the tile) and adds with __dadd_rn.  Same pipeline, same order of adds.
+template <int MODE, bool VEC4, bool WPC, int PER, int LOG_LPE, bool F64 = false>
 __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args a) {
+  static_assert(!F64 || hub_seg(MODE), "doubles: segment sums only (the SpMMs are f32 in the reference)");
   constexpr int kLpe = 1 << LOG_LPE, kEpl = kWave / kLpe;          // lanes per element, elements per load instruction
   constexpr int kHfCols = kLpe * 4;                                 // columns per slab
   constexpr int kHfPer = PER, kHfStage = kHfProd * PER * kEpl;      // elements per LDS half
-  __shared__ float buf[2][kHfStage][kHfCols];        // 2 x 32 KiB (PER = 4, 64 columns) ... 2 x 16 KiB
+  __shared__ __attribute__((aligned(16))) float buf[2][kHfStage][kHfCols];   // 2 x 32 KiB (PER = 4, 64 columns) ... 2 x 16 KiB
   constexpr int NW = WPC ? 4 : 1;
   const int64_t slabs = (a.K + kHfCols - 1) / kHfCols;
   const int64_t jb = block_id() / slabs, slab = block_id() - jb * slabs;
@@ -199,6 +203,28 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
     return;
   }
   // ---- consumer: one column per lane, the elements of a stage in order ---------------------------------------------
+  if constexpr (F64) {
+    double acc = 0.0;
+    const int ndbl = ncol >> 1;          // (an even number of words: whole doubles)
+    for (int64_t s = 0; s < nstp; ++s) {
+      lds_barrier();
+      const int b = (int)(s & 1);
+      if (lane < ndbl && s < nst) {
+        const int cnt = (int)((len - s * kHfStage) < kHfStage ? (len - s * kHfStage) : kHfStage);
+        int e = 0;
+        for (; e + 8 <= cnt; e += 8) {
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const double *>(&buf[b][e + q][2 * lane]);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc = __dadd_rn(acc, v[q]);
+        }
+        for (; e < cnt; ++e) acc = __dadd_rn(acc, *reinterpret_cast<const double *>(&buf[b][e][2 * lane]));
+      }
+    }
+    if (lane < ndbl) reinterpret_cast<double *>(a.partial)[j * (a.K >> 1) + (c0 >> 1) + lane] = acc;
+    return;
+  }
   float acc = 0.0f;
   for (int64_t s = 0; s < nstp; ++s) {
     lds_barrier();                       // stage s is parked (the producers go on to park stage s + 1 in the other half)
@@ -284,7 +310,21 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *f
     if (vec4) GGL_HF2(M, W, true);                     \
     else GGL_HF2(M, W, false);                         \
   } while (0)
-  if (seg) {
+  if (seg && a.f64) {   // (light stages: one instantiation per index mode and width class is enough for this rare dtype)
+#define GGL_HF64(M)                                                                                       \
+  do {                                                                                                     \
+    if (narrow) {                                                                                          \
+      if (vec4) GGL_LAUNCH((hub_rows_f32_kernel<M, true, false, 2, 2, true>), grid, kHfBlock, s, a);       \
+      else GGL_LAUNCH((hub_rows_f32_kernel<M, false, false, 2, 2, true>), grid, kHfBlock, s, a);           \
+    } else if (vec4) {                                                                                     \
+      GGL_LAUNCH((hub_rows_f32_kernel<M, true, false, 2, 4, true>), grid, kHfBlock, s, a);                 \
+    } else {                                                                                               \
+      GGL_LAUNCH((hub_rows_f32_kernel<M, false, false, 2, 4, true>), grid, kHfBlock, s, a);                \
+    }                                                                                                      \
+  } while (0)
+    if (a.perm) GGL_HF64(HUB_SEG_PERM); else GGL_HF64(HUB_SEG);
+#undef GGL_HF64
+  } else if (seg) {
     if (a.perm) GGL_HF(HUB_SEG_PERM, false); else GGL_HF(HUB_SEG, false);
   } else if (!has_w) {
     GGL_HF(HUB_SPMM, false);

@@ -629,8 +629,8 @@ static inline int pow2_ceil_log2(int64_t v) {
 // mode whose value is "an element, times its weight" — segment sum / mean, SpMM sum / mean, bspmm, with or without the
 // epilogue.  (max has no rounding; the mean / max backward walks keep their chunks.)
 template <typename T, int OP, int MODE> constexpr bool exact_long_mode() {
-  return std::is_same<T, float>::value && OP != OP_MAX &&
-         (seg_like(MODE) || spmm_like(MODE) || MODE == MODE_BSPMM);
+  return OP != OP_MAX && ((std::is_same<T, float>::value && (seg_like(MODE) || spmm_like(MODE) || MODE == MODE_BSPMM)) ||
+                          (std::is_same<T, double>::value && (MODE == MODE_SEG)));
 }
 
 template <typename T, int VEC, int OP, int MODE, int IDX, bool RAG = false>
@@ -662,8 +662,10 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
   if constexpr (exact_long_mode<T, OP, MODE>()) {
     if (exact) {
       HubF32Args h{};
+      constexpr int kWords = std::is_same<T, double>::value ? 2 : 1;   // doubles travel as pairs of 4-byte words (hubf32.hip)
+      h.f64 = kWords == 2 ? 1 : 0;
       h.x = reinterpret_cast<const float *>(a.x);
-      h.x_ld = d.x_ld;
+      h.x_ld = d.x_ld * kWords;
       h.perm = a.perm;
       h.col = seg_like(MODE) ? nullptr : a.col;
       h.w = seg_like(MODE) ? nullptr : a.w;
@@ -674,7 +676,7 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
       h.long_rows = a.long_rows;
       h.long_order = a.long_order;
       h.n_long = a.n_long;
-      h.K = a.K;
+      h.K = a.K * kWords;
       h.partial = static_cast<float *>(a.partial);
       h.avg_long_len = a.n_chunks * a.chunk / (a.n_long > 0 ? a.n_long : 1);   // (chunks are full but the last of a row)
       const int rc = hub_f32_launch(h, stream, options().exact_side_stream != 0, &forked);

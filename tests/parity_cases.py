@@ -376,6 +376,16 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
                 assert plan.n_long >= 3
                 assert_same(to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids_k, N), f"exact seg sum K{K} sorted={sort}")
                 assert_same(to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids_k, N), f"exact seg mean K{K} sorted={sort}")
+        # ---- ... and of doubles (the same pipeline moving the row as 4-byte words, the consumer adding doubles)
+        for K in (1, 3, 4, 8, 9, 32, 33, 100):
+            ids = hub_ids()
+            rng.shuffle(ids)
+            for sort in (False, True):
+                ids_k = np.sort(ids) if sort else ids
+                x = rng.standard_normal((E, K)) * 3
+                xt, it = to_t(x, dev), to_t(ids_k, dev)
+                assert_same(to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids_k, N), f"exact f64 seg sum K{K} sorted={sort}")
+                assert_same(to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids_k, N), f"exact f64 seg mean K{K} sorted={sort}")
         # ---- gspmm sum / mean, forward and transposed backward; weights absent / first sight / sorted copy
         for K in (4, 48, 64, 100, 256):
             index = np.stack([rng.integers(0, N, size=E), hub_ids()]).astype(np.int64)
@@ -443,7 +453,7 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
             ids = hub_ids()
             x = (rng.standard_normal((E, 64)) * 3).astype(np.float32)
             np.testing.assert_allclose(to_np(eng.c_segment_sum(to_t(x, dev), to_t(ids, dev), N)),
-                                       oracle.segment_sum(x, ids, N), rtol=1e-5, atol=1e-4)
+                                       oracle.segment_sum(x, ids, N), rtol=1e-4, atol=1e-3)   # (another association of 2900 adds)
             chunked = to_np(eng.c_segment_sum(to_t(x, dev), to_t(ids, dev), N))
         # ---- ... and a plan whose LONGEST row exceeds `exact_long_max` takes it (a star graph's centre would be one add
         # chain of E elements): same bits as the switch above on the GPU; the host build never chunks a summing row
