@@ -714,6 +714,8 @@ class DistGCNTrainer:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg.group)
             return float(t.item())
 
+        if on_gpu:
+            torch.cuda.synchronize(dev)   # nothing of an earlier step may still read the buffers dropped below
         for kind in ("exchange", "const"):
             best = None
             for n in candidates:
