@@ -31,7 +31,7 @@ def main():
     p.add_argument("--unfused", action="store_true", help="GATConv on the segment ops instead of FusedGATConv")
     p.add_argument("--gpu", type=int, default=0)
     args = p.parse_args()
-    dev = torch.device("cuda", args.gpu)
+    dev = torch.device("cuda", args.gpu) if args.gpu >= 0 else torch.device("cpu")   # gat_trainer.py's own "--gpu -1"
     n, f, c = 2708, 1433, 7
     x, y, edge_index = homophilous_graph(n, f, c, deg=2, seed=0, device=dev)
     edge_index = add_self_loops(edge_index, n)
@@ -52,7 +52,7 @@ def main():
             logits = net(x, edge_index, n)
         val_acc = float((logits[val_idx].argmax(1) == y[val_idx]).float().mean())
         if epoch % 10 == 0 or epoch == args.n_epoch - 1:
-            print("Epoch [{:0>3d}]   train loss: {:.4f}  val acc: {:.4f}".format(epoch + 1, float(loss), val_acc))
+            print("Epoch [{:0>3d}]   train loss: {:.4f}  val acc: {:.4f}".format(epoch + 1, float(loss.detach()), val_acc))
         if val_acc > best_val:
             best_val, best_state = val_acc, {k: v.clone() for k, v in net.state_dict().items()}
     net.load_state_dict(best_state)

@@ -70,7 +70,7 @@ def main():
             logits = net(x, edge_index, None, n)
         val_acc = float((logits[val_idx].argmax(1) == y[val_idx]).float().mean())
         if epoch % 10 == 0 or epoch == args.n_epoch - 1:
-            print("Epoch [{:0>3d}]   train loss: {:.4f}  val acc: {:.4f}".format(epoch + 1, float(loss), val_acc))
+            print("Epoch [{:0>3d}]   train loss: {:.4f}  val acc: {:.4f}".format(epoch + 1, float(loss.detach()), val_acc))
         if val_acc > best_val:
             best_val, best_state = val_acc, {k: v.clone() for k, v in net.state_dict().items()}
     net.load_state_dict(best_state)

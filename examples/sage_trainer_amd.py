@@ -31,14 +31,21 @@ def main():
     p.add_argument("--sampler", default="static", choices=["static", "dynamic"],
                    help="static: BlockSampler (fixed capacities, no host reads; one replayed hipGraph per batch on a "
                         "single GPU); dynamic: NeighborSampler (exact shapes, two host reads per hop)")
+    p.add_argument("--gpu", type=int, default=0, help="-1: everything on the host (the reference trainer's own flag; CPU "
+                                                      "tensors dispatch to the host build of the kernel sources)")
     args = p.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
+    on_gpu = args.gpu >= 0
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", str(args.gpu)))) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     n, f, c = args.nodes, 128, 16
     x, y, edge_index = homophilous_graph(n, f, c, deg=10, p_same=0.7, signal=0.3, seed=0, device=dev)
     perm = torch.randperm(n, generator=torch.Generator(device=dev).manual_seed(1), device=dev)
@@ -51,7 +58,7 @@ def main():
         caps = bs.calibrate(per_rank, trials=8, slack=1.3)
         tr = SAGEBlockTrainer(bs, f, args.hidden_dim, c, num_layers=args.num_layers, drop_rate=args.drop_rate,
                               lr=args.lr, device=dev, caps=caps, world=world)
-        if world == 1:   # the whole step — sampling included — as one replayed hipGraph
+        if world == 1 and on_gpu:   # the whole step — sampling included — as one replayed hipGraph
             seed_buf = train_idx[:per_rank].clone()
             graphed = tr.capture(x, y, seed_buf)
     else:
@@ -69,7 +76,7 @@ def main():
             else:
                 loss = tr.step(x, y, seeds)
             if rank == 0 and b % 10 == 0:
-                print("Epoch [{:0>3d}] batch {:3d}/{}  train loss: {:.4f}".format(epoch + 1, b, n_batches, float(loss)))
+                print("Epoch [{:0>3d}] batch {:3d}/{}  train loss: {:.4f}".format(epoch + 1, b, n_batches, float(loss.detach())))
         tr.net.eval()
         with torch.no_grad():
             dst, n_id, adjs = sampler.sample(test_idx[:4096])

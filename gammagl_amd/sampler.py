@@ -159,7 +159,7 @@ class NeighborSampler:
     once, then ``sample(batch)`` returns ``(batch, n_id, adjs)`` with ``adjs`` outermost hop first."""
 
     def __init__(self, edge_index, sample_lists, num_nodes=None, eng=None):
-        self.eng = eng or _engine()
+        self.eng = eng or _engine(edge_index)   # (CPU tensors: the host build, like the reference's CPU sampler)
         self.sizes = list(sample_lists)
         ei = edge_index.contiguous().to(torch.int64)
         if num_nodes is None:
@@ -272,7 +272,7 @@ class BlockSampler:
     min(deg, fanout) distinct neighbours per row), padded to capacity."""
 
     def __init__(self, edge_index, sample_lists, num_nodes=None, eng=None):
-        self.eng = eng or _engine()
+        self.eng = eng or _engine(edge_index)   # (CPU tensors: the host build, like the reference's CPU sampler)
         self.sizes = [int(s) for s in sample_lists]
         if any(s <= 0 for s in self.sizes):
             raise ValueError("BlockSampler needs positive fan-outs (use NeighborSampler for full neighbourhoods)")

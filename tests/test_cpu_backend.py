@@ -120,6 +120,21 @@ def test_gcn_trainer_example_runs_on_the_cpu():
     assert len(lines) >= 2, r.stdout[-1000:]
 
 
+def test_gat_and_sage_trainer_examples_run_on_the_cpu():
+    """The other two reference trainers with their own `--gpu -1`: fused and unfused GAT, and the neighbour-sampled
+    GraphSAGE trainer with both samplers (the samplers pick the host build from the edge list's device)."""
+    env = {k: v for k, v in os.environ.items() if k != "GGL_BENCH_EMUL"}
+    runs = [["gat_trainer_amd.py", "--n_epoch", "2"], ["gat_trainer_amd.py", "--n_epoch", "1", "--unfused"],
+            ["sage_trainer_amd.py", "--n_epoch", "1", "--nodes", "6000", "--batch_size", "512", "--hidden_dim", "16"],
+            ["sage_trainer_amd.py", "--n_epoch", "1", "--nodes", "6000", "--batch_size", "512", "--hidden_dim", "16",
+             "--sampler", "dynamic"]]
+    for argv in runs:
+        r = subprocess.run([sys.executable, os.path.join(REPO, "examples", argv[0]), "--gpu", "-1"] + argv[1:],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (argv, r.stderr[-2000:])
+        assert "test acc" in r.stdout.lower(), (argv, r.stdout[-500:])
+
+
 def test_zero_edit_binding_of_the_sparse_ops(tmp_path, golden):
     """`gammagl/ops/sparse/sparse.py:26-29` binds its GPU module in one import statement: a stand-in package holding
     exactly that statement binds `gammagl_amd/compat/_sparse_cuda.py` dropped at `ops/sparse/_sparse_cuda.py`; the
