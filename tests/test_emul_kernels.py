@@ -126,6 +126,25 @@ def test_host_build_walks_every_summing_row_in_one_piece(eng, oracle):
             assert eng.seg_plan(it, N).n_long >= 1
             pc.assert_same(pc.to_np(eng.c_segment_sum(xt, it, N)), oracle.segment_sum(x, ids, N), f"f64 host sum K{K}")
             pc.assert_same(pc.to_np(eng.c_segment_mean(xt, it, N)), oracle.segment_mean(x, ids, N), f"f64 host mean K{K}")
+        # ... and the backward walks of gspmm mean / max over hub SOURCES (the GPU keeps its chunks there)
+        index = np.stack([rng.integers(0, N, size=E), rng.integers(0, N, size=E)]).astype(np.int64)
+        index[0, :1800] = 3                       # a hub source: a long row of the transposed plan
+        index[1, 1800:3000] = 5                   # a hub destination
+        index = np.ascontiguousarray(index[:, rng.permutation(E)])
+        w = rng.standard_normal(E).astype(np.float32)
+        for K in (4, 33):
+            xs = rng.standard_normal((N, K)).astype(np.float32)
+            go = rng.standard_normal((N, K)).astype(np.float32)
+            it, wt = pc.to_t(index, DEV), pc.to_t(w, DEV)
+            assert eng.graph_plan(it, N).bwd.n_long >= 1
+            xt = pc.to_t(xs, DEV).requires_grad_(True)
+            eng.c_spmm_mean(it, wt, xt).backward(pc.to_t(go, DEV))
+            _, cnt = oracle.spmm_mean_fwd(index, w, xs)
+            pc.assert_same(pc.to_np(xt.grad), oracle.spmm_mean_bwd(index, w, go, cnt), f"host mean backward K{K}")
+            xt = pc.to_t(xs, DEV).requires_grad_(True)
+            eng.c_spmm_max(it, wt, xt).backward(pc.to_t(go, DEV))
+            _, arg = oracle.spmm_max_fwd(index, w, xs)
+            pc.assert_same(pc.to_np(xt.grad), oracle.spmm_max_bwd(index, w, go, arg), f"host max backward K{K}")
     finally:
         eng.chunk = old
         eng.clear_caches()
