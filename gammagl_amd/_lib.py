@@ -72,6 +72,7 @@ SIGNATURES = {
     "ggl_spmm_max": (c_int, [_P, _V, _V, c_int, _V, c_int64, _V, _V, _V]),
     "ggl_spmm_mean_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
     "ggl_spmm_max_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
+    "ggl_spmm_max_bwd32": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
     "ggl_bspmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, _V]),
     "ggl_bspmm_grad_w": (c_int, [_V, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
     "ggl_bspmm_grad_w_sorted_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),

@@ -34,7 +34,10 @@ enum Mode {
   MODE_SPMM_EPI = 5,   // MODE_SPMM + the layer epilogue applied to the finished row before its only store:
                        // y = dropout(relu(reduced + add[row] + bias))  (gcn_conv.py:105-106, models/gcn.py:55-59;
                        // add = SAGEConv's fc_self(x_dst) term, sage_conv.py:100-108)
-  MODE_SEG_EPI = 6     // MODE_SEG + the same epilogue (the message() + aggregate() route of a sampled block)
+  MODE_SEG_EPI = 6,    // MODE_SEG + the same epilogue (the message() + aggregate() route of a sampled block)
+  MODE_MAXBWD32 = 7    // MODE_MAXBWD reading its witnesses from a compact int32 copy (ggl_spmm_max_bwd32): its own
+                       // instantiation — a run-time width switch inside the walk was measured and loses (the backend stops
+                       // merging a lane's four witness loads: K = 256 forward + backward 68.0 -> 75.9 ms)
 };
 constexpr bool spmm_like(int mode) { return mode == MODE_SPMM || mode == MODE_SPMM_EPI; }
 constexpr bool seg_like(int mode) { return mode == MODE_SEG || mode == MODE_SEG_EPI; }
@@ -255,8 +258,10 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
         const int64_t cnt = q.aux_rowptr[xrow + 1] - q.aux_rowptr[xrow];
         v = (A)__fdiv_rn((float)v, (float)cnt);
         if (has_w) v = (A)__fmul_rn((float)v, wv);
-      } else if (MODE == MODE_MAXBWD) {
-        if (q.aux_arg[xrow * K + kk + i] != row) continue;
+      } else if (MODE == MODE_MAXBWD || MODE == MODE_MAXBWD32) {
+        const int64_t won = MODE == MODE_MAXBWD32 ? (int64_t) reinterpret_cast<const int32_t *>(q.aux_arg)[xrow * K + kk + i]
+                                                  : q.aux_arg[xrow * K + kk + i];
+        if (won != row) continue;
         if (has_w) v = (A)__fmul_rn(wv, (float)v);
       }
       if (OP == OP_MAX) {
@@ -1181,6 +1186,17 @@ extern "C" int ggl_spmm_max_bwd(const ggl_segplan_t *planT, const int32_t *colT,
   GGL_REQUIRE(argsrc || planT->E * K == 0, GGL_EINVAL, "argsrc is NULL");
   a.aux_arg = argsrc;
   return launch_f32<OP_SUM, MODE_MAXBWD>(a, as_stream(stream));
+}
+
+extern "C" int ggl_spmm_max_bwd32(const ggl_segplan_t *planT, const int32_t *colT, const float *w,
+                                  int w_by_pos, const float *g, const int32_t *argsrc32, int64_t K,
+                                  float *gx, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, planT, colT, w, w_by_pos, g, K, gx, false);
+  if (rc) return rc;
+  GGL_REQUIRE(argsrc32 || planT->E * K == 0, GGL_EINVAL, "argsrc32 is NULL");
+  a.aux_arg = reinterpret_cast<const int64_t *>(argsrc32);
+  return launch_f32<OP_SUM, MODE_MAXBWD32>(a, as_stream(stream));
 }
 
 // ---- bspmm ---------------------------------------------------------------------------------------

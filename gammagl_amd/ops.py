@@ -708,8 +708,13 @@ class Engine:
                 self._check(L.ggl_spmm_mean_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
                                                 _ptr(aux), K, _ptr(out), st))
         elif op == "max_bwd":
-            self._check(L.ggl_spmm_max_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
-                                           _ptr(aux), K, _ptr(out), st))
+            if int(L.ggl_get_option(b"maxbwd_arg32")):   # A/B knob: witnesses from a compact int32 copy (one [N, K] pass)
+                aux32 = aux.to(torch.int32)
+                self._check(L.ggl_spmm_max_bwd32(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
+                                                 _ptr(aux32), K, _ptr(out), st))
+            else:
+                self._check(L.ggl_spmm_max_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
+                                               _ptr(aux), K, _ptr(out), st))
         else:
             raise ValueError(op)
         return out, None

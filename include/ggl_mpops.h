@@ -238,6 +238,11 @@ int ggl_spmm_mean_bwd(const ggl_segplan_t *planT, const int32_t *colT, const flo
                       void *stream);
 int ggl_spmm_max_bwd(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
                      const float *g, const int64_t *argsrc, int64_t K, float *gx, void *stream);
+/* the same walk with the witnesses in a compact int32 copy of argsrc (node ids index int32 arrays everywhere in this
+ * library): the lookup is per edge AND column, 8 of the walk's 12 bytes per element with int64 witnesses.  NOT yet the
+ * hosts' default: unmeasured on the GPU (the Engine takes it with the option `maxbwd_arg32`; results identical). */
+int ggl_spmm_max_bwd32(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
+                       const float *g, const int32_t *argsrc32, int64_t K, float *gx, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bspmm — multi-head SpMM, f32; supersedes bspmm_sum_cpu_{forward,backward}

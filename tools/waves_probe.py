@@ -31,4 +31,9 @@ for K in (64, 256):
             fn(ei, w, xk).backward(go)
         with torch.no_grad():
             f = ev(lambda: fn(ei, w, xk))
-        print(f"{tag} gspmm {name} K={K:3d}: fwd {f:7.3f}  fwd+bwd {ev(fb):7.3f}", flush=True)
+        line = f"{tag} gspmm {name} K={K:3d}: fwd {f:7.3f}  fwd+bwd {ev(fb):7.3f}"
+        if name == "max":      # the backward with its witnesses from a compact int32 copy (its own instantiation, MODE_MAXBWD32)
+            eng.set_option("maxbwd_arg32", 1)
+            line += f"   fwd+bwd (int32 witnesses) {ev(fb):7.3f}"
+            eng.set_option("maxbwd_arg32", 0)
+        print(line, flush=True)
