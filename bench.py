@@ -170,6 +170,13 @@ def hip_parity_spmm(ei, w, x, y_ref, impl):
     y = eng.c_spmm_sum(ei_d, w_d, x_d)
     one = gp.fwd.counts() <= gp.fwd.chunk
     rep = parity.report(y, y_ref, rows_in_one_piece=one)
+    # hub rows are added in the reference's serial order (hubf32.hip) unless the plan's longest row exceeds the exact walk's
+    # bound: then EVERY row must be the reference's bits, not merely within the tolerance
+    exact = int(eng.lib.ggl_get_option(b"exact_long_rows")) != 0 and int(gp.fwd.max_len) <= int(eng.lib.ggl_get_option(b"exact_long_max"))
+    rep["exact_long_rows"] = exact
+    if exact and rep["rows_bit_exact_frac"] < 1.0:
+        rep["ok"] = False
+        rep["why"] = "exact_long_rows is on: every f32 sum row must be bit-identical to the reference"
     rep.update({"against": impl, "what": f"ONE K={int(x.shape[1])} CSR SpMM-sum forward of the benchmark graph itself "
                                          f"(N={n}, E={int(ei.shape[1])}), same weights and features on both sides",
                 "rows_longer_than_chunk": int((~one).sum()), "chunk": int(gp.fwd.chunk),
@@ -503,6 +510,7 @@ def run_secondary(args, t_start):
     returns its full line (value, ms_per_step, roofline, cpu_baseline, parity).  A child that fails or would overrun the
     command's time budget is reported as such, never silently dropped."""
     import subprocess
+    import tempfile
 
     lines = []
     for name, config, flags in SECONDARY:
@@ -516,10 +524,16 @@ def run_secondary(args, t_start):
         if name == "papers-share":
             cmd += ["--pmc-traffic", "off"]    # (two more builds of a 93 GB share: its counters live in profiles/)
         t0 = time.perf_counter()
+        detail = os.path.join(tempfile.gettempdir(), f"ggl_bench_{os.getpid()}_{name}.json")
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, SECONDARY_BUDGET_S + 120 - spent))
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, SECONDARY_BUDGET_S + 120 - spent),
+                               env=dict(os.environ, GGL_BENCH_DETAIL=detail))
             js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             line = json.loads(js[-1]) if js else None
+            if line is not None and os.path.exists(detail):     # the child's complete record (its stdout line is compact)
+                with open(detail) as f:
+                    line = json.load(f)
+                os.unlink(detail)
             if line is None:
                 line = {"workload": name, "error": f"no JSON line (rc {r.returncode}): {r.stderr[-300:]}"}
             elif r.returncode != 0:
@@ -532,6 +546,127 @@ def run_secondary(args, t_start):
         line["wall_s"] = round(time.perf_counter() - t0, 1)
         lines.append(line)
     return lines
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the line the driver parses: compact.  Everything verbose (prose, calibration tables, the secondary configs' full
+# lines) goes to bench_detail.json + earlier stdout lines; the LAST stdout line is the headline alone, < 4 KB
+# ---------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4000      # bytes; the driver keeps a bounded tail of stdout (round 4's 28 KB line was not parseable)
+DETAIL_FILE = os.environ.get("GGL_BENCH_DETAIL", os.path.join(REPO, "bench_detail.json"))
+
+
+def _r(v, nd=4):
+    """numbers at the precision they are measured to (shorter line, same content)"""
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{nd + 2}g}") if abs(v) >= 1 else round(v, nd + 3)
+    return v
+
+
+def _pick(d, keys, nd=4):
+    return {k: _r(d[k], nd) for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 1] + "~"
+
+
+def compact_secondary(line):
+    """what the headline keeps of a secondary config's full line"""
+    if "error" in line or "skipped" in line:
+        return _pick(line, ("workload", "error", "skipped")) | {"workload": line.get("workload")}
+    rf, par = line.get("roofline") or {}, line.get("parity") or {}
+    return {"workload": _short(line.get("config", {}).get("workload", line.get("workload", "?")).split(":")[0], 24),
+            "value": _r(line.get("value")), "unit": "edges/s", "ms_per_step": _r(line.get("ms_per_step")),
+            "frac": _r(rf.get("frac")), "alg_frac": _r(rf.get("alg_frac")), "parity_ok": par.get("ok"),
+            "cpu_baseline": _r((line.get("cpu_baseline") or {}).get("value"))}
+
+
+def compact_line(out):
+    """The contract's ONE line: every field the driver and the judge read (metric, value, ms_per_step, steps, warmup,
+    dtype, config, roofline, cpu_baseline, parity), numbers only — the prose is in bench_detail.json."""
+    c = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data", "rccl_ranks", "engine") if k in out}
+    cfg = out.get("config") or {}
+    cc = {"workload": _short(cfg.get("workload", ""), 200)}
+    cc.update(_pick(cfg, ("association", "hipgraph", "aggregations_per_step", "parallelism", "gcn_norm", "rank0_local_edges",
+                          "rank0_owned_rows", "rank0_halo_rows", "rank0_send_rows", "matmul_precision", "loss", "batch",
+                          "launches_per_step")))
+    if "hipgraph" in cc:
+        cc["hipgraph"] = _short(cc["hipgraph"], 24)
+    if "matmul_precision" in cc:
+        cc["matmul_precision"] = _short(cc["matmul_precision"], 24)
+    af = cfg.get("aggregate_first") or cfg.get("transform_first")
+    if isinstance(af, dict):
+        cc["aggregate_first" if "aggregate_first" in cfg else "transform_first"] = _pick(af, ("ms_per_step", "value", "aggregations_per_step"))
+    if cfg.get("orderings"):
+        cc["orderings"] = [_pick(o, ("relabel", "ms_per_step", "value", "ms_per_aggregate_K256")) for o in cfg["orderings"]]
+    if isinstance(cfg.get("norm_both"), dict):
+        cc["norm_both"] = _pick(cfg["norm_both"], ("ms_per_step_cached", "ms_per_step_uncached"))
+    ex = cfg.get("exchange")
+    if isinstance(ex, dict):
+        cc["exchange"] = _pick(ex, ("halo_exposed_ms", "a2a_GB_per_step", "GBps_per_link", "overlap_frac", "chunks"))
+    c["config"] = cc
+    rf = out.get("roofline")
+    if rf:
+        r = {"bound": rf.get("bound", "hbm"), "kernel": _short(rf.get("kernel", ""), 100)}
+        r.update(_pick(rf, ("achieved", "peak", "unit", "frac", "traffic", "launches_per_aggregate", "ms_per_launch", "ms_per_aggregate",
+                            "alg_bytes_per_aggregate", "eff_GBps", "alg_frac", "frac_of_peak", "achievable_GBps", "frac_of_achievable",
+                            "compulsory_bytes", "traffic_over_compulsory", "traffic_over_algorithmic", "hub_ms_per_launch",
+                            "row_walk_ms_per_launch")))
+        r["traffic_source"] = _short(rf.get("traffic_source", ""), 90)
+        cal = (rf.get("pmc_calibration") or {}).get("applied")
+        if cal:
+            r["pmc_factors"] = _pick(cal, ("read_factor", "write_factor"))
+        c["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if cb:
+        b = _pick(cb, ("value", "unit", "cores", "kind"))
+        b["sample"] = _short(cb.get("sample", ""), 160)
+        tf = cb.get("torch_fallback")
+        if isinstance(tf, dict):
+            b["torch_fallback"] = _pick(tf, ("value", "cores", "unit"))
+            b["torch_fallback"]["sample"] = _short(tf.get("sample", ""), 120)
+        c["cpu_baseline"] = b
+    par = out.get("parity")
+    if par:
+        pp = _pick(par, ("ok", "rows", "rows_bit_exact_frac", "elems_bit_exact_frac", "tol", "max_rel_err", "max_abs_err",
+                         "rows_longer_than_chunk", "grad_max_rel_err", "grad_tol", "bwd_rows_bit_exact_frac"), nd=3)
+        pp["against"] = _short(par.get("against", ""), 60)
+        c["parity"] = pp
+    if out.get("secondary"):
+        c["secondary"] = [compact_secondary(x) for x in out["secondary"]]
+    c["detail"] = os.path.basename(DETAIL_FILE)
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:      # never let prose push the contract's fields out of the driver's tail
+        for key in ("traffic_source", "sample"):
+            for obj in (c.get("roofline", {}), c.get("cpu_baseline", {}), c.get("cpu_baseline", {}).get("torch_fallback", {})):
+                if key in obj:
+                    obj[key] = _short(obj[key], 40)
+        c["config"]["workload"] = _short(c["config"]["workload"], 60)
+        line = json.dumps(c, separators=(",", ":"))
+    assert len(line) <= LINE_LIMIT, f"headline line is {len(line)} bytes"
+    return line
+
+
+def emit(out):
+    """stdout: one compact line per secondary config (prefixed by nothing: each is a valid JSON line), then the
+    headline LAST; the complete, verbose record -> bench_detail.json (and gpurun_out/ when that directory exists)."""
+    try:
+        paths = {DETAIL_FILE} | ({os.path.join(REPO, "gpurun_out", "bench_detail.json")} if "GGL_BENCH_DETAIL" not in os.environ else set())
+        for path in paths:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    json.dump(out, f, indent=1)
+    except OSError as ex:
+        print(f"bench.py: could not write the detail file: {ex}", file=sys.stderr)
+    for sec in out.get("secondary") or []:
+        if "metric" in sec:
+            print(compact_line(sec), flush=True)
+    print(compact_line(out), flush=True)
 
 
 def main():
@@ -641,7 +776,7 @@ def main():
                 tuned = None
 
     want_cpu = world == 1 and not args.no_cpu_baseline and not emul
-    args.keep_host_graph = want_cpu and kind == "gcn" and args.workload != "tiny"
+    args.keep_host_graph = want_cpu and kind == "gcn"
     try:
         out, ctx = RUNNERS[kind](args, dev, rank, world, eng=eng)
     except Exception as err:  # noqa: BLE001
@@ -664,15 +799,13 @@ def main():
         cpu_args = None
         if want_cpu:
             if kind == "gcn":
-                full = None
-                if args.workload != "tiny":
-                    if ctx.get("host_graph") is not None:
-                        ei, w = ctx["host_graph"]
-                    else:
-                        pg = ctx["pg"]    # N = 1: rank 0 holds the whole graph (a dry share: its local-source block)
-                        ei, w = torch.stack([pg.ei_loc[0], pg.ei_loc[1]]).cpu().contiguous(), pg.w_loc.cpu()
-                        del pg
-                    full = (ei, w, int(out["config"].get("rank0_owned_rows", 0)))
+                if ctx.get("host_graph") is not None:
+                    ei, w = ctx["host_graph"]
+                else:
+                    pg = ctx["pg"]    # N = 1: rank 0 holds the whole graph (a dry share: its local-source block)
+                    ei, w = torch.stack([pg.ei_loc[0], pg.ei_loc[1]]).cpu().contiguous(), pg.w_loc.cpu()
+                    del pg
+                full = (ei, w, int(out["config"].get("rank0_owned_rows", 0)))
                 cpu_args = (args.hidden, sizes_of(args.workload)[3], args.seed, full)
             elif kind == "gat":
                 cpu_args = ({"ei": ctx["ei"].cpu(), "n": ctx["n"]}, args.seed)
@@ -729,7 +862,7 @@ def main():
                 {"gcn": cpu_baseline_gcn, "gat": cpu_baseline_gat, "sage": cpu_baseline_sage}[kind](*cpu_args)
         if secondary_wanted(args, world, emul):
             out["secondary"] = run_secondary(args, t_start)
-        print(json.dumps(out), flush=True)
+        emit(out)
         if out.get("parity") is not None and not out["parity"]["ok"]:
             # a fast kernel whose results differ from the reference's is not a result: the line above says by how much
             print(f"bench.py: HIP result outside the parity criterion: {out['parity']}", file=sys.stderr, flush=True)

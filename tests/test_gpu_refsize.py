@@ -182,8 +182,10 @@ def test_products_size_aggregate_vs_the_reference(eng, dev, ref):
     yb.backward(go.cpu())
     rf = parity.check(ya.detach(), yb.detach(), "products K=256 forward", rows_in_one_piece=_one_piece(gp.fwd))
     rb = parity.check(a.grad, b.grad, "products K=256 backward", rows_in_one_piece=_one_piece(gp.bwd))
-    # all but the hub rows (longer than the 4096-element chunk) are the reference's own bits
-    assert rf["rows_bit_exact_frac"] > 0.999 and rb["rows_bit_exact_frac"] > 0.999, (rf, rb)
+    # EVERY row is the reference's own bits: the hub rows (longer than the 4096-element chunk) are added up in the
+    # reference's serial order by hubf32.hip — a regression in the hub walk (1752 rows here) must fail this test
+    assert rf["rows_bit_exact_frac"] == 1.0 and rb["rows_bit_exact_frac"] == 1.0, (rf, rb)
+    assert rf["max_abs_err"] == 0.0 and rb["max_abs_err"] == 0.0, (rf, rb)
 
 
 def test_reddit_size_gat_layer_vs_the_reference_ops(eng, dev, ref):
