@@ -593,7 +593,8 @@ def compact_line(out):
     cfg = out.get("config") or {}
     cc = {"workload": _short(cfg.get("workload", ""), 200)}
     cc.update(_pick(cfg, ("association", "hipgraph", "aggregations_per_step", "parallelism", "gcn_norm", "rank0_local_edges",
-                          "rank0_owned_rows", "rank0_halo_rows", "rank0_send_rows", "matmul_precision", "loss", "batch",
+                          "rank0_owned_rows", "rank0_halo_rows", "rank0_send_rows", "rank0_peak_edges_during_build",
+                          "rank0_halo_GB_per_step", "matmul_precision", "loss", "batch",
                           "launches_per_step")))
     if "hipgraph" in cc:
         cc["hipgraph"] = _short(cc["hipgraph"], 24)

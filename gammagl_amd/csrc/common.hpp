@@ -101,6 +101,7 @@ struct Options {
   int64_t maxbwd_arg32 = 0;       // hosts: gspmm max backward through ggl_spmm_max_bwd32 (A/B knob, unmeasured)
   int64_t exact_long_max = (int64_t)1 << 21;   // ... unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
+  int64_t hub_one_launch = 1;     // ... once per aggregate over the full width where the aggregate runs as column blocks (0 = once per block)
 };
 Options &options();
 

@@ -232,6 +232,33 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
     if (lane < ncol && s < nst) {
       const int cnt = (int)((len - s * kHfStage) < kHfStage ? (len - s * kHfStage) : kHfStage);
       int e = 0;
+      if (cnt == kHfStage) {
+        // a full stage, software-pipelined (round 5): the NEXT eight ds_read_b32 are in flight while the current eight
+        // dependent adds retire — LDS returns in order, so the wait before a group of adds is lgkmcnt(8), not (0).  The
+        // add chain (4 cycles per dependent v_add_f32) is then the only thing on the critical path inside a stage; the
+        // first group's LDS latency is exposed once per stage.  Same adds, same order, same bits.
+        float va[8], vb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) va[q] = buf[b][q][lane];
+#pragma unroll
+        for (int g = 0; g < kHfStage; g += 16) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) vb[q] = buf[b][g + 8 + q][lane];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc = __fadd_rn(acc, va[q]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (g + 16 < kHfStage) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) va[q] = buf[b][g + 16 + q][lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc = __fadd_rn(acc, vb[q]);
+        }
+        e = kHfStage;
+      }
       for (; e + 8 <= cnt; e += 8) {
         float v[8];
 #pragma unroll

@@ -54,6 +54,7 @@ Options &options() {
     t.exact_long_rows = env_i64("GGL_EXACT_LONG_ROWS", t.exact_long_rows);
     t.exact_side_stream = env_i64("GGL_EXACT_SIDE_STREAM", t.exact_side_stream);
     t.exact_long_max = env_i64("GGL_EXACT_LONG_MAX", t.exact_long_max);
+    t.hub_one_launch = env_i64("GGL_HUB_ONE_LAUNCH", t.hub_one_launch);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     return t;
   }();
@@ -294,6 +295,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "exact_long_rows")) o.exact_long_rows = value;
   else if (!strcmp(name, "exact_side_stream")) o.exact_side_stream = value;
   else if (!strcmp(name, "exact_long_max")) o.exact_long_max = value;
+  else if (!strcmp(name, "hub_one_launch")) o.hub_one_launch = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
@@ -316,6 +318,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "exact_long_rows")) return o.exact_long_rows;
   if (!strcmp(name, "exact_side_stream")) return o.exact_side_stream;
   if (!strcmp(name, "exact_long_max")) return o.exact_long_max;
+  if (!strcmp(name, "hub_one_launch")) return o.hub_one_launch;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   return -1;
 }

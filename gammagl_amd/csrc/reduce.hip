@@ -619,6 +619,11 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   const float *epi_add;
   int64_t add_ld;
   int64_t epi_K, epi_col0; // 0 / 0 = the launch covers whole rows
+  // column-block launches whose hub rows are walked ONCE per aggregate (launch_f32_cols): 0 = the whole op (hub walk, row
+  // walk, long_final); 1 = the row walk only (the hub walk over the full width is already in flight, long_final comes
+  // later); 2 = join the hub walk (if `hub_forked`) + long_final only
+  int phase;
+  int hub_forked;
 };
 
 static inline int pow2_ceil_log2(int64_t v) {
@@ -638,17 +643,51 @@ template <typename T, int OP, int MODE> constexpr bool exact_long_mode() {
                           (std::is_same<T, double>::value && (MODE == MODE_SEG)));
 }
 
+// ... and whether this launch takes it (positions travel as int32 in the hub kernel's registers, like the plan's own perm
+// entries; one add chain of 10^7 elements: no)
+template <typename T, int OP, int MODE> static bool exact_long_applies(const ReduceArgs &a) {
+#ifdef GGL_EMULATE
+  return false;
+#else
+  if constexpr (exact_long_mode<T, OP, MODE>())
+    return a.n_long > 0 && options().exact_long_rows != 0 && a.E < ((int64_t)1 << 31) &&
+           (options().exact_long_max <= 0 || a.max_len <= options().exact_long_max);
+  return false;
+#endif
+}
+
+#ifndef GGL_EMULATE
+template <typename T, int MODE> static HubF32Args hub_args_of(const ReduceArgs &a, int64_t x_ld) {
+  HubF32Args h{};
+  constexpr int kWords = std::is_same<T, double>::value ? 2 : 1;   // doubles travel as pairs of 4-byte words (hubf32.hip)
+  h.f64 = kWords == 2 ? 1 : 0;
+  h.x = reinterpret_cast<const float *>(a.x);
+  h.x_ld = x_ld * kWords;
+  h.perm = a.perm;
+  h.col = seg_like(MODE) ? nullptr : a.col;
+  h.w = seg_like(MODE) ? nullptr : a.w;
+  h.w_by_pos = a.w_by_pos;
+  h.H = a.H;
+  h.C = (MODE == MODE_BSPMM) ? a.C : 0;
+  h.rowptr = a.rowptr;
+  h.long_rows = a.long_rows;
+  h.long_order = a.long_order;
+  h.n_long = a.n_long;
+  h.K = a.K * kWords;
+  h.partial = static_cast<float *>(a.partial);
+  h.avg_long_len = a.n_chunks * a.chunk / (a.n_long > 0 ? a.n_long : 1);   // (chunks are full but the last of a row)
+  return h;
+}
+#endif
+
 template <typename T, int VEC, int OP, int MODE, int IDX, bool RAG = false>
 static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) {
   using S = typename TT<T>::S;
   ReduceArgs a = a_in;
   const bool uniform = !RAG && (d.logL == 6) && std::is_same<T, float>::value;   // (ragged rows: K <= 128 only)
   S *out = static_cast<S *>(a.out);
-  bool exact = false, forked = false;
-  // (positions travel as int32 in the hub kernel's registers, like the plan's own perm entries)
-  if constexpr (exact_long_mode<T, OP, MODE>())
-    exact = a.n_long > 0 && options().exact_long_rows != 0 && a.E < ((int64_t)1 << 31) &&
-            (options().exact_long_max <= 0 || a.max_len <= options().exact_long_max);   // (one add chain of 10^7 elements: no)
+  bool forked = a.phase == 2 && a.hub_forked != 0;
+  const bool exact = exact_long_applies<T, OP, MODE>(a);
 #ifdef GGL_EMULATE
   // the host build walks a row with one thread anyway: no chunks at all IS the reference's serial order — for every
   // summing mode and dtype (f64 and the backward walks included), not only the ones the GPU's hub kernel covers
@@ -657,33 +696,16 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
     d.n_long = 0; d.n_chunks = 0;
     d.chunk = (int64_t)1 << 62;
   }
-  exact = false;
 #endif
+  GGL_REQUIRE(a.phase == 0 || exact, GGL_EINVAL, "phased launches are for the exact hub walk only");
   if (a.n_long > 0)
     GGL_REQUIRE(a.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
   d.chunk_blocks = (a.n_long > 0 && !exact) ? ceil_div(a.n_chunks, kWavesPerBlock) : 0;
   d.exact_long = exact ? 1 : 0;
 #ifndef GGL_EMULATE
   if constexpr (exact_long_mode<T, OP, MODE>()) {
-    if (exact) {
-      HubF32Args h{};
-      constexpr int kWords = std::is_same<T, double>::value ? 2 : 1;   // doubles travel as pairs of 4-byte words (hubf32.hip)
-      h.f64 = kWords == 2 ? 1 : 0;
-      h.x = reinterpret_cast<const float *>(a.x);
-      h.x_ld = d.x_ld * kWords;
-      h.perm = a.perm;
-      h.col = seg_like(MODE) ? nullptr : a.col;
-      h.w = seg_like(MODE) ? nullptr : a.w;
-      h.w_by_pos = a.w_by_pos;
-      h.H = a.H;
-      h.C = (MODE == MODE_BSPMM) ? a.C : 0;
-      h.rowptr = a.rowptr;
-      h.long_rows = a.long_rows;
-      h.long_order = a.long_order;
-      h.n_long = a.n_long;
-      h.K = a.K * kWords;
-      h.partial = static_cast<float *>(a.partial);
-      h.avg_long_len = a.n_chunks * a.chunk / (a.n_long > 0 ? a.n_long : 1);   // (chunks are full but the last of a row)
+    if (exact && a.phase == 0) {
+      const HubF32Args h = hub_args_of<T, MODE>(a, d.x_ld);
       const int rc = hub_f32_launch(h, stream, options().exact_side_stream != 0, &forked);
       if (rc) return rc;
     }
@@ -693,7 +715,9 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
   GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "grid too large");
   const int32_t *order = (options().row_order && (!uniform || options().row_order > 1)) ? a.row_order : nullptr;
 #define GGL_RR_ARGS GGL_RPTR_ARGS(S), order, a.long_rows, a.chunk_ptr, static_cast<S *>(a.partial), a.partial_arg, out, a.arg, d
-  if (uniform) {
+  if (a.phase == 2) {
+    // (join + long_final only)
+  } else if (uniform) {
     if constexpr (!RAG) {
       // the f32 wave-per-row kernels; U = 8 only for the dominant SpMM-sum (A/B knob)
       if (std::is_same<T, float>::value && VEC == 4 && OP == OP_SUM && spmm_like(MODE) &&
@@ -716,6 +740,7 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
   }
 #undef GGL_RR_ARGS
   GGL_LAUNCH_CHECK();
+  if (a.phase == 1) return GGL_OK;
 #ifndef GGL_EMULATE
   if (forked) {
     const int rc = hub_f32_join(stream);
@@ -824,8 +849,23 @@ static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
   static_assert(OP != OP_MAX && (MODE == MODE_SPMM || MODE == MODE_SPMM_EPI), "column blocks: sum / mean SpMM only");
   const int64_t bw = col_block_width(a0.E, a0.K, a0.N);
   if (bw <= 0 || a0.N <= 0) return launch_f32<OP, MODE>(a0, stream);
+  // The hub rows are walked ONCE per aggregate, over the full width (round 5): one hub launch forked in front of the first
+  // column block, every slab of every hub row an independent workgroup — the K / 64 add chains of the longest row run
+  // side by side instead of one per column-block launch, each of which used to end 0.2-0.5 ms after its row walk — joined
+  // before ONE long_final over the full width.  The partial buffer holds n_chunks >= n_long full-width rows.
+  bool one_hub = false, forked = false;
+#ifndef GGL_EMULATE
+  if (options().hub_one_launch != 0 && exact_long_applies<float, OP, MODE>(a0)) {
+    GGL_REQUIRE(a0.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
+    const HubF32Args h = hub_args_of<float, MODE>(a0, a0.x_ld > 0 ? a0.x_ld : a0.K);
+    const int rc = hub_f32_launch(h, stream, options().exact_side_stream != 0, &forked);
+    if (rc) return rc;
+    one_hub = true;
+  }
+#endif
   for (int64_t c0 = 0; c0 < a0.K; c0 += bw) {
     ReduceArgs a = a0;
+    a.phase = one_hub ? 1 : 0;
     a.K = (a0.K - c0) < bw ? (a0.K - c0) : bw;
     a.x = static_cast<const float *>(a0.x) + c0;
     a.out = static_cast<float *>(a0.out) + c0;
@@ -840,6 +880,12 @@ static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
     a.epi_col0 = a0.epi_col0 + c0;
     const int rc = launch_f32<OP, MODE>(a, stream);
     if (rc) return rc;
+  }
+  if (one_hub) {
+    ReduceArgs a = a0;
+    a.phase = 2;
+    a.hub_forked = forked ? 1 : 0;
+    return launch_f32<OP, MODE>(a, stream);
   }
   return GGL_OK;
 }

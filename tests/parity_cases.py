@@ -412,7 +412,32 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
             if K % 64 == 0 and K >= 128:
                 with option(eng, "col_block_min_edges", 0), option(eng, "col_block_min_degree", 0):
                     assert int(eng.lib.ggl_spmm_col_blocks(E, K, N)) > 1
-                    assert_same(to_np(eng.c_spmm_sum(it, wt, to_t(x, dev))), want, f"exact spmm sum K{K} column blocks")
+                    # hub_one_launch = 1 (round 5): ONE hub launch over the full width in front of the first block + one
+                    # long_final behind the last; 0: a hub launch and a long_final per column block — same bits
+                    for one in (1, 0):
+                        with option(eng, "hub_one_launch", one):
+                            xt = to_t(x, dev).requires_grad_(True)
+                            y = eng.c_spmm_sum(it, wt, xt)
+                            y.backward(to_t(go, dev))
+                            assert_same(to_np(y), want, f"exact spmm sum K{K} column blocks one_hub={one}")
+                            assert_same(to_np(xt.grad), want_g, f"exact spmm sum backward K{K} column blocks one_hub={one}")
+                            assert_same(to_np(eng.c_spmm_mean(it, wt, to_t(x, dev))), oracle.spmm_mean_fwd(index, w, x)[0],
+                                        f"exact spmm mean K{K} column blocks one_hub={one}")
+                            bb = rng.standard_normal(K).astype(np.float32)
+                            ye = eng.spmm_epi(gp, wt, to_t(x, dev), "sum", bias=to_t(bb, dev), relu=True)
+                            assert_same(to_np(ye), np.maximum(want + bb, 0).astype(np.float32),
+                                        f"exact spmm epi K{K} column blocks one_hub={one}")
+                            acc0 = rng.standard_normal((N, K)).astype(np.float32)
+                            outa = to_t(acc0, dev)
+                            eng.spmm_sum_into(gp.fwd, gp.col, wt, to_t(x, dev), outa, accumulate=True)
+                            # (out += : the chain of a row starts from what `out` held — no oracle form; both launch
+                            #  shapes must agree bit for bit and sit within rounding of the two-step sum)
+                            got_acc = to_np(outa)
+                            assert np.allclose(got_acc, acc0 + want, rtol=1e-4, atol=1e-3), f"accumulate K{K} one_hub={one}"
+                            if one == 1:
+                                first_acc = got_acc
+                            else:
+                                assert_same(got_acc, first_acc, f"accumulate K{K}: one hub launch vs one per block")
             # strided + accumulate: a column block of a wider matrix, a second edge set added onto a result
             if K >= 48 and K % 16 == 0:
                 wide = to_t(np.concatenate([x, x[:, :16]], axis=1), dev)

@@ -466,15 +466,15 @@ def test_bench_launches_its_own_ranks(tmp_path):
                         "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4000, r.stdout     # the headline alone, compact (bench.compact_line)
+    out = json.loads(lines[-1])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["engine"].startswith("host-emulation")
     assert out["config"]["rank0_peak_edges_during_build"] <= 3.3 * 420000 / 2   # ~3x its share, transiently
     # one rank, unchanged contract
     r1 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--workload", "tiny",
                          "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    o1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    o1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
     assert o1["n_gpus"] == 1 and o1["rccl_ranks"] == 1 and o1["config"]["parallelism"] == "1 GPU"
     # a launcher that started a different number of ranks than --gpus: no line
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--workload", "tiny"],
