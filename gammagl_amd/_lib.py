@@ -15,7 +15,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_host.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class SegPlanC(ctypes.Structure):
@@ -73,6 +73,10 @@ SIGNATURES = {
     "ggl_spmm_mean_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
     "ggl_spmm_max_bwd": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
     "ggl_spmm_max_bwd32": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
+    "ggl_spmm_max_mask_bytes": (c_size_t, [c_int64, c_int64]),
+    "ggl_spmm_max_mask": (c_int, [_P, _V, _V, _V, c_int64, _V, _V]),
+    "ggl_spmm_max_bwd_mask": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
+    "ggl_invert_perm": (c_int, [_V, c_int64, _V, _V]),
     "ggl_bspmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, _V]),
     "ggl_bspmm_grad_w": (c_int, [_V, _V, _V, c_int64, c_int64, c_int64, _V, _V]),
     "ggl_bspmm_grad_w_sorted_scratch_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int64]),

@@ -98,7 +98,10 @@ struct Options {
   // f32 sums: rows longer than the plan's chunk are added up in the reference's serial order (hubf32.hip: bit-identical to
   // the CPU extension on EVERY row) instead of chunk by chunk (within rounding of it); 0 = the chunked walk (A/B switch)
   int64_t exact_long_rows = 1;
-  int64_t maxbwd_arg32 = 0;       // hosts: gspmm max backward through ggl_spmm_max_bwd32 (A/B knob, unmeasured)
+  int64_t maxbwd_arg32 = 0;       // hosts: gspmm max backward through ggl_spmm_max_bwd32 (A/B knob)
+  // hosts: gspmm max backward through a 1-bit winner mask (ggl_spmm_max_mask + ggl_spmm_max_bwd_mask) for rows of at least
+  // this many columns (0 = never: the witness walk)
+  int64_t maxbwd_mask = 32;
   int64_t exact_long_max = (int64_t)1 << 21;   // ... unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
   int64_t hub_one_launch = 1;     // ... once per aggregate over the full width where the aggregate runs as column blocks (0 = once per block)

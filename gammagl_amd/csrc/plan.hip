@@ -56,6 +56,7 @@ Options &options() {
     t.exact_long_max = env_i64("GGL_EXACT_LONG_MAX", t.exact_long_max);
     t.hub_one_launch = env_i64("GGL_HUB_ONE_LAUNCH", t.hub_one_launch);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
+    t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
     return t;
   }();
   return o;
@@ -297,6 +298,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "exact_long_max")) o.exact_long_max = value;
   else if (!strcmp(name, "hub_one_launch")) o.hub_one_launch = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
+  else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
 }
@@ -320,6 +322,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "exact_long_max")) return o.exact_long_max;
   if (!strcmp(name, "hub_one_launch")) return o.hub_one_launch;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
+  if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
   return -1;
 }
 
@@ -538,6 +541,21 @@ extern "C" int ggl_plan_long_fill(const int64_t *rowptr, int64_t N, int64_t chun
              (const int64_t *)sl, (const int64_t *)sc, long_rows, chunk_ptr, n_long, totals[1]);
   GGL_LAUNCH_CHECK();
   GGL_HIP_CHECK(hipStreamSynchronize(s));
+  return GGL_OK;
+}
+
+// inv[perm[i]] = i: the inverse of a permutation of [0, n) (GraphPlan.tpos = the inverse of posT: forward sorted position
+// -> transposed sorted position, which ggl_spmm_max_mask scatters an edge's winner bits to)
+__global__ __launch_bounds__(kBlock) void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ inv) {
+  const int64_t stride = grid_threads();
+  for (int64_t i = thread_id(); i < n; i += stride) inv[perm[i]] = (int32_t)i;
+}
+
+extern "C" int ggl_invert_perm(const int32_t *perm, int64_t n, int32_t *inv, void *stream) {
+  GGL_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && ((perm && inv) || n == 0), GGL_EINVAL, "bad arguments");
+  if (n == 0) return GGL_OK;
+  GGL_LAUNCH((invert_perm_kernel), grid_for(n), kBlock, as_stream(stream), perm, n, inv);
+  GGL_LAUNCH_CHECK();
   return GGL_OK;
 }
 

@@ -35,10 +35,14 @@ enum Mode {
                        // y = dropout(relu(reduced + add[row] + bias))  (gcn_conv.py:105-106, models/gcn.py:55-59;
                        // add = SAGEConv's fc_self(x_dst) term, sage_conv.py:100-108)
   MODE_SEG_EPI = 6,    // MODE_SEG + the same epilogue (the message() + aggregate() route of a sampled block)
-  MODE_MAXBWD32 = 7    // MODE_MAXBWD reading its witnesses from a compact int32 copy (ggl_spmm_max_bwd32): its own
+  MODE_MAXBWD32 = 7,   // MODE_MAXBWD reading its witnesses from a compact int32 copy (ggl_spmm_max_bwd32): its own
                        // instantiation — a run-time width switch inside the walk was measured and loses (the backend stops
                        // merging a lane's four witness loads: K = 256 forward + backward 68.0 -> 75.9 ms)
+  MODE_MAXBWDM = 8     // MODE_MAXBWD reading ONE BIT per (edge, column) — "this edge's source is the row's witness" — from a
+                       // mask in transposed position order (ggl_spmm_max_mask builds it in destination order, where the
+                       // witness row is wave-uniform): K / 8 bytes per edge beside the 4K-byte gradient row instead of 8K
 };
+constexpr bool maxbwd_like(int mode) { return mode == MODE_MAXBWD || mode == MODE_MAXBWD32 || mode == MODE_MAXBWDM; }
 constexpr bool spmm_like(int mode) { return mode == MODE_SPMM || mode == MODE_SPMM_EPI; }
 constexpr bool seg_like(int mode) { return mode == MODE_SEG || mode == MODE_SEG_EPI; }
 constexpr bool epi_mode(int mode) { return mode == MODE_SPMM_EPI || mode == MODE_SEG_EPI; }
@@ -79,6 +83,7 @@ struct ReduceDims {
   // is the one the full-width launch draws, so a result assembled block by block carries the same mask
   int64_t epi_K, epi_col0;
   int64_t add_ld;          // row stride of epi_add
+  int64_t mask_words;      // MODE_MAXBWDM: 32-bit words per edge of the winner mask (ceil(K / 32))
 };
 
 template <typename S> struct RPtrs {
@@ -239,7 +244,7 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
     } else {
       const int64_t c = (int64_t)q.col[p];
       xrow = c;
-      who = c;
+      who = MODE == MODE_MAXBWDM ? p : c;      // (the masked max backward looks its bits up by POSITION)
       wv = 1.0f;
       if (has_w) {
         const int64_t wi = w_perm ? (int64_t)q.perm[p] : p;
@@ -249,6 +254,12 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
   };
 
   auto accumulate = [&](const S (&raw)[VEC], int64_t xrow, float wv, int64_t who) {
+    uint32_t mbits = 0;
+    if (MODE == MODE_MAXBWDM && !RAG) {
+      // a lane's VEC (1 or 4) columns start at a multiple of VEC: their bits sit in ONE word of the edge's mask row
+      const uint32_t *mk = reinterpret_cast<const uint32_t *>(q.aux_arg) + who * d.mask_words;
+      mbits = mk[kk >> 5] >> (kk & 31);
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       A v = TT<T>::load(raw[i]);
@@ -258,6 +269,14 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
         const int64_t cnt = q.aux_rowptr[xrow + 1] - q.aux_rowptr[xrow];
         v = (A)__fdiv_rn((float)v, (float)cnt);
         if (has_w) v = (A)__fmul_rn((float)v, wv);
+      } else if (MODE == MODE_MAXBWDM) {
+        if (RAG) {    // (ragged rows: the tail lane's columns may straddle a word)
+          const uint32_t *mk = reinterpret_cast<const uint32_t *>(q.aux_arg) + who * d.mask_words;
+          if (i < nv && !((mk[(kk + i) >> 5] >> ((kk + i) & 31)) & 1u)) continue;
+        } else if (!((mbits >> i) & 1u)) {
+          continue;
+        }
+        if (has_w) v = (A)__fmul_rn(wv, (float)v);
       } else if (MODE == MODE_MAXBWD || MODE == MODE_MAXBWD32) {
         const int64_t won = MODE == MODE_MAXBWD32 ? (int64_t) reinterpret_cast<const int32_t *>(q.aux_arg)[xrow * K + kk + i]
                                                   : q.aux_arg[xrow * K + kk + i];
@@ -624,6 +643,7 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   // later); 2 = join the hub walk (if `hub_forked`) + long_final only
   int phase;
   int hub_forked;
+  int64_t mask_words;      // MODE_MAXBWDM
 };
 
 static inline int pow2_ceil_log2(int64_t v) {
@@ -767,6 +787,7 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   d.epi_K = a.epi_K > 0 ? a.epi_K : a.K; d.epi_col0 = a.epi_col0;
   d.epi_vec = (d.epi_K % 4 == 0) ? 4 : 1;
   d.add_ld = a.add_ld > 0 ? a.add_ld : a.K;
+  d.mask_words = a.mask_words;
   const int64_t kv = ceil_div(a.K, VEC);
   d.logL = pow2_ceil_log2(kv < kWave ? kv : kWave);
   if (d.logL > 6) d.logL = 6;
@@ -1243,6 +1264,129 @@ extern "C" int ggl_spmm_max_bwd32(const ggl_segplan_t *planT, const int32_t *col
   GGL_REQUIRE(argsrc32 || planT->E * K == 0, GGL_EINVAL, "argsrc32 is NULL");
   a.aux_arg = reinterpret_cast<const int64_t *>(argsrc32);
   return launch_f32<OP_SUM, MODE_MAXBWD32>(a, as_stream(stream));
+}
+
+// ---- gspmm(max) backward through a winner mask (round 5) --------------------------------------------------------------
+// The backward of spmm_max_cpu.cpp:57-99 feeds w[e] * g[dst, k] to every edge e whose SOURCE is the witness stored for
+// (dst, k).  Walked in source order (one output row per source, adds in ascending edge order: the reference's bits) every
+// edge used to look up its destination's witness row: 8K bytes of int64 beside the 4K-byte gradient row, 3x the sum's
+// traffic and 50 of the 68 ms of a K = 256 forward + backward.  The comparison only needs the witness row where it is
+// WAVE-UNIFORM — in destination order: max_mask_kernel walks the forward plan, a wavefront per row (chunks of hub rows as
+// in row_reduce_kernel), a lane per column holding that column's witness in a register; per edge one compare per 64
+// columns IS the ballot (v_cmp writes the 64-bit lane mask), and lanes 0 .. 2 NP - 1 store the edge's K bits at its
+// TRANSPOSED position (tpos: forward position -> transposed position, once per graph).  The transposed walk then streams
+// K / 8 bytes per edge in its own order.  Mask: word (t * ceil(K / 32) + k / 32), bit k % 32.
+template <int NP>
+__global__ __launch_bounds__(kBlock) void max_mask_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                          const int32_t *__restrict__ tpos, const int64_t *__restrict__ argsrc,
+                                                          const int32_t *__restrict__ long_rows,
+                                                          const int64_t *__restrict__ chunk_ptr, uint32_t *__restrict__ mask,
+                                                          int64_t N, int64_t K, int64_t KW, int64_t chunk, int64_t n_long,
+                                                          int64_t n_chunks, int64_t chunk_blocks) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  int64_t row, beg, end;
+  if (block_id() < chunk_blocks) {
+    const int64_t cid = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(block_id() * kWavesPerBlock + wave));
+    if (cid >= n_chunks) return;
+    int64_t lo = 0, hi = n_long - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
+    }
+    row = long_rows[lo];
+    beg = rowptr[row] + (cid - chunk_ptr[lo]) * chunk;
+    const int64_t rend = rowptr[row + 1];
+    end = beg + chunk < rend ? beg + chunk : rend;
+  } else {
+    row = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((block_id() - chunk_blocks) * kWavesPerBlock + wave));
+    if (row >= N) return;
+    beg = rowptr[row];
+    end = rowptr[row + 1];
+    if (end - beg > chunk || end == beg) return;      // long rows: the chunk blocks above
+  }
+#ifdef GGL_EMULATE
+  if (lane != 0) return;
+  for (int64_t p = beg; p < end; ++p) {
+    const int64_t s = col[p], t = tpos[p];
+    for (int64_t wd = 0; wd < KW; ++wd) {
+      uint32_t bits = 0;
+      for (int b = 0; b < 32 && wd * 32 + b < K; ++b)
+        if (argsrc[row * K + wd * 32 + b] == s) bits |= 1u << b;
+      mask[t * KW + wd] = bits;
+    }
+  }
+#else
+  for (int64_t k0 = 0; k0 < K; k0 += (int64_t)kWave * NP) {
+    int32_t a[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int64_t k = k0 + (int64_t)kWave * i + lane;
+      a[i] = k < K ? (int32_t)argsrc[row * K + k] : -1;     // (node ids are >= 0: a padding column never matches)
+    }
+    const int64_t w0 = k0 >> 5;
+    const bool stores = lane < 2 * NP && w0 + lane < KW;
+    const int half = lane & 1, plane = lane >> 1;
+    auto emit = [&](int32_t s, int64_t t) {
+      uint64_t b[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) b[i] = __ballot(a[i] == s);
+      uint64_t mine = b[0];
+#pragma unroll
+      for (int i = 1; i < NP; ++i) mine = plane == i ? b[i] : mine;
+      const uint32_t word = half ? (uint32_t)(mine >> 32) : (uint32_t)mine;
+      if (stores) mask[t * KW + w0 + lane] = word;
+    };
+    int64_t p = beg;
+    for (; p + 4 <= end; p += 4) {      // (unrolled by hand: the ballots are convergent operations, `#pragma unroll` declines)
+      int32_t s4[4];
+      int64_t t4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s4[u] = col[p + u]; t4[u] = tpos[p + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) emit(s4[u], t4[u]);
+    }
+    for (; p < end; ++p) emit(col[p], tpos[p]);
+  }
+#endif
+}
+
+extern "C" size_t ggl_spmm_max_mask_bytes(int64_t E, int64_t K) {
+  return (size_t)(E > 0 ? E : 0) * (size_t)((K + 31) / 32) * sizeof(uint32_t);
+}
+
+extern "C" int ggl_spmm_max_mask(const ggl_segplan_t *planF, const int32_t *colF, const int32_t *tpos,
+                                 const int64_t *argsrc, int64_t K, uint32_t *mask, void *stream) {
+  GGL_REQUIRE(planF != nullptr && planF->rowptr != nullptr, GGL_EINVAL, "plan is NULL");
+  const int64_t E = planF->E, N = planF->N;
+  if (E <= 0 || K <= 0 || N <= 0) return GGL_OK;
+  GGL_REQUIRE(colF && tpos && argsrc && mask, GGL_EINVAL, "ggl_spmm_max_mask: NULL argument");
+  GGL_REQUIRE(N < ((int64_t)1 << 31), GGL_EINVAL, "too many rows");
+  GGL_REQUIRE(planF->n_long == 0 || (planF->long_rows && planF->chunk_ptr), GGL_EINVAL, "plan has long rows but no chunk list");
+  const int64_t KW = (K + 31) / 32;
+  const int64_t chunk_blocks = planF->n_long > 0 ? ceil_div(planF->n_chunks, (int64_t)kWavesPerBlock) : 0;
+  const int64_t grid = chunk_blocks + ceil_div(N, (int64_t)kWavesPerBlock);
+  hipStream_t st = as_stream(stream);
+#define GGL_MM(NP)                                                                                                  \
+  GGL_LAUNCH((max_mask_kernel<NP>), grid, kBlock, st, planF->rowptr, colF, tpos, argsrc, planF->long_rows,         \
+             planF->chunk_ptr, mask, N, K, KW, planF->chunk, planF->n_long, planF->n_chunks, chunk_blocks)
+  if (K <= 64) GGL_MM(1);
+  else if (K <= 128) GGL_MM(2);
+  else GGL_MM(4);
+#undef GGL_MM
+  GGL_LAUNCH_CHECK();
+  return GGL_OK;
+}
+
+extern "C" int ggl_spmm_max_bwd_mask(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
+                                     const float *g, const uint32_t *mask, int64_t K, float *gx, void *stream) {
+  ReduceArgs a{};
+  int rc = spmm_common(a, planT, colT, w, w_by_pos, g, K, gx, false);
+  if (rc) return rc;
+  GGL_REQUIRE(mask || planT->E * K == 0, GGL_EINVAL, "mask is NULL");
+  a.aux_arg = reinterpret_cast<const int64_t *>(mask);
+  a.mask_words = (K + 31) / 32;
+  return launch_f32<OP_SUM, MODE_MAXBWDM>(a, as_stream(stream));
 }
 
 // ---- bspmm ---------------------------------------------------------------------------------------

@@ -63,7 +63,8 @@ using torch::autograd::variable_list;
   X(ggl_bias_act_bwd_workspace_bytes) X(ggl_bias_act_bwd) X(ggl_spmm_epi_ex) X(ggl_segment_epi)                        \
   X(ggl_sample_hop_workspace_bytes) X(ggl_sample_hop)                                                                \
   X(ggl_policy_chunk) X(ggl_policy_spmm_width) X(ggl_policy_head_channels) X(ggl_policy_mean_bwd_prescale)            \
-  X(ggl_policy_gradw_sorted) X(ggl_policy_xcd_run_rows) X(ggl_policy_row_order)
+  X(ggl_policy_gradw_sorted) X(ggl_policy_xcd_run_rows) X(ggl_policy_row_order)                                     \
+  X(ggl_spmm_max_mask_bytes) X(ggl_spmm_max_mask) X(ggl_spmm_max_bwd_mask) X(ggl_invert_perm) X(ggl_get_option)
 
 struct Api {
   void *handle = nullptr;
@@ -403,6 +404,18 @@ struct GraphPlan {
     inv.index_put_({pf.to(at::kLong)}, ar);
     posT = inv.index_select(0, pt.to(at::kLong)).contiguous();
   }
+  // forward sorted position -> transposed sorted position (int32 [E]; ops.py GraphPlan.tpos): where ggl_spmm_max_mask
+  // scatters an edge's winner bits for the max backward's transposed walk
+  Tensor tpos;
+  void need_tpos(const Tensor &index) {
+    need_posT(index);
+    std::lock_guard<std::mutex> g(mu);
+    if (tpos.defined()) return;
+    const Api &a = api_for(posT.device());
+    Tensor t = at::empty_like(posT);
+    check(a, a.ggl_invert_perm(posT.data_ptr<int32_t>(), E, t.data_ptr<int32_t>(), stream_of(posT.device())));
+    tpos = t;
+  }
 };
 
 static Cache<GraphPlan> &graph_cache() {
@@ -507,7 +520,8 @@ static std::pair<const float *, int> weights_for(const Api &a, GraphPlan &gp, co
 enum class SpOp { Sum, Mean, Max, MeanBwd, MaxBwd };
 
 static std::pair<Tensor, Tensor> spmm_fwd(SpOp op, GraphPlan &gp, const SegPlan &p, const Tensor &col, const Tensor &w,
-                                          const Tensor &x, int64_t n_out, const Tensor &aux = Tensor()) {
+                                          const Tensor &x, int64_t n_out, const Tensor &aux = Tensor(),
+                                          const Tensor &tpos = Tensor()) {
   const auto dev = x.device();
   const Api &a = api_for(dev);
   int64_t K = 1;
@@ -548,9 +562,21 @@ static std::pair<Tensor, Tensor> spmm_fwd(SpOp op, GraphPlan &gp, const SegPlan 
         check(a, a.ggl_spmm_mean_bwd(&cs, c, wp, by_pos, xp, aux.data_ptr<int64_t>(), K, op_, st));
       }
       break;
-    case SpOp::MaxBwd:
-      check(a, a.ggl_spmm_max_bwd(&cs, c, wp, by_pos, xp, aux.data_ptr<int64_t>(), K, op_, st));
+    case SpOp::MaxBwd: {
+      const int64_t mk = a.ggl_get_option("maxbwd_mask");
+      if (tpos.defined() && mk > 0 && K >= mk) {
+        // a 1-bit winner mask built in destination order, read in the transposed walk's own order (ops.py _spmm_fwd)
+        Tensor mask = at::empty({static_cast<int64_t>(a.ggl_spmm_max_mask_bytes(p.E, K) / 4) + 4}, x.options().dtype(at::kInt));
+        ggl_segplan_t fs = gp.fwd->c(Tensor());
+        check(a, a.ggl_spmm_max_mask(&fs, gp.col.data_ptr<int32_t>(), tpos.data_ptr<int32_t>(), aux.data_ptr<int64_t>(), K,
+                                     reinterpret_cast<uint32_t *>(mask.data_ptr<int32_t>()), st));
+        check(a, a.ggl_spmm_max_bwd_mask(&cs, c, wp, by_pos, xp, reinterpret_cast<const uint32_t *>(mask.data_ptr<int32_t>()),
+                                         K, op_, st));
+      } else {
+        check(a, a.ggl_spmm_max_bwd(&cs, c, wp, by_pos, xp, aux.data_ptr<int64_t>(), K, op_, st));
+      }
       break;
+    }
   }
   return {out, Tensor()};
 }
@@ -733,7 +759,12 @@ static Tensor spmm_max_backward_kernel(const Tensor &index, const c10::optional<
   Tensor g = grad.contiguous(), w = opt_dense(weight);
   c10::OptionalDeviceGuard guard(g.device());
   auto gp = bwd_plan(index, g.size(0));
-  return spmm_fwd(SpOp::MaxBwd, *gp, *gp->bwd, gp->colT, w, g, gp->N_src, arg.contiguous()).first;
+  Tensor tpos;
+  if (api_for(g.device()).ggl_get_option("maxbwd_mask") > 0) {
+    gp->need_tpos(index.contiguous());
+    tpos = gp->tpos;
+  }
+  return spmm_fwd(SpOp::MaxBwd, *gp, *gp->bwd, gp->colT, w, g, gp->N_src, arg.contiguous(), tpos).first;
 }
 static std::tuple<Tensor, Tensor> spmm_max_arg_kernel(const Tensor &i, const c10::optional<Tensor> &w, const Tensor &x) {
   Tensor arg;

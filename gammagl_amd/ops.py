@@ -81,7 +81,7 @@ class SegPlan:
 class GraphPlan:
     """CSR (rows = destination) and, lazily, CSC (rows = source) plans of one edge_index."""
 
-    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT", "_rowidx", "aux")
+    __slots__ = ("engine", "index", "N_dst", "N_src", "E", "fwd", "col", "_bwd", "_colT", "_posT", "_tpos", "_rowidx", "aux")
 
     def __init__(self, engine, index, n_dst, n_src):
         self.engine = engine
@@ -93,7 +93,7 @@ class GraphPlan:
         self.fwd = engine.seg_plan(index[1], self.N_dst)
         engine._check_range(index[0], self.N_src)
         self.col = engine.gather_i32(index[0], self.fwd.perm)
-        self._bwd = self._colT = self._posT = self._rowidx = None
+        self._bwd = self._colT = self._posT = self._tpos = self._rowidx = None
         self.aux = {}  # graph-constant tensors callers derive from this edge list (e.g. GCN edge norms)
         self._schedule()
 
@@ -128,7 +128,7 @@ class GraphPlan:
         # edge weights arrive in CSR order: the transposed walk reads them through `permute` (a COO-built plan's CSC side
         # carries the original edge id of every position in its own `perm` instead)
         gp._bwd.wperm = gp._posT
-        gp._rowidx = None
+        gp._rowidx = gp._tpos = None
         gp.aux = {}
         gp._schedule()
         return gp
@@ -199,6 +199,17 @@ class GraphPlan:
             inv[pf.long()] = ar
             self._posT = inv[pt.long()].contiguous()
         return self._posT
+
+    @property
+    def tpos(self):
+        """forward sorted position -> transposed sorted position (int32 [E]): the inverse of `posT` — where
+        ggl_spmm_max_mask scatters an edge's winner bits for the transposed walk of the max backward."""
+        if self._tpos is None:
+            posT = self.posT
+            self._tpos = torch.empty_like(posT)
+            eng = self.engine
+            eng._check(eng.lib.ggl_invert_perm(_ptr(posT), self.E, _ptr(self._tpos), eng._stream(posT.device)))
+        return self._tpos
 
 
 class _PlanCache:
@@ -662,7 +673,7 @@ class Engine:
                                                 self._stream(dev)))
         return out
 
-    def _spmm_fwd(self, op, plan, col, w, x, n_out, perm_override=None, aux=None):
+    def _spmm_fwd(self, op, plan, col, w, x, n_out, perm_override=None, aux=None, gp=None):
         """op in sum/mean/max/mean_bwd/max_bwd.  x [N_in, *]; returns out [n_out, *] (+argsrc)."""
         dev = x.device
         K = int(math.prod(x.shape[1:]))
@@ -708,7 +719,16 @@ class Engine:
                 self._check(L.ggl_spmm_mean_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
                                                 _ptr(aux), K, _ptr(out), st))
         elif op == "max_bwd":
-            if int(L.ggl_get_option(b"maxbwd_arg32")):   # A/B knob: witnesses from a compact int32 copy (one [N, K] pass)
+            mk = int(L.ggl_get_option(b"maxbwd_mask"))
+            if gp is not None and mk > 0 and K >= mk:
+                # a 1-bit winner mask built in DESTINATION order (the witness row is wave-uniform there), read in the
+                # transposed walk's own order: K / 8 bytes per edge instead of 8K (include/ggl_mpops.h)
+                mask = torch.empty(int(L.ggl_spmm_max_mask_bytes(plan.E, K)) // 4 + 4, dtype=torch.int32, device=dev)
+                fs = gp.fwd.c_struct(None)
+                self._check(L.ggl_spmm_max_mask(ctypes.byref(fs), _ptr(gp.col), _ptr(gp.tpos), _ptr(aux), K, _ptr(mask), st))
+                self._check(L.ggl_spmm_max_bwd_mask(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
+                                                    _ptr(mask), K, _ptr(out), st))
+            elif int(L.ggl_get_option(b"maxbwd_arg32")):   # A/B knob: witnesses from a compact int32 copy (one [N, K] pass)
                 aux32 = aux.to(torch.int32)
                 self._check(L.ggl_spmm_max_bwd32(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
                                                  _ptr(aux32), K, _ptr(out), st))
@@ -878,7 +898,7 @@ class Engine:
                 gp = ctx.gp
                 (arg,) = ctx.saved_tensors
                 gx, _ = eng._spmm_fwd("max_bwd", gp.bwd, gp.colT, ctx.w, g.contiguous(), gp.N_src,
-                                      aux=arg)
+                                      aux=arg, gp=gp)
                 return None, None, gx
 
         class BSpMMSum(torch.autograd.Function):  # src/gspmm.cpp:204-260

@@ -39,7 +39,13 @@ extern "C" {
 /* 5 (round 3): + ggl_bspmm_grad_w_sorted[_scratch_bytes]; v4's number had not been raised for the symbols added
  * late in round 2 (ggl_sample_hop, ggl_block_transpose, ggl_gat_sh_*, ggl_segment_hub16*, ggl_spmm_col_blocks) */
 /* 6 (round 4): + ggl_calib_stream (bench.py's achievable-rate yardstick) */
-#define GGL_ABI_VERSION 7
+/* 7 (round 4): ggl_segplan_t GREW by `long_order` and `max_len` (appended; hubf32.hip's serial hub walk); + ggl_spmm_max_bwd32;
+ *   ggl_policy_gradw_sorted takes (H, C).  Because the struct grew, a caller compiled against ABI <= 6 would hand the
+ *   library a SHORTER struct than it reads: every caller MUST check ggl_abi_version() == GGL_ABI_VERSION before it passes
+ *   a ggl_segplan_t (gammagl_amd/_lib.py bind(), ggl_torch.cpp api_for() both refuse a mismatching library). */
+/* 8 (round 5): + ggl_invert_perm, ggl_spmm_max_mask[_bytes], ggl_spmm_max_bwd_mask (gspmm max backward through a 1-bit
+ *   winner mask); options hub_one_launch, maxbwd_mask.  No struct change. */
+#define GGL_ABI_VERSION 8
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
 enum {
@@ -243,6 +249,19 @@ int ggl_spmm_max_bwd(const ggl_segplan_t *planT, const int32_t *colT, const floa
  * hosts' default: unmeasured on the GPU (the Engine takes it with the option `maxbwd_arg32`; results identical). */
 int ggl_spmm_max_bwd32(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
                        const float *g, const int32_t *argsrc32, int64_t K, float *gx, void *stream);
+/* The max backward through a WINNER MASK (round 5; same sums in the same order as ggl_spmm_max_bwd, spmm_max_cpu.cpp:88-93):
+ *   ggl_spmm_max_mask  walks the FORWARD plan (rows = destinations, where argsrc's row is wave-uniform) and writes, for the
+ *     edge at forward position p, bit k = [argsrc[dst, k] == colF[p]] into mask word tpos[p] * ceil(K/32) + k/32, bit k%32;
+ *     tpos[p] = the edge's position in the TRANSPOSED plan (ggl_invert_perm of the hosts' posT), once per graph;
+ *   ggl_spmm_max_bwd_mask  is the transposed walk reading K/8 mask bytes per edge instead of 8K witness bytes.
+ * mask: ggl_spmm_max_mask_bytes(E, K) bytes, fully overwritten by ggl_spmm_max_mask. */
+size_t ggl_spmm_max_mask_bytes(int64_t E, int64_t K);
+int ggl_spmm_max_mask(const ggl_segplan_t *planF, const int32_t *colF, const int32_t *tpos, const int64_t *argsrc,
+                      int64_t K, uint32_t *mask, void *stream);
+int ggl_spmm_max_bwd_mask(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
+                          const float *g, const uint32_t *mask, int64_t K, float *gx, void *stream);
+/* inv[perm[i]] = i for a permutation of [0, n), n < 2^31 */
+int ggl_invert_perm(const int32_t *perm, int64_t n, int32_t *inv, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bspmm — multi-head SpMM, f32; supersedes bspmm_sum_cpu_{forward,backward}

@@ -414,6 +414,8 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
                     assert int(eng.lib.ggl_spmm_col_blocks(E, K, N)) > 1
                     # hub_one_launch = 1 (round 5): ONE hub launch over the full width in front of the first block + one
                     # long_final behind the last; 0: a hub launch and a long_final per column block — same bits
+                    bb = rng.standard_normal(K).astype(np.float32)
+                    acc0 = rng.standard_normal((N, K)).astype(np.float32)
                     for one in (1, 0):
                         with option(eng, "hub_one_launch", one):
                             xt = to_t(x, dev).requires_grad_(True)
@@ -423,11 +425,9 @@ def check_exact_long_rows(eng, dev, oracle, chunk=64):
                             assert_same(to_np(xt.grad), want_g, f"exact spmm sum backward K{K} column blocks one_hub={one}")
                             assert_same(to_np(eng.c_spmm_mean(it, wt, to_t(x, dev))), oracle.spmm_mean_fwd(index, w, x)[0],
                                         f"exact spmm mean K{K} column blocks one_hub={one}")
-                            bb = rng.standard_normal(K).astype(np.float32)
                             ye = eng.spmm_epi(gp, wt, to_t(x, dev), "sum", bias=to_t(bb, dev), relu=True)
                             assert_same(to_np(ye), np.maximum(want + bb, 0).astype(np.float32),
                                         f"exact spmm epi K{K} column blocks one_hub={one}")
-                            acc0 = rng.standard_normal((N, K)).astype(np.float32)
                             outa = to_t(acc0, dev)
                             eng.spmm_sum_into(gp.fwd, gp.col, wt, to_t(x, dev), outa, accumulate=True)
                             # (out += : the chain of a row starts from what `out` held — no oracle form; both launch
@@ -1952,3 +1952,57 @@ def check_round4_paths(eng, dev, oracle):
         oy, oarg = oracle.spmm_max_fwd(index, w, x)
         assert_same(to_np(y), oy, f"spmm max K{K} (padded walk)")
         np.testing.assert_allclose(to_np(xt.grad), oracle.spmm_max_bwd(index, w, go, oarg), rtol=1e-5, atol=1e-5)
+
+
+def check_max_backward_forms(eng, dev, oracle, chunk=64):
+    """gspmm(max) backward three ways — int64 witnesses (ggl_spmm_max_bwd), int32 witnesses (ggl_spmm_max_bwd32) and the
+    1-bit winner mask of round 5 (ggl_spmm_max_mask in destination order -> ggl_spmm_max_bwd_mask in source order): the same
+    gradient, bit for bit, as the oracle (spmm_max_cpu.cpp:57-99) — ties, DUPLICATE edges (each copy is fed), empty rows, a
+    hub source (chunked transposed rows) and a hub destination (the mask kernel's chunk blocks), sorted and shuffled edge
+    lists, widths below / at / above one mask word, ragged widths, several 256-column passes."""
+    old = eng.chunk
+    eng.chunk = chunk
+    eng.clear_caches()
+    try:
+        rng = np.random.default_rng(11)
+        N, E = 60, 3000
+        for K in (1, 4, 7, 32, 33, 47, 64, 100, 128, 130, 256, 300):
+            index = np.stack([rng.integers(0, N - 4, size=E), rng.integers(0, N - 4, size=E)]).astype(np.int64)
+            index[0, :900] = 2                                          # hub source
+            index[1, 1200:2100] = 7                                     # hub destination
+            index[:, 1000:1100] = index[:, 1100:1200]                   # duplicate edges
+            for shuffle in (True, False):
+                if shuffle:
+                    index = np.ascontiguousarray(index[:, rng.permutation(E)])
+                else:
+                    index = np.ascontiguousarray(index[:, np.argsort(index[1], kind="stable")])
+                w = rng.standard_normal(E).astype(np.float32)
+                xs = np.round(rng.standard_normal((N, K)) * 2).astype(np.float32)   # (rounded: plenty of ties)
+                go = rng.standard_normal((N, K)).astype(np.float32)
+                _, arg = oracle.spmm_max_fwd(index, w, xs)
+                want = oracle.spmm_max_bwd(index, w, go, arg)
+                it, wt = to_t(index, dev), to_t(w, dev)
+                gp = eng.graph_plan(it, N)
+                assert gp.fwd.n_long >= 1 and gp.bwd.n_long >= 1
+                one_piece = to_np(gp.bwd.counts() <= gp.bwd.chunk)          # (chunked transposed rows: within rounding)
+                for name, opts in (("int64 witnesses", {"maxbwd_mask": 0, "maxbwd_arg32": 0}),
+                                   ("int32 witnesses", {"maxbwd_mask": 0, "maxbwd_arg32": 1}),
+                                   ("winner mask", {"maxbwd_mask": 1, "maxbwd_arg32": 0})):
+                    with option(eng, "maxbwd_mask", opts["maxbwd_mask"]), option(eng, "maxbwd_arg32", opts["maxbwd_arg32"]):
+                        for call in range(2):       # (second call: weights streamed from their sorted copy)
+                            xt = to_t(xs, dev).requires_grad_(True)
+                            eng.c_spmm_max(it, wt, xt).backward(to_t(go, dev))
+                            got = to_np(xt.grad)
+                            assert_same(got[one_piece], want[one_piece], f"max backward, {name}, K{K} shuffle={shuffle} call {call}")
+                            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4)
+                # no weights
+                with option(eng, "maxbwd_mask", 1):
+                    xt = to_t(xs, dev).requires_grad_(True)
+                    eng.c_spmm_max(it, None, xt).backward(to_t(go, dev))
+                    ones = np.ones(E, np.float32)
+                    _, arg1 = oracle.spmm_max_fwd(index, ones, xs)
+                    want1 = oracle.spmm_max_bwd(index, ones, go, arg1)
+                    assert_same(to_np(xt.grad)[one_piece], want1[one_piece], f"max backward, winner mask, no weights K{K}")
+    finally:
+        eng.chunk = old
+        eng.clear_caches()

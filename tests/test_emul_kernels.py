@@ -150,29 +150,8 @@ def test_host_build_walks_every_summing_row_in_one_piece(eng, oracle):
         eng.clear_caches()
 
 
-def test_max_backward_with_int32_witnesses_is_the_same_walk(eng, oracle):
-    """ggl_spmm_max_bwd32 (option maxbwd_arg32: the witnesses from a compact int32 copy): the same gradient, bit for bit,
-    as the int64 walk and as the oracle — ties, duplicate edges, empty rows, a hub source, odd and 16-byte widths."""
-    import numpy as np
-    rng = np.random.default_rng(11)
-    N, E = 60, 3000
-    for K in (1, 4, 7, 32, 47, 64):
-        index = np.stack([rng.integers(0, N - 4, size=E), rng.integers(0, N - 4, size=E)]).astype(np.int64)
-        index[0, :900] = 2
-        index[:, 1000:1100] = index[:, 1100:1200]                  # duplicate edges
-        w = rng.standard_normal(E).astype(np.float32)
-        xs = np.round(rng.standard_normal((N, K)) * 2).astype(np.float32)   # (rounded: plenty of ties)
-        go = rng.standard_normal((N, K)).astype(np.float32)
-        _, arg = oracle.spmm_max_fwd(index, w, xs)
-        want = oracle.spmm_max_bwd(index, w, go, arg)
-        got = {}
-        for knob in (0, 1):
-            with pc.option(eng, "maxbwd_arg32", knob):
-                xt = pc.to_t(xs, DEV).requires_grad_(True)
-                eng.c_spmm_max(pc.to_t(index, DEV), pc.to_t(w, DEV), xt).backward(pc.to_t(go, DEV))
-                got[knob] = pc.to_np(xt.grad)
-        pc.assert_same(got[0], want, f"max backward K{K}")
-        pc.assert_same(got[1], want, f"max backward, int32 witnesses K{K}")
+def test_max_backward_forms(eng, oracle):
+    pc.check_max_backward_forms(eng, DEV, oracle)
 
 
 def test_gat_fused_random(eng, oracle):

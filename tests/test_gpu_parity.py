@@ -1000,6 +1000,14 @@ def test_int_vector_lanes_and_padded_max_walk(eng, dev, oracle):
     pc.check_round4_paths(eng, dev, oracle)
 
 
+def test_max_backward_forms(eng, dev, oracle):
+    """gspmm(max) backward through int64 witnesses, int32 witnesses and the round-5 winner mask: one gradient, the oracle's;
+    also through folded 2-D grids."""
+    pc.check_max_backward_forms(eng, dev, oracle)
+    with pc.option(eng, "max_grid_x", 3):
+        pc.check_max_backward_forms(eng, dev, oracle)
+
+
 def test_sage_replica_step_as_two_graphs_around_the_allreduce(eng, dev):
     """Config 4 with replicas: [sample .. backward, flatten] | RCCL all-reduce (eager) | [unflatten, Adam] as two replayed
     hipGraphs — on ONE GPU with a world-size-1 NCCL group standing in for the replicas (the collective is real, the
