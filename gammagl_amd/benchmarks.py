@@ -311,8 +311,10 @@ def pmc_probe_gcn(args, dev, eng):
     torch.cuda.synchronize()
     # (reps + 1 warm-up) aggregates of `launches` dispatches each were the LAST dispatches of the dominant kernel: the
     # parent averages the counters over exactly those (a clustered order runs the same kernel while it is computed)
+    # ... and the hub walk beside them runs ONCE per aggregate since round 5 (hub_one_launch; once per launch otherwise)
+    hub = 5 * (1 if (launches > 1 and int(eng.lib.ggl_get_option(b"hub_one_launch"))) else launches)
     print(f"pmc-probe: E={gp.E} rows_in={rows} K={args.hidden} launches/aggregate={launches} ms/aggregate={ms:.3f} "
-          f"dispatches={5 * launches}", flush=True)
+          f"aggregates=5 dispatches={5 * launches},{hub}", flush=True)
 
 
 def run_gcn(args, dev, rank, world, eng=None):
@@ -496,7 +498,7 @@ def pmc_probe_gat(args, dev, eng):
         for _ in range(4):
             eng.gat_fused(ei, el, er, x, 0.2)
     torch.cuda.synchronize()
-    print("pmc-probe: gat forward 8x8 on the Reddit-sized graph dispatches=4", flush=True)
+    print("pmc-probe: gat forward 8x8 on the Reddit-sized graph aggregates=4 dispatches=4", flush=True)
 
 
 def run_gat(args, dev, rank, world, eng=None):

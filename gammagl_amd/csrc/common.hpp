@@ -98,10 +98,11 @@ struct Options {
   // f32 sums: rows longer than the plan's chunk are added up in the reference's serial order (hubf32.hip: bit-identical to
   // the CPU extension on EVERY row) instead of chunk by chunk (within rounding of it); 0 = the chunked walk (A/B switch)
   int64_t exact_long_rows = 1;
-  int64_t maxbwd_arg32 = 0;       // hosts: gspmm max backward through ggl_spmm_max_bwd32 (A/B knob)
-  // hosts: gspmm max backward through a 1-bit winner mask (ggl_spmm_max_mask + ggl_spmm_max_bwd_mask) for rows of at least
-  // this many columns (0 = never: the witness walk)
-  int64_t maxbwd_mask = 32;
+  // hosts: gspmm max backward (products-sized graph, forward + backward, profiles/r5_max_backward.txt):
+  //   K = 64 : int64 witnesses 16.5 ms, int32 witnesses (ggl_spmm_max_bwd32) 12.8, winner mask 15.8 (its pre-pass: 6.4)
+  //   K = 256: int64 67.6, int32 52.2, winner mask (ggl_spmm_max_mask + ggl_spmm_max_bwd_mask) 41.6 (pre-pass: 7.8)
+  int64_t maxbwd_arg32 = 1;       // witnesses from a compact int32 copy ...
+  int64_t maxbwd_mask = 128;      // ... and from this many columns up a 1-bit winner mask instead (0 = never)
   int64_t exact_long_max = (int64_t)1 << 21;   // ... unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
   int64_t hub_one_launch = 1;     // ... once per aggregate over the full width where the aggregate runs as column blocks (0 = once per block)
@@ -150,8 +151,8 @@ struct HubF32Args {
   int64_t avg_long_len;     // average length of the long rows (picks the stage size)
   int f64;                  // segment sums of doubles: x / x_ld / K / partial in 4-byte WORDS (2 per element), see hubf32.hip
 };
-int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *forked);
-int hub_f32_join(hipStream_t stream);
+int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, int *forked);   // *forked: 0 or the join token
+int hub_f32_join(hipStream_t stream, int token);
 #endif
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -272,49 +272,71 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
   if (lane < ncol) a.partial[j * a.K + c0 + lane] = acc;
 }
 
-// ---- the side stream the hub launch runs on (one per device, created on first use) ----------------------------------
+// ---- the side streams the hub launch runs on (two per device, created on first use) ----------------------------------
+// One for callers whose stream is being recorded into a hipGraph, one for eager callers: an eager launch must never land on a
+// stream that another thread's capture has pulled in through its fork event (it would be recorded into that graph, or
+// fail).  Every call takes its OWN join event from a small ring (round 4 shared one per device: a later record from a
+// capturing stream could leave an eager stream waiting on a captured event); the ring is sized far above the number of
+// hub launches that can be un-joined at once (one per host thread inside the library).
+constexpr int kHubJoinRing = 32;
 struct HubSide {
   hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t fork = nullptr, join[kHubJoinRing] = {};
+  int next = 0;
   bool ok = false;
-  // two host threads (the caller's and an autograd worker) may launch through here: the fork .. join-record sequence of
-  // one call must not interleave with another's (the events are shared).  A later call's join record sits behind this
-  // call's hub launch in the side stream's FIFO, so waiting on it can only over-wait.
+  // two host threads (the caller's and an autograd worker) may launch through here: the fork-record .. launch ..
+  // join-record sequence of one call must not interleave with another's (fork is shared, the FIFO order is the contract)
   std::mutex mu;
 };
-static HubSide *hub_side() {
-  static HubSide sides[16];
+static HubSide *hub_side(bool capturing) {
+  static HubSide sides[16][2];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  HubSide &s = sides[dev];
+  HubSide &s = sides[dev][capturing ? 1 : 0];
   static std::mutex create_mu;
   std::lock_guard<std::mutex> g(create_mu);
   if (!s.ok) {
     // (a high-priority queue for the hub walk was measured and changes nothing: products step 74.99 vs 75.05 ms, bspmm
     //  16 x 16 forward 17.39 vs 17.56 — profiles/r4_negative_results.txt)
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    bool good = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    good = good && hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; good && i < kHubJoinRing; ++i) good = hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) == hipSuccess;
+    if (!good) {      // nothing half-made stays behind (and the next call starts from scratch)
+      for (int i = 0; i < kHubJoinRing; ++i)
+        if (s.join[i]) { (void)hipEventDestroy(s.join[i]); s.join[i] = nullptr; }
+      if (s.fork) { (void)hipEventDestroy(s.fork); s.fork = nullptr; }
+      if (s.stream) { (void)hipStreamDestroy(s.stream); s.stream = nullptr; }
+      (void)hipGetLastError();
+      return nullptr;
+    }
     s.ok = true;
   }
   return &s;
 }
+static bool stream_is_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
 
-// Launch the exact-order walk of the plan's long rows.  With `beside` the launch goes to the library's side stream,
-// forked from `stream` here; the caller launches its kernel over the other rows on `stream` and then calls
-// hub_f32_join(stream) before anything reads `partial`.
-int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *forked) {
-  *forked = false;
+// Launch the exact-order walk of the plan's long rows.  With `beside` the launch goes to one of the library's side
+// streams, forked from `stream` here; the caller launches its kernel(s) over the other rows on `stream` and then calls
+// hub_f32_join(stream, *forked) before anything reads `partial`.  *forked = 0: not forked; otherwise the join token.
+int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, int *forked) {
+  *forked = 0;
   if (a.n_long <= 0 || a.K <= 0) return GGL_OK;
   hipStream_t s = stream;
-  HubSide *side = beside ? hub_side() : nullptr;
+  const bool capturing = beside && stream_is_capturing(stream);
+  HubSide *side = beside ? hub_side(capturing) : nullptr;
   std::unique_lock<std::mutex> lock;
+  int token = 0;
   if (side != nullptr) {
     lock = std::unique_lock<std::mutex>(side->mu);
     GGL_HIP_CHECK(hipEventRecord(side->fork, stream));
     GGL_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
     s = side->stream;
-    *forked = true;
+    token = 1 + side->next + (capturing ? kHubJoinRing : 0);
+    side->next = (side->next + 1) % kHubJoinRing;
   }
   const bool narrow = a.K <= 16;                       // 16-column slabs, 4 lanes per element
   const int64_t slabs = ceil_div(a.K, (int64_t)(narrow ? 16 : 64));
@@ -365,14 +387,18 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, bool *f
 #undef GGL_HF
 #undef GGL_HF2
   GGL_LAUNCH_CHECK();
-  if (*forked) GGL_HIP_CHECK(hipEventRecord(side->join, side->stream));
+  if (token) {
+    GGL_HIP_CHECK(hipEventRecord(side->join[(token - 1) % kHubJoinRing], side->stream));
+    *forked = token;
+  }
   return GGL_OK;
 }
 
-int hub_f32_join(hipStream_t stream) {
-  HubSide *side = hub_side();
+int hub_f32_join(hipStream_t stream, int token) {
+  if (token <= 0) return GGL_OK;
+  HubSide *side = hub_side(token > kHubJoinRing);
   GGL_REQUIRE(side != nullptr, GGL_EHIP, "hub side stream is gone");
-  GGL_HIP_CHECK(hipStreamWaitEvent(stream, side->join, 0));
+  GGL_HIP_CHECK(hipStreamWaitEvent(stream, side->join[(token - 1) % kHubJoinRing], 0));
   return GGL_OK;
 }
 

@@ -706,7 +706,7 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
   ReduceArgs a = a_in;
   const bool uniform = !RAG && (d.logL == 6) && std::is_same<T, float>::value;   // (ragged rows: K <= 128 only)
   S *out = static_cast<S *>(a.out);
-  bool forked = a.phase == 2 && a.hub_forked != 0;
+  int forked = a.phase == 2 ? a.hub_forked : 0;     // the hub launch's join token (0 = nothing to join)
   const bool exact = exact_long_applies<T, OP, MODE>(a);
 #ifdef GGL_EMULATE
   // the host build walks a row with one thread anyway: no chunks at all IS the reference's serial order — for every
@@ -763,7 +763,7 @@ static int launch_idx(const ReduceArgs &a_in, ReduceDims d, hipStream_t stream) 
   if (a.phase == 1) return GGL_OK;
 #ifndef GGL_EMULATE
   if (forked) {
-    const int rc = hub_f32_join(stream);
+    const int rc = hub_f32_join(stream, forked);
     if (rc) return rc;
   }
 #endif
@@ -874,7 +874,8 @@ static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
   // column block, every slab of every hub row an independent workgroup — the K / 64 add chains of the longest row run
   // side by side instead of one per column-block launch, each of which used to end 0.2-0.5 ms after its row walk — joined
   // before ONE long_final over the full width.  The partial buffer holds n_chunks >= n_long full-width rows.
-  bool one_hub = false, forked = false;
+  bool one_hub = false;
+  int forked = 0;
 #ifndef GGL_EMULATE
   if (options().hub_one_launch != 0 && exact_long_applies<float, OP, MODE>(a0)) {
     GGL_REQUIRE(a0.partial != nullptr, GGL_EWORKSPACE, "plan has long rows but no partial buffer");
@@ -905,7 +906,7 @@ static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
   if (one_hub) {
     ReduceArgs a = a0;
     a.phase = 2;
-    a.hub_forked = forked ? 1 : 0;
+    a.hub_forked = forked;
     return launch_f32<OP, MODE>(a, stream);
   }
   return GGL_OK;

@@ -64,7 +64,8 @@ using torch::autograd::variable_list;
   X(ggl_sample_hop_workspace_bytes) X(ggl_sample_hop)                                                                \
   X(ggl_policy_chunk) X(ggl_policy_spmm_width) X(ggl_policy_head_channels) X(ggl_policy_mean_bwd_prescale)            \
   X(ggl_policy_gradw_sorted) X(ggl_policy_xcd_run_rows) X(ggl_policy_row_order)                                     \
-  X(ggl_spmm_max_mask_bytes) X(ggl_spmm_max_mask) X(ggl_spmm_max_bwd_mask) X(ggl_invert_perm) X(ggl_get_option)
+  X(ggl_spmm_max_mask_bytes) X(ggl_spmm_max_mask) X(ggl_spmm_max_bwd_mask) X(ggl_invert_perm) X(ggl_get_option)      \
+  X(ggl_spmm_max_bwd32)
 
 struct Api {
   void *handle = nullptr;
@@ -572,6 +573,9 @@ static std::pair<Tensor, Tensor> spmm_fwd(SpOp op, GraphPlan &gp, const SegPlan 
                                      reinterpret_cast<uint32_t *>(mask.data_ptr<int32_t>()), st));
         check(a, a.ggl_spmm_max_bwd_mask(&cs, c, wp, by_pos, xp, reinterpret_cast<const uint32_t *>(mask.data_ptr<int32_t>()),
                                          K, op_, st));
+      } else if (a.ggl_get_option("maxbwd_arg32") != 0) {   // witnesses from a compact int32 copy (one [N, K] pass)
+        Tensor aux32 = aux.to(at::kInt);
+        check(a, a.ggl_spmm_max_bwd32(&cs, c, wp, by_pos, xp, aux32.data_ptr<int32_t>(), K, op_, st));
       } else {
         check(a, a.ggl_spmm_max_bwd(&cs, c, wp, by_pos, xp, aux.data_ptr<int64_t>(), K, op_, st));
       }

@@ -109,6 +109,7 @@ class PartitionedGraph:
         self.rank, self.world, self.group = rank, world, group
         self.dry = send_rows is not None
         self.comm = world > 1 or self_halo_from is not None or self.dry
+        _apply_dist_exact(self)
         dev = s.device
         self.bounds = list(bounds)
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
@@ -270,29 +271,16 @@ class PartitionedGraph:
         return _HaloAggregate.apply(h, self, bias, bool(relu), p, bool(halo_included))
 
 
-def _chunked_when_partitioned(fn):
-    """A/B switch (GGL_DIST_EXACT=0): run one forward / backward of a partitioned aggregate with the f32 hub rows CHUNKED
-    (library option `exact_long_rows` = 0 for the duration, restored afterwards).  A row of a partitioned graph is the sum of
-    two launches — its local-source edges, then its halo-source edges added on top — so the reference's serial order is out
-    of reach there whatever a single launch does; the serial hub walk (hubf32.hip) is kept anyway because since it
-    starts its longest rows first it is the FASTER walk: products-sized dry shares 17.05 -> 15.94 ms per step at P = 8,
-    29.5 -> 27.1 at P = 4 (profiles/r4_dry_share_knobs.txt; before the longest-first order it cost 0.6 ms at P = 8)."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapped(ctx, *args):
-        pg = next((a for a in args if isinstance(a, PartitionedGraph)), None) or getattr(ctx, "pg", None)
-        if pg is None or not pg.comm or DIST_EXACT:
-            return fn(ctx, *args)
-        lib = pg.eng.lib
-        old = int(lib.ggl_get_option(b"exact_long_rows"))
-        lib.ggl_set_option(b"exact_long_rows", 0)
-        try:
-            return fn(ctx, *args)
-        finally:
-            lib.ggl_set_option(b"exact_long_rows", old)
-
-    return wrapped
+def _apply_dist_exact(pg):
+    """A/B switch (GGL_DIST_EXACT=0): partitioned aggregates walk their f32 hub rows CHUNKED.  A row of a partitioned graph is
+    the sum of two launches — its local-source edges, then its halo-source edges added on top — so the reference's serial
+    order is out of reach there whatever a single launch does; the serial hub walk (hubf32.hip) is kept anyway because since
+    it starts its longest rows first it is the FASTER walk: products-sized dry shares 17.05 -> 15.94 ms per step at P = 8,
+    29.5 -> 27.1 at P = 4 (profiles/r4_dry_share_knobs.txt).  The switch sets the library option `exact_long_rows` ONCE, when
+    a partitioned graph with a communicator is constructed — a rank is a process, and the option is process-wide (round 4
+    flipped it around every forward / backward, which other threads' launches could observe half-way)."""
+    if pg.comm and not DIST_EXACT:
+        pg.eng.lib.ggl_set_option(b"exact_long_rows", 0)
 
 
 class _HaloAggregate(torch.autograd.Function):
@@ -320,7 +308,6 @@ class _HaloAggregate(torch.autograd.Function):
         return [(i * w, (i + 1) * w) for i in range(n)]
 
     @staticmethod
-    @_chunked_when_partitioned
     def forward(ctx, h, pg, bias, relu, p_drop, pre=False):
         eng = pg.eng
         pre = bool(pre and pg.comm)      # halo rows already in place: NO collective, whether or not this rank has a halo
@@ -379,7 +366,6 @@ class _HaloAggregate(torch.autograd.Function):
         return out
 
     @staticmethod
-    @_chunked_when_partitioned
     def backward(ctx, g):
         pg = ctx.pg
         eng = pg.eng
@@ -444,7 +430,6 @@ class _ConstInputLayer(torch.autograd.Function):
     (products-sized graph, 8 ranks: 0.6 ms of GEMM instead of 1.7 GB over xGMI per step)."""
 
     @staticmethod
-    @_chunked_when_partitioned
     def forward(ctx, x_cat, w, pg, bias, relu, p_drop, pad_out):
         eng, nl = pg.eng, pg.n_local
         dev = x_cat.device
@@ -474,7 +459,6 @@ class _ConstInputLayer(torch.autograd.Function):
         return out
 
     @staticmethod
-    @_chunked_when_partitioned
     def backward(ctx, g):
         pg = ctx.pg
         eng, nl = pg.eng, pg.n_local

@@ -193,12 +193,16 @@ class SAGEBlockTrainer:
             return self.graph
         import torch.distributed as dist
 
-        self._params = [p for p in self.net.parameters()]
+        # the FIRST warm-up step runs through the eager step(): which parameters receive a gradient at all is only known
+        # after a backward — the flat buffer covers exactly those (step() filters `p.grad is not None` the same way; a
+        # parameter without a gradient used to crash _grads_to_flat)
+        self.step(x, y, seeds)
+        self._params = [p for p in self.net.parameters() if p.grad is not None]
         self._flat = torch.zeros(sum(p.numel() for p in self._params), device=x.device, dtype=torch.float32)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(int(warmup), 1)):      # plans, sampler scratch, Adam state, RCCL channels exist before capture
+            for _ in range(max(int(warmup), 1) - 1):  # plans, sampler scratch, Adam state, RCCL channels exist before capture
                 self._front(x, y, seeds)
                 dist.all_reduce(self._flat, group=self.group)
                 self._back()
@@ -217,9 +221,11 @@ class SAGEBlockTrainer:
             return self.graph
         pool = torch.cuda.graph_pool_handle()
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1, pool=pool):
+        # "thread_local": an RCCL group is live — its watchdog thread polls events, which the default "global" capture
+        # mode turns into a capture error (GraphedStep's docstring; the ONE_GRAPH branch above does the same)
+        with torch.cuda.graph(self._g1, pool=pool, capture_error_mode="thread_local"):
             self._loss = self._front(x, y, seeds)
-        with torch.cuda.graph(self._g2, pool=pool):
+        with torch.cuda.graph(self._g2, pool=pool, capture_error_mode="thread_local"):
             self._back()
         self.graph = self._replay_replica
         return self.graph

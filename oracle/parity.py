@@ -67,3 +67,30 @@ def check(got, ref, what, tol=TOL, rows_in_one_piece=None, floor_min=0.0):
     r = report(got, ref, tol, rows_in_one_piece, floor_min)
     assert r["ok"], f"{what}: {r}"
     return r
+
+
+def gat_truth_f64(ei, el, er, x, go, n, slope=0.2):
+    """gat_conv.py:103-112 + softmax.py:29-35 in float64 with torch on the tensors' device, under autograd: the ground truth
+    both f32 evaluations of a GAT layer (the fused HIP kernels, the reference ops composed) are measured against.
+    Returns (out, gx, g_el, g_er) as float64."""
+    src, dst = ei[0], ei[1]
+    xd, eld, erd = (t.detach().double().requires_grad_(True) for t in (x, el, er))
+    s = torch.nn.functional.leaky_relu(eld[src] + erd[dst], slope)
+    m = torch.full((n, s.shape[1]), -float("inf"), dtype=torch.float64, device=s.device)
+    m = m.scatter_reduce(0, dst.view(-1, 1).expand_as(s), s, reduce="amax", include_self=True)
+    ex = torch.exp(s - m[dst])
+    den = torch.zeros_like(m).index_add_(0, dst, ex)
+    alpha = ex / (den[dst] + 1e-16)
+    out = torch.zeros(n, *x.shape[1:], dtype=torch.float64, device=x.device).index_add_(0, dst, xd[src] * alpha.unsqueeze(-1))
+    out.backward(go.double())
+    return out.detach(), xd.grad, eld.grad, erd.grad
+
+
+def gat_errors_vs_truth(truth, got):
+    """{name: max row-scale relative error} of an (out, gx, g_el, g_er) tuple against gat_truth_f64's (logit gradients
+    cancel to ~0 over whole rows: their scale floor is the tensor's mean magnitude, as in the f32-vs-f32 checks)."""
+    out = {}
+    for name, t64, a in zip(("out", "gx", "g_el", "g_er"), truth, got):
+        floor = float(t64.abs().mean()) if name in ("g_el", "g_er") else 0.0
+        out[name] = report(a.double().to(t64.device), t64, tol=1.0, floor_min=floor)["max_rel_err"]
+    return out

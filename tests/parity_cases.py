@@ -1783,6 +1783,33 @@ def check_neighbor_sample(fn, dev, oracle):
             assert np.array_equal(nodes[f_hi:f_hi + len(new)], new), "new nodes ascending"
             f_lo, f_hi = f_hi, f_hi + len(new)
         assert at == len(edges)
+    # DUPLICATE input nodes (the reference never deduplicates them: get_new_input_nodes only compares NEW ids with the list,
+    # neighbor_sample.cu:436-532): every copy is a frontier entry of its own, sampled independently, and an edge that leads
+    # to a duplicated node points at ONE of its positions — which one is unpinned (kernal_get_row's search is not
+    # restated; here: the first).  What is pinned: positions are valid and hold the right node, owners are per entry.
+    N, E = 40, 400
+    src = rng.integers(0, N, size=E)
+    dst = np.sort(rng.integers(0, N, size=E))
+    colptr = np.zeros(N + 1, np.int64)
+    np.add.at(colptr, dst + 1, 1)
+    colptr = np.cumsum(colptr)
+    row = src.astype(np.int64)
+    seeds = [5, 9, 5, 5, 12]
+    cp, rw, sd = to_t(colptr, dev), to_t(row, dev), to_t(np.array(seeds, np.int64), dev)
+    for fan in ([-1, -1], [3, 2]):
+        cols, rows, nodes, edges = (to_np(t) for t in fn(cp, rw, sd, torch.tensor(fan), False, False, 0))
+        assert nodes[: len(seeds)].tolist() == seeds
+        assert len(set(nodes[len(seeds):].tolist())) == len(nodes) - len(seeds), "appended nodes are distinct"
+        assert not (set(nodes[len(seeds):].tolist()) & set(seeds)), "a seed is never appended again"
+        assert np.array_equal(nodes[rows], row[edges]) and rows.min() >= 0 and rows.max() < len(nodes)
+        owner = nodes[cols]
+        assert np.all((colptr[owner] <= edges) & (edges < colptr[owner + 1]))
+        f = fan[0]
+        deg = colptr[np.array(seeds) + 1] - colptr[np.array(seeds)]
+        exp = deg if f < 0 else np.minimum(deg, f)
+        n0 = int(exp.sum())
+        assert np.array_equal(cols[:n0], np.repeat(np.arange(len(seeds)), exp)), "every copy of a seed is sampled for, in place"
+        assert np.all(rows[np.isin(row[edges], [5])] == 0), "an edge leading to a duplicated seed points at its first position"
 
 
 def check_cpp_fused_route(ops, eng, dev, oracle=None):

