@@ -190,6 +190,42 @@ def _gcn_data(pg, f_in, n_cls, seed, rank, dev, world):
     return x, y, train_local, max(int(nt), 1), gen
 
 
+def _norm_both_steps(pg, data, args, f_in, n_cls, dev, steps=4):
+    """Side figure (round-4 verdict, missing #5): the step as the reference's example runs it BY DEFAULT —
+    GCNModel(norm='both') with edge_weight=None, every GCNConv.forward computing its own symmetric normalisation from the
+    edge list (gcn_conv.py:88-102: two `degree` scatters, two pows, two [E] gathers, two [E] products per layer; the
+    `calc_gcn_norm` line of examples/gcn/gcn_trainer.py:58-59 is commented out there) — through layers.GCNModel, (a) as
+    shipped here: the weights computed once per edge_index and kept on the graph's plan, (b) recomputed in every
+    forward like the reference (layers.CACHE_GCN_NORM = False).  The headline step (norm='none' + precomputed weights) is
+    (a) minus the layer-side bookkeeping."""
+    from . import layers
+    from .trainer import GCNTrainer
+
+    x, y, train_local, _, _ = data
+    ei = pg.ei_loc                      # one rank: the whole graph, local ids = global ids
+    n = pg.n_local
+    res = {}
+    for label, cached in (("ms_per_step_cached", True), ("ms_per_step_uncached", False)):
+        layers.CACHE_GCN_NORM = cached
+        try:
+            tr = GCNTrainer(f_in, args.hidden, n_cls, num_layers=args.layers, norm="both", seed=args.seed, device=dev)
+            for _ in range(2):
+                tr.step(x, ei, y, train_local, n)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(x, ei, y, train_local, n)
+            torch.cuda.synchronize()
+            res[label] = (time.perf_counter() - t0) / steps * 1e3
+        finally:
+            layers.CACHE_GCN_NORM = True
+        del tr
+    res["note"] = ("GCNModel(norm='both'), edge_weight=None (the reference example's default, gcn_conv.py:88-102): cached = the "
+                   "normalised weights kept on the graph's plan; uncached = recomputed in every GCNConv.forward as the reference does")
+    torch.cuda.empty_cache()
+    return res
+
+
 def _wants_graph(args, pg, dev, world):
     """Record the step into a hipGraph?  One rank on a GPU only; `auto`: launch-bound sizes (bench.py --hipgraph)."""
     mode = getattr(args, "hipgraph", "off")
@@ -437,6 +473,9 @@ def run_gcn(args, dev, rank, world, eng=None):
     also = spec.get("also") if also in (None, "auto") else (None if also == "none" else also)
     also = [also] if isinstance(also, str) else list(also or [])
     also = [a for a in also if a != args.relabel]
+    if (world == 1 and not parts and dev.type == "cuda" and args.workload == "products"
+            and not getattr(args, "no_comparison", False)):
+        out["config"]["norm_both"] = _norm_both_steps(pg, data, args, f_in, n_cls, dev)
     ctx = {"pg": pg, "data": data}
     if also and world == 1 and not parts and not getattr(args, "no_comparison", False):
         host_graph = None

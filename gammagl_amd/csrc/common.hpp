@@ -105,6 +105,7 @@ struct Options {
   int64_t maxbwd_mask = 128;      // ... and from this many columns up a 1-bit winner mask instead (0 = never)
   int64_t exact_long_max = (int64_t)1 << 21;   // ... unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
+  int64_t gat_sh_waves = 0;       // >= 4: the output-layer GAT backward's source walk (dropout form) built for 4 wavefronts per SIMD (A/B)
   int64_t hub_one_launch = 1;     // ... once per aggregate over the full width where the aggregate runs as column blocks (0 = once per block)
 };
 Options &options();

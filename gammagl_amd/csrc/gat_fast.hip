@@ -624,8 +624,11 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
 
 // source walk of the backward (transposed plan): T[j,h,:] = sum_q alpha_q keep_q/(1-pd) gy[i_q,:] and
 // gel[j,h] = sum_q de_q, with <dA_ih, x_j> = <gy_i, z_jh>, z_j = the row's own transformed features (registers)
-template <bool DROP>
-__global__ __launch_bounds__(kBlock) void gat_sh_bwd_src_kernel(
+// WAVES: wavefronts per SIMD the register allocator is asked to leave room for (1 = no request).  With dropout the kernel
+// needs 140 registers = 3 wavefronts per SIMD (without: 127 = 4); asked for 4 it fits 128 with 10 spilled values (44 bytes of
+// scratch).  Option `gat_sh_waves` (A/B, round 5): profiles/r5_gat_sh_waves.txt.
+template <bool DROP, int WAVES = 1>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void gat_sh_bwd_src_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col /* colT */, const int32_t *__restrict__ posT,
     const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
     const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ z,
@@ -974,7 +977,10 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? planT->row_order : nullptr;
-    if (d.drop_thresh)
+    if (d.drop_thresh && options().gat_sh_waves >= 4)
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 4>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    else if (d.drop_thresh)
       GGL_LAUNCH((gat_sh_bwd_src_kernel<true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
                  planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
     else

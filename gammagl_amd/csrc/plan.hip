@@ -55,6 +55,7 @@ Options &options() {
     t.exact_side_stream = env_i64("GGL_EXACT_SIDE_STREAM", t.exact_side_stream);
     t.exact_long_max = env_i64("GGL_EXACT_LONG_MAX", t.exact_long_max);
     t.hub_one_launch = env_i64("GGL_HUB_ONE_LAUNCH", t.hub_one_launch);
+    t.gat_sh_waves = env_i64("GGL_GAT_SH_WAVES", t.gat_sh_waves);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
     return t;
@@ -297,6 +298,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "exact_side_stream")) o.exact_side_stream = value;
   else if (!strcmp(name, "exact_long_max")) o.exact_long_max = value;
   else if (!strcmp(name, "hub_one_launch")) o.hub_one_launch = value;
+  else if (!strcmp(name, "gat_sh_waves")) o.gat_sh_waves = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
@@ -321,6 +323,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "exact_side_stream")) return o.exact_side_stream;
   if (!strcmp(name, "exact_long_max")) return o.exact_long_max;
   if (!strcmp(name, "hub_one_launch")) return o.hub_one_launch;
+  if (!strcmp(name, "gat_sh_waves")) return o.gat_sh_waves;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
   return -1;

@@ -136,6 +136,9 @@ class MessagePassing(nn.Module):
         return self.update(x)
 
 
+CACHE_GCN_NORM = True    # False: every GCNConv.forward recomputes its normalisation, as the reference does (bench.py's side figure)
+
+
 class GCNConv(MessagePassing):
     def __init__(self, in_channels, out_channels, norm='both', add_bias=True):
         super().__init__()
@@ -153,7 +156,7 @@ class GCNConv(MessagePassing):
         edge_weight=None it depends on the graph alone, so it is computed once per edge_index and kept on the
         cached GraphPlan (the same tensor every call also lets the SpMM stream its sorted copy)."""
         gp = None
-        if edge_weight is None:
+        if edge_weight is None and CACHE_GCN_NORM:
             gp = _engine(edge_index).graph_plan(edge_index, num_nodes)
             hit = gp.aux.get(("gcn_norm", self._norm))
             if hit is not None:
