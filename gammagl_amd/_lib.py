@@ -75,7 +75,8 @@ SIGNATURES = {
     "ggl_spmm_max_bwd32": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
     "ggl_spmm_max_mask_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_spmm_max_mask": (c_int, [_P, _V, _V, _V, c_int64, _V, _V]),
-    "ggl_spmm_max_bwd_mask": (c_int, [_P, _V, _V, c_int, _V, _V, c_int64, _V, _V]),
+    "ggl_spmm_max_mask_words": (c_int64, [c_int64, c_int]),
+    "ggl_spmm_max_bwd_mask": (c_int, [_P, _V, _V, c_int, _V, _V, _V, c_int64, _V, _V]),
     "ggl_invert_perm": (c_int, [_V, c_int64, _V, _V]),
     "ggl_bspmm_sum": (c_int, [_P, _V, _V, c_int, _V, c_int64, c_int64, _V, _V]),
     "ggl_bspmm_grad_w": (c_int, [_V, _V, _V, c_int64, c_int64, c_int64, _V, _V]),

@@ -103,6 +103,8 @@ struct Options {
   //   K = 256: int64 67.6, int32 52.2, winner mask (ggl_spmm_max_mask + ggl_spmm_max_bwd_mask) 41.6 (pre-pass: 7.8)
   int64_t maxbwd_arg32 = 1;       // witnesses from a compact int32 copy ...
   int64_t maxbwd_mask = 128;      // ... and from this many columns up a 1-bit winner mask instead (0 = never)
+  int64_t maxbwd_mask_wlane = 0;   // ... its forward-order records assembled with v_writelane (inline asm) instead of selects (A/B)
+  int64_t maxbwd_mask_scatter = 0; // ... its records scattered to transposed positions instead of kept in forward order (A/B)
   int64_t exact_long_max = (int64_t)1 << 21;   // ... unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
   int64_t gat_sh_waves = 0;       // >= 4: the output-layer GAT backward's source walk (dropout form) built for 4 wavefronts per SIMD (A/B)

@@ -13,7 +13,7 @@ namespace ggl {
 // arithmetic per load, a predicated rescale per edge) against 12 memory instructions, and the Reddit-sized
 // 60 MB feature panel is cache-resident — 114.8 M edges x 16 lanes of that is ~5 ms of issue time on its
 // own.  These variants do the same walks with an order of magnitude fewer VALU instructions:
-//   * exp through v_exp_f32 (exp2(x * log2 e), ~1e-6 relative on the operand range of a softmax; the GAT
+//   * exp through v_exp_f32 (exp2(x * log2 e) with the scaling compensated since round 5: 1.2e-7 relative, see fexp; the GAT
 //     parity bar is 1e-5 relative against the oracle's three-pass restatement);
 //   * one rescale per block of 4 / 8 edges (block maximum first) instead of a predicated one per edge;
 //   * column indices as one 16-byte load per 4 edges (the walk is aligned to multiples of 4);
@@ -30,7 +30,21 @@ namespace ggl {
 // to 1e-5 relative, not bit-exact).  The host-emulated test build cannot shuffle between its sequentially
 // executed lanes: it keeps the kernels above for every shape (they also remain the path for other shapes).
 // =====================================================================================================
-__device__ __forceinline__ float fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896340736f); }
+// exp(v), v <= 0 (a softmax exponent), through v_exp_f32 (exp2, 1 ulp) with the argument scaling COMPENSATED (round 5):
+// v * log2(e) rounded to f32 carries |v| * 6e-8 of relative error into the result (1.7e-6 at v = -30 — ten times expf's,
+// and systematic along a row: it showed as 1.6e-5 in g_er against an fp64 evaluation of the layer where the reference's own
+// f32 composition has 5.5e-6, tests/test_gpu_refsize.py).  hi + lo = v * log2(e) to ~2^-48 (the product's rounding error by
+// FMA + the low word of the constant); exp2(hi + lo) = exp2(hi) * (1 + lo ln 2).  Measured error 1.2e-7 (v in [-30, 0]).
+// Five more VALU instructions per exponential in walks that wait on memory.  (v below -100: exp2 flushes to 0 either way;
+// the clamp keeps -FLT_MAX - x, the "no edge yet" running maximum, from turning into inf - inf.)
+__device__ __forceinline__ float fexp(float v) {
+  constexpr float kLhi = 1.44269502162933349609375f, kLlo = 1.925963033500e-08f;   // log2(e) = kLhi + kLlo
+  v = fmaxf(v, -100.0f);
+  const float hi = __fmul_rn(v, kLhi);
+  const float lo = __fadd_rn(__builtin_fmaf(v, kLhi, -hi), __fmul_rn(v, kLlo));
+  const float r = __builtin_amdgcn_exp2f(hi);
+  return __builtin_fmaf(r, __fmul_rn(lo, 0.693147180559945309f), r);
+}
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));

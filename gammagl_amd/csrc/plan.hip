@@ -58,6 +58,8 @@ Options &options() {
     t.gat_sh_waves = env_i64("GGL_GAT_SH_WAVES", t.gat_sh_waves);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
+    t.maxbwd_mask_scatter = env_i64("GGL_MAXBWD_MASK_SCATTER", t.maxbwd_mask_scatter);
+    t.maxbwd_mask_wlane = env_i64("GGL_MAXBWD_MASK_WLANE", t.maxbwd_mask_wlane);
     return t;
   }();
   return o;
@@ -301,6 +303,8 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "gat_sh_waves")) o.gat_sh_waves = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
+  else if (!strcmp(name, "maxbwd_mask_scatter")) o.maxbwd_mask_scatter = value;
+  else if (!strcmp(name, "maxbwd_mask_wlane")) o.maxbwd_mask_wlane = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
 }
@@ -326,6 +330,8 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "gat_sh_waves")) return o.gat_sh_waves;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
+  if (!strcmp(name, "maxbwd_mask_scatter")) return o.maxbwd_mask_scatter;
+  if (!strcmp(name, "maxbwd_mask_wlane")) return o.maxbwd_mask_wlane;
   return -1;
 }
 

@@ -83,7 +83,8 @@ struct ReduceDims {
   // is the one the full-width launch draws, so a result assembled block by block carries the same mask
   int64_t epi_K, epi_col0;
   int64_t add_ld;          // row stride of epi_add
-  int64_t mask_words;      // MODE_MAXBWDM: 32-bit words per edge of the winner mask (ceil(K / 32))
+  int64_t mask_words;      // MODE_MAXBWDM: 32-bit words per edge record of the winner mask
+  int64_t mask_col0;       // ... and the first column of this launch inside the full row (column-block launches)
 };
 
 template <typename S> struct RPtrs {
@@ -244,7 +245,9 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
     } else {
       const int64_t c = (int64_t)q.col[p];
       xrow = c;
-      who = MODE == MODE_MAXBWDM ? p : c;      // (the masked max backward looks its bits up by POSITION)
+      // the masked max backward looks its bits up by POSITION: its own, or (mask in forward order) the edge's forward
+      // position posT[p] — handed down in the aux_rowptr slot, which only the mean backward uses otherwise
+      who = MODE == MODE_MAXBWDM ? (q.aux_rowptr ? (int64_t) reinterpret_cast<const int32_t *>(q.aux_rowptr)[p] : p) : c;
       wv = 1.0f;
       if (has_w) {
         const int64_t wi = w_perm ? (int64_t)q.perm[p] : p;
@@ -258,7 +261,8 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
     if (MODE == MODE_MAXBWDM && !RAG) {
       // a lane's VEC (1 or 4) columns start at a multiple of VEC: their bits sit in ONE word of the edge's mask row
       const uint32_t *mk = reinterpret_cast<const uint32_t *>(q.aux_arg) + who * d.mask_words;
-      mbits = mk[kk >> 5] >> (kk & 31);
+      const int64_t kc = d.mask_col0 + kk;          // (column block of a wider row: the bit index is the full row's)
+      mbits = mk[kc >> 5] >> (kc & 31);
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -272,7 +276,8 @@ __device__ __forceinline__ void reduce_range(const RPtrs<typename TT<T>::S> &q, 
       } else if (MODE == MODE_MAXBWDM) {
         if (RAG) {    // (ragged rows: the tail lane's columns may straddle a word)
           const uint32_t *mk = reinterpret_cast<const uint32_t *>(q.aux_arg) + who * d.mask_words;
-          if (i < nv && !((mk[(kk + i) >> 5] >> ((kk + i) & 31)) & 1u)) continue;
+          const int64_t kc = d.mask_col0 + kk + i;
+          if (i < nv && !((mk[kc >> 5] >> (kc & 31)) & 1u)) continue;
         } else if (!((mbits >> i) & 1u)) {
           continue;
         }
@@ -643,7 +648,7 @@ struct ReduceArgs {  // host-side bundle: everything one logical op needs
   // later); 2 = join the hub walk (if `hub_forked`) + long_final only
   int phase;
   int hub_forked;
-  int64_t mask_words;      // MODE_MAXBWDM
+  int64_t mask_words, mask_col0;   // MODE_MAXBWDM
 };
 
 static inline int pow2_ceil_log2(int64_t v) {
@@ -788,6 +793,7 @@ static int launch_typed(const ReduceArgs &a, hipStream_t stream) {
   d.epi_vec = (d.epi_K % 4 == 0) ? 4 : 1;
   d.add_ld = a.add_ld > 0 ? a.add_ld : a.K;
   d.mask_words = a.mask_words;
+  d.mask_col0 = a.mask_col0;
   const int64_t kv = ceil_div(a.K, VEC);
   d.logL = pow2_ceil_log2(kv < kWave ? kv : kWave);
   if (d.logL > 6) d.logL = 6;
@@ -817,7 +823,7 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <int OP, int MODE>
 static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
-  constexpr bool kStatic = (seg_like(MODE) || spmm_like(MODE));
+  constexpr bool kStatic = (seg_like(MODE) || spmm_like(MODE) || MODE == MODE_MAXBWDM);
   const bool vec4 = !options().force_generic && (a.K % 4 == 0) && aligned16(a.x) &&
                     aligned16(a.out) && (!a.partial || aligned16(a.partial)) &&
                     (a.x_ld % 4 == 0) && (a.out_ld % 4 == 0) && (MODE != MODE_BSPMM || a.C % 4 == 0) &&
@@ -867,7 +873,8 @@ extern "C" int64_t ggl_spmm_col_blocks(int64_t E, int64_t K, int64_t N) {
 
 template <int OP, int MODE>
 static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
-  static_assert(OP != OP_MAX && (MODE == MODE_SPMM || MODE == MODE_SPMM_EPI), "column blocks: sum / mean SpMM only");
+  static_assert(OP != OP_MAX && (MODE == MODE_SPMM || MODE == MODE_SPMM_EPI || MODE == MODE_MAXBWDM),
+                "column blocks: sum / mean SpMM and the masked max backward (a sum) only");
   const int64_t bw = col_block_width(a0.E, a0.K, a0.N);
   if (bw <= 0 || a0.N <= 0) return launch_f32<OP, MODE>(a0, stream);
   // The hub rows are walked ONCE per aggregate, over the full width (round 5): one hub launch forked in front of the first
@@ -900,6 +907,7 @@ static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
     }
     a.epi_K = a0.epi_K > 0 ? a0.epi_K : a0.K;
     a.epi_col0 = a0.epi_col0 + c0;
+    a.mask_col0 = a0.mask_col0 + c0;
     const int rc = launch_f32<OP, MODE>(a, stream);
     if (rc) return rc;
   }
@@ -1352,8 +1360,152 @@ __global__ __launch_bounds__(kBlock) void max_mask_kernel(const int64_t *__restr
 #endif
 }
 
-extern "C" size_t ggl_spmm_max_mask_bytes(int64_t E, int64_t K) {
-  return (size_t)(E > 0 ? E : 0) * (size_t)((K + 31) / 32) * sizeof(uint32_t);
+// The same comparison with the mask in FORWARD position order (tpos == NULL; round 5, second form).  Scattering 126 M
+// records of 8-32 bytes to transposed positions cost 6.4-7.8 ms on the products-sized graph whatever their width (every
+// one a partial-line write that ends in DRAM: profiles/r5_probe_hub_and_max_backward.txt) — more than the comparison itself.
+// Here the records of 32 consecutive forward positions are assembled ACROSS the wavefront's lanes — each ballot word is
+// selected into the lane that owns that piece of the 32-record block — and leave as one coalesced store per 32 edges;
+// the transposed walk then reads an edge's record at its forward position posT[p] (a random 8-32 byte READ beside its
+// 256-1024 byte gradient row).  Record = KWp words, KWp = ggl_spmm_max_mask_words(K): ceil(K / 32) rounded up to 1, 2, 4 or
+// a multiple of 8, so that a record is made of whole per-lane pieces.
+// NW = words of a record this pass covers (8: two lanes x 4 words per edge; 4 / 2 / 1: one lane per edge).
+#ifndef GGL_EMULATE
+// lanes `lane` of r0..r3 := the wave-uniform words x0..x3 (v_writelane_b32, lane select in M0 so that the value may sit in
+// any SGPR: before gfx10 the two may not be different SGPRs).  This compiler exposes no writelane builtin; the select form
+// (compare on the lane id + v_cndmask per word + a v_mov per word to get the SGPR into a VGPR) costs 22 VALU instructions
+// per edge at K = 256 where this costs 12.  A/B: option maxbwd_mask_wlane.
+__device__ __forceinline__ void put_lane4(int lane, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t &r0, uint32_t &r1,
+                                          uint32_t &r2, uint32_t &r3) {
+  asm volatile("s_mov_b32 m0, %4\n\ts_nop 1\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
+               "v_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0"
+               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)
+               : "s"(lane), "s"(x0), "s"(x1), "s"(x2), "s"(x3));   // (M0 is reserved: nothing else in this kernel reads it)
+}
+__device__ __forceinline__ void put_lane2(int lane, uint32_t x0, uint32_t x1, uint32_t &r0, uint32_t &r1) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+               : "+v"(r0), "+v"(r1)
+               : "s"(lane), "s"(x0), "s"(x1));
+}
+#endif
+template <int NP, int NW, bool WL = false>
+__global__ __launch_bounds__(kBlock) void max_mask_seq_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                              const int64_t *__restrict__ argsrc,
+                                                              const int32_t *__restrict__ long_rows,
+                                                              const int64_t *__restrict__ chunk_ptr, uint32_t *__restrict__ mask,
+                                                              int64_t N, int64_t K, int64_t KWp, int64_t chunk, int64_t n_long,
+                                                              int64_t n_chunks, int64_t chunk_blocks) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  int64_t row, beg, end;
+  if (block_id() < chunk_blocks) {
+    const int64_t cid = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(block_id() * kWavesPerBlock + wave));
+    if (cid >= n_chunks) return;
+    int64_t lo = 0, hi = n_long - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (chunk_ptr[mid] <= cid) lo = mid; else hi = mid - 1;
+    }
+    row = long_rows[lo];
+    beg = rowptr[row] + (cid - chunk_ptr[lo]) * chunk;
+    const int64_t rend = rowptr[row + 1];
+    end = beg + chunk < rend ? beg + chunk : rend;
+  } else {
+    row = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((block_id() - chunk_blocks) * kWavesPerBlock + wave));
+    if (row >= N) return;
+    beg = rowptr[row];
+    end = rowptr[row + 1];
+    if (end - beg > chunk || end == beg) return;      // long rows: the chunk blocks above
+  }
+#ifdef GGL_EMULATE
+  if (lane != 0) return;
+  for (int64_t p = beg; p < end; ++p) {
+    const int64_t s = col[p];
+    for (int64_t wd = 0; wd < KWp; ++wd) {
+      uint32_t bits = 0;
+      for (int b = 0; b < 32 && wd * 32 + b < K; ++b)
+        if (argsrc[row * K + wd * 32 + b] == s) bits |= 1u << b;
+      mask[p * KWp + wd] = bits;
+    }
+  }
+#else
+  for (int64_t k0 = 0; k0 < K; k0 += (int64_t)kWave * NP) {
+    int32_t a[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int64_t k = k0 + (int64_t)kWave * i + lane;
+      a[i] = k < K ? (int32_t)argsrc[row * K + k] : -1;     // (node ids are >= 0: a padding column never matches)
+    }
+    const int64_t w0 = k0 >> 5;                              // first word of the record this pass fills
+    const int e_lane = NW == 8 ? (lane >> 1) : lane;         // the edge of a 32-edge block whose piece this lane holds
+    for (int64_t pb = beg & ~(int64_t)31; pb < end; pb += 32) {
+      const int64_t lo = pb > beg ? pb : beg, hi = pb + 32 < end ? pb + 32 : end;
+      uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      auto emit = [&](int64_t p, int32_t s) {
+        const int e = (int)(p - pb);
+        uint64_t b[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) b[i] = __ballot(a[i] == s);
+        // the lane (NW = 8: the two lanes) that owns this edge's piece of the block takes the ballot words: a compare on the
+        // lane id + one v_cndmask per word (this compiler has no v_writelane builtin; the select is two instructions more)
+        if (WL && NW == 8) {
+          const uint64_t bA = b[0], bB = b[NP > 1 ? 1 : 0], bC = b[NP > 2 ? 2 : 0], bD = b[NP > 3 ? 3 : 0];
+          put_lane4(2 * e, (uint32_t)bA, (uint32_t)(bA >> 32), (uint32_t)bB, (uint32_t)(bB >> 32), r0, r1, r2, r3);
+          put_lane4(2 * e + 1, (uint32_t)bC, (uint32_t)(bC >> 32), (uint32_t)bD, (uint32_t)(bD >> 32), r0, r1, r2, r3);
+        } else if (WL && NW == 4) {
+          const uint64_t bA = b[0], bB = b[NP > 1 ? 1 : 0];
+          put_lane4(e, (uint32_t)bA, (uint32_t)(bA >> 32), (uint32_t)bB, (uint32_t)(bB >> 32), r0, r1, r2, r3);
+        } else if (WL && NW == 2) {
+          put_lane2(e, (uint32_t)b[0], (uint32_t)(b[0] >> 32), r0, r1);
+        } else if (NW == 8) {
+          const bool m0 = lane == 2 * e, m1 = lane == 2 * e + 1;
+          const uint64_t bA = b[0], bB = b[NP > 1 ? 1 : 0], bC = b[NP > 2 ? 2 : 0], bD = b[NP > 3 ? 3 : 0];
+          r0 = m0 ? (uint32_t)bA : m1 ? (uint32_t)bC : r0;
+          r1 = m0 ? (uint32_t)(bA >> 32) : m1 ? (uint32_t)(bC >> 32) : r1;
+          r2 = m0 ? (uint32_t)bB : m1 ? (uint32_t)bD : r2;
+          r3 = m0 ? (uint32_t)(bB >> 32) : m1 ? (uint32_t)(bD >> 32) : r3;
+        } else {
+          const bool m0 = lane == e;
+          r0 = m0 ? (uint32_t)b[0] : r0;
+          if (NW >= 2) r1 = m0 ? (uint32_t)(b[0] >> 32) : r1;
+          if (NW >= 4) {
+            r2 = m0 ? (uint32_t)b[NP > 1 ? 1 : 0] : r2;
+            r3 = m0 ? (uint32_t)(b[NP > 1 ? 1 : 0] >> 32) : r3;
+          }
+        }
+      };
+      int64_t p = lo;
+      for (; p + 4 <= hi; p += 4) {      // (unrolled by hand: ballots are convergent operations, `#pragma unroll` declines)
+        int32_t s4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] = col[p + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) emit(p + u, s4[u]);
+      }
+      for (; p < hi; ++p) emit(p, col[p]);
+      // one store per lane and 32-edge block: the lanes whose edge lies in [lo, hi) — a block shared with the neighbouring
+      // row (or chunk) is completed by that row's wavefront, each lane's piece belongs to exactly one edge
+      const int64_t pe = pb + e_lane;
+      if (pe >= lo && pe < hi && (NW == 8 || lane < 32)) {
+        uint32_t *dst = mask + pe * KWp + w0 + (NW == 8 ? 4 * (lane & 1) : 0);
+        if (NW >= 4) *reinterpret_cast<uint4 *>(dst) = uint4{r0, r1, r2, r3};
+        else if (NW == 2) *reinterpret_cast<uint2 *>(dst) = uint2{r0, r1};
+        else *dst = r0;
+      }
+    }
+  }
+#endif
+}
+
+// words per edge record: transposed-order mask (scatter form) ceil(K / 32); forward-order mask ggl_spmm_max_mask_words(K)
+static int64_t mask_words_seq(int64_t K) {
+  const int64_t kw = (K + 31) / 32;
+  return kw <= 1 ? 1 : kw <= 2 ? 2 : kw <= 4 ? 4 : ((kw + 7) / 8) * 8;
+}
+extern "C" int64_t ggl_spmm_max_mask_words(int64_t K, int forward_order) {
+  return forward_order ? mask_words_seq(K) : (K + 31) / 32;
+}
+extern "C" size_t ggl_spmm_max_mask_bytes(int64_t E, int64_t K) {     // (room for either form)
+  return (size_t)(E > 0 ? E : 0) * (size_t)mask_words_seq(K) * sizeof(uint32_t);
 }
 
 extern "C" int ggl_spmm_max_mask(const ggl_segplan_t *planF, const int32_t *colF, const int32_t *tpos,
@@ -1361,13 +1513,37 @@ extern "C" int ggl_spmm_max_mask(const ggl_segplan_t *planF, const int32_t *colF
   GGL_REQUIRE(planF != nullptr && planF->rowptr != nullptr, GGL_EINVAL, "plan is NULL");
   const int64_t E = planF->E, N = planF->N;
   if (E <= 0 || K <= 0 || N <= 0) return GGL_OK;
-  GGL_REQUIRE(colF && tpos && argsrc && mask, GGL_EINVAL, "ggl_spmm_max_mask: NULL argument");
+  GGL_REQUIRE(colF && argsrc && mask, GGL_EINVAL, "ggl_spmm_max_mask: NULL argument");
   GGL_REQUIRE(N < ((int64_t)1 << 31), GGL_EINVAL, "too many rows");
   GGL_REQUIRE(planF->n_long == 0 || (planF->long_rows && planF->chunk_ptr), GGL_EINVAL, "plan has long rows but no chunk list");
-  const int64_t KW = (K + 31) / 32;
   const int64_t chunk_blocks = planF->n_long > 0 ? ceil_div(planF->n_chunks, (int64_t)kWavesPerBlock) : 0;
   const int64_t grid = chunk_blocks + ceil_div(N, (int64_t)kWavesPerBlock);
   hipStream_t st = as_stream(stream);
+  if (tpos == nullptr) {      // forward-order records, assembled across lanes, one coalesced store per 32 edges
+    const int64_t KWp = mask_words_seq(K);
+    GGL_REQUIRE((reinterpret_cast<uintptr_t>(mask) & 15u) == 0, GGL_EINVAL, "mask must be 16-byte aligned");
+#ifdef GGL_EMULATE
+    constexpr bool kCanWl = false;
+#else
+    constexpr bool kCanWl = true;
+#endif
+    const bool wl = kCanWl && options().maxbwd_mask_wlane != 0;
+#define GGL_MS(NP, NW)                                                                                              \
+  do {                                                                                                              \
+    if (wl) GGL_LAUNCH((max_mask_seq_kernel<NP, NW, kCanWl>), grid, kBlock, st, planF->rowptr, colF, argsrc, planF->long_rows, \
+                       planF->chunk_ptr, mask, N, K, KWp, planF->chunk, planF->n_long, planF->n_chunks, chunk_blocks);       \
+    else GGL_LAUNCH((max_mask_seq_kernel<NP, NW, false>), grid, kBlock, st, planF->rowptr, colF, argsrc, planF->long_rows,  \
+                    planF->chunk_ptr, mask, N, K, KWp, planF->chunk, planF->n_long, planF->n_chunks, chunk_blocks);          \
+  } while (0)
+    if (K <= 32) GGL_MS(1, 1);
+    else if (K <= 64) GGL_MS(1, 2);
+    else if (K <= 128) GGL_MS(2, 4);
+    else GGL_MS(4, 8);
+#undef GGL_MS
+    GGL_LAUNCH_CHECK();
+    return GGL_OK;
+  }
+  const int64_t KW = (K + 31) / 32;
 #define GGL_MM(NP)                                                                                                  \
   GGL_LAUNCH((max_mask_kernel<NP>), grid, kBlock, st, planF->rowptr, colF, tpos, argsrc, planF->long_rows,         \
              planF->chunk_ptr, mask, N, K, KW, planF->chunk, planF->n_long, planF->n_chunks, chunk_blocks)
@@ -1380,14 +1556,17 @@ extern "C" int ggl_spmm_max_mask(const ggl_segplan_t *planF, const int32_t *colF
 }
 
 extern "C" int ggl_spmm_max_bwd_mask(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
-                                     const float *g, const uint32_t *mask, int64_t K, float *gx, void *stream) {
+                                     const float *g, const uint32_t *mask, const int32_t *mask_pos, int64_t K, float *gx,
+                                     void *stream) {
   ReduceArgs a{};
   int rc = spmm_common(a, planT, colT, w, w_by_pos, g, K, gx, false);
   if (rc) return rc;
   GGL_REQUIRE(mask || planT->E * K == 0, GGL_EINVAL, "mask is NULL");
   a.aux_arg = reinterpret_cast<const int64_t *>(mask);
-  a.mask_words = (K + 31) / 32;
-  return launch_f32<OP_SUM, MODE_MAXBWDM>(a, as_stream(stream));
+  // mask_pos = posT (the forward position of every transposed position): records in forward order; NULL: in transposed order
+  a.aux_rowptr = reinterpret_cast<const int64_t *>(mask_pos);
+  a.mask_words = mask_pos ? mask_words_seq(K) : (K + 31) / 32;
+  return launch_f32_cols<OP_SUM, MODE_MAXBWDM>(a, as_stream(stream));
 }
 
 // ---- bspmm ---------------------------------------------------------------------------------------

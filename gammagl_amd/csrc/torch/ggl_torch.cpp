@@ -566,13 +566,15 @@ static std::pair<Tensor, Tensor> spmm_fwd(SpOp op, GraphPlan &gp, const SegPlan 
     case SpOp::MaxBwd: {
       const int64_t mk = a.ggl_get_option("maxbwd_mask");
       if (tpos.defined() && mk > 0 && K >= mk) {
-        // a 1-bit winner mask built in destination order, read in the transposed walk's own order (ops.py _spmm_fwd)
+        // a 1-bit winner mask built in destination order; records in forward order, read at posT[t] (ops.py _spmm_fwd) —
+        // `tpos` here IS posT unless the A/B knob maxbwd_mask_scatter asks for records scattered to transposed positions
+        const bool scatter = a.ggl_get_option("maxbwd_mask_scatter") != 0;
         Tensor mask = at::empty({static_cast<int64_t>(a.ggl_spmm_max_mask_bytes(p.E, K) / 4) + 4}, x.options().dtype(at::kInt));
         ggl_segplan_t fs = gp.fwd->c(Tensor());
-        check(a, a.ggl_spmm_max_mask(&fs, gp.col.data_ptr<int32_t>(), tpos.data_ptr<int32_t>(), aux.data_ptr<int64_t>(), K,
-                                     reinterpret_cast<uint32_t *>(mask.data_ptr<int32_t>()), st));
+        check(a, a.ggl_spmm_max_mask(&fs, gp.col.data_ptr<int32_t>(), scatter ? tpos.data_ptr<int32_t>() : nullptr,
+                                     aux.data_ptr<int64_t>(), K, reinterpret_cast<uint32_t *>(mask.data_ptr<int32_t>()), st));
         check(a, a.ggl_spmm_max_bwd_mask(&cs, c, wp, by_pos, xp, reinterpret_cast<const uint32_t *>(mask.data_ptr<int32_t>()),
-                                         K, op_, st));
+                                         scatter ? nullptr : tpos.data_ptr<int32_t>(), K, op_, st));
       } else if (a.ggl_get_option("maxbwd_arg32") != 0) {   // witnesses from a compact int32 copy (one [N, K] pass)
         Tensor aux32 = aux.to(at::kInt);
         check(a, a.ggl_spmm_max_bwd32(&cs, c, wp, by_pos, xp, aux32.data_ptr<int32_t>(), K, op_, st));
@@ -765,8 +767,13 @@ static Tensor spmm_max_backward_kernel(const Tensor &index, const c10::optional<
   auto gp = bwd_plan(index, g.size(0));
   Tensor tpos;
   if (api_for(g.device()).ggl_get_option("maxbwd_mask") > 0) {
-    gp->need_tpos(index.contiguous());
-    tpos = gp->tpos;
+    if (api_for(g.device()).ggl_get_option("maxbwd_mask_scatter") != 0) {
+      gp->need_tpos(index.contiguous());
+      tpos = gp->tpos;
+    } else {
+      gp->need_posT(index.contiguous());
+      tpos = gp->posT;
+    }
   }
   return spmm_fwd(SpOp::MaxBwd, *gp, *gp->bwd, gp->colT, w, g, gp->N_src, arg.contiguous(), tpos).first;
 }

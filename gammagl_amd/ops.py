@@ -725,9 +725,13 @@ class Engine:
                 # transposed walk's own order: K / 8 bytes per edge instead of 8K (include/ggl_mpops.h)
                 mask = torch.empty(int(L.ggl_spmm_max_mask_bytes(plan.E, K)) // 4 + 4, dtype=torch.int32, device=dev)
                 fs = gp.fwd.c_struct(None)
-                self._check(L.ggl_spmm_max_mask(ctypes.byref(fs), _ptr(gp.col), _ptr(gp.tpos), _ptr(aux), K, _ptr(mask), st))
-                self._check(L.ggl_spmm_max_bwd_mask(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
-                                                    _ptr(mask), K, _ptr(out), st))
+                # records in forward order (coalesced writes; the walk reads record posT[t]) unless the A/B knob asks for
+                # the scatter to transposed positions (maxbwd_mask_scatter: streamed reads, slower writes)
+                scatter = int(L.ggl_get_option(b"maxbwd_mask_scatter")) != 0
+                self._check(L.ggl_spmm_max_mask(ctypes.byref(fs), _ptr(gp.col), _ptr(gp.tpos) if scatter else None, _ptr(aux), K,
+                                                _ptr(mask), st))
+                self._check(L.ggl_spmm_max_bwd_mask(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), _ptr(mask),
+                                                    None if scatter else _ptr(gp.posT), K, _ptr(out), st))
             elif int(L.ggl_get_option(b"maxbwd_arg32")):   # A/B knob: witnesses from a compact int32 copy (one [N, K] pass)
                 aux32 = aux.to(torch.int32)
                 self._check(L.ggl_spmm_max_bwd32(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),

@@ -250,16 +250,23 @@ int ggl_spmm_max_bwd(const ggl_segplan_t *planT, const int32_t *colT, const floa
 int ggl_spmm_max_bwd32(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
                        const float *g, const int32_t *argsrc32, int64_t K, float *gx, void *stream);
 /* The max backward through a WINNER MASK (round 5; same sums in the same order as ggl_spmm_max_bwd, spmm_max_cpu.cpp:88-93):
- *   ggl_spmm_max_mask  walks the FORWARD plan (rows = destinations, where argsrc's row is wave-uniform) and writes, for the
- *     edge at forward position p, bit k = [argsrc[dst, k] == colF[p]] into mask word tpos[p] * ceil(K/32) + k/32, bit k%32;
- *     tpos[p] = the edge's position in the TRANSPOSED plan (ggl_invert_perm of the hosts' posT), once per graph;
- *   ggl_spmm_max_bwd_mask  is the transposed walk reading K/8 mask bytes per edge instead of 8K witness bytes.
- * mask: ggl_spmm_max_mask_bytes(E, K) bytes, fully overwritten by ggl_spmm_max_mask. */
+ *   ggl_spmm_max_mask  walks the FORWARD plan (rows = destinations, where argsrc's row is wave-uniform) and writes one
+ *     record per edge, bit k = [argsrc[dst, k] == colF[p]] for the edge at forward position p:
+ *       tpos == NULL (the hosts' default): records in FORWARD position order, ggl_spmm_max_mask_words(K, 1) words each
+ *         (ceil(K/32) rounded up to 1, 2, 4 or a multiple of 8), written as coalesced 32-record blocks; the backward
+ *         reads record posT[t] for transposed position t (pass mask_pos = posT, the hosts' GraphPlan.posT);
+ *       tpos != NULL: records SCATTERED to transposed position tpos[p] (ggl_invert_perm of posT), ceil(K/32) words
+ *         each; the backward streams them in its own order (mask_pos = NULL).  Measured slower (the scatter), kept as A/B.
+ *     bit k of a record: word k/32, bit k%32.  mask: ggl_spmm_max_mask_bytes(E, K) bytes (room for either form), 16-byte
+ *     aligned, every record fully overwritten;
+ *   ggl_spmm_max_bwd_mask  is the transposed walk reading K/8 mask bytes per edge instead of 8K witness bytes. */
+int64_t ggl_spmm_max_mask_words(int64_t K, int forward_order);
 size_t ggl_spmm_max_mask_bytes(int64_t E, int64_t K);
 int ggl_spmm_max_mask(const ggl_segplan_t *planF, const int32_t *colF, const int32_t *tpos, const int64_t *argsrc,
                       int64_t K, uint32_t *mask, void *stream);
 int ggl_spmm_max_bwd_mask(const ggl_segplan_t *planT, const int32_t *colT, const float *w, int w_by_pos,
-                          const float *g, const uint32_t *mask, int64_t K, float *gx, void *stream);
+                          const float *g, const uint32_t *mask, const int32_t *mask_pos, int64_t K, float *gx,
+                          void *stream);
 /* inv[perm[i]] = i for a permutation of [0, n), n < 2^31 */
 int ggl_invert_perm(const int32_t *perm, int64_t n, int32_t *inv, void *stream);
 

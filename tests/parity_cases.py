@@ -1993,7 +1993,7 @@ def check_max_backward_forms(eng, dev, oracle, chunk=64):
     try:
         rng = np.random.default_rng(11)
         N, E = 60, 3000
-        for K in (1, 4, 7, 32, 33, 47, 64, 100, 128, 130, 256, 300):
+        for K in (1, 4, 7, 32, 33, 47, 64, 100, 128, 130, 160, 256, 300, 512, 600):
             index = np.stack([rng.integers(0, N - 4, size=E), rng.integers(0, N - 4, size=E)]).astype(np.int64)
             index[0, :900] = 2                                          # hub source
             index[1, 1200:2100] = 7                                     # hub destination
@@ -2014,8 +2014,10 @@ def check_max_backward_forms(eng, dev, oracle, chunk=64):
                 one_piece = to_np(gp.bwd.counts() <= gp.bwd.chunk)          # (chunked transposed rows: within rounding)
                 for name, opts in (("int64 witnesses", {"maxbwd_mask": 0, "maxbwd_arg32": 0}),
                                    ("int32 witnesses", {"maxbwd_mask": 0, "maxbwd_arg32": 1}),
-                                   ("winner mask", {"maxbwd_mask": 1, "maxbwd_arg32": 0})):
-                    with option(eng, "maxbwd_mask", opts["maxbwd_mask"]), option(eng, "maxbwd_arg32", opts["maxbwd_arg32"]):
+                                   ("winner mask, forward order", {"maxbwd_mask": 1, "maxbwd_arg32": 0}),
+                                   ("winner mask, scattered", {"maxbwd_mask": 1, "maxbwd_arg32": 0, "maxbwd_mask_scatter": 1})):
+                    with option(eng, "maxbwd_mask", opts["maxbwd_mask"]), option(eng, "maxbwd_arg32", opts["maxbwd_arg32"]), \
+                            option(eng, "maxbwd_mask_scatter", opts.get("maxbwd_mask_scatter", 0)):
                         for call in range(2):       # (second call: weights streamed from their sorted copy)
                             xt = to_t(xs, dev).requires_grad_(True)
                             eng.c_spmm_max(it, wt, xt).backward(to_t(go, dev))

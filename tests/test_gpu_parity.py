@@ -1006,6 +1006,8 @@ def test_max_backward_forms(eng, dev, oracle):
     pc.check_max_backward_forms(eng, dev, oracle)
     with pc.option(eng, "max_grid_x", 3):
         pc.check_max_backward_forms(eng, dev, oracle)
+    with pc.option(eng, "maxbwd_mask_wlane", 1):        # the forward-order records assembled with v_writelane (inline asm)
+        pc.check_max_backward_forms(eng, dev, oracle)
 
 
 def test_sage_replica_step_as_two_graphs_around_the_allreduce(eng, dev):

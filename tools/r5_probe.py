@@ -39,7 +39,7 @@ for relabel in (("random", "degree") if "hub" in what else ("random",)):
                 print(f"[{relabel}] spmm sum K={K}: {ev(lambda: eng.c_spmm_sum(ei, w, xk)):7.3f} ms", flush=True)
         del x
     if "max" in what and relabel == "random":
-        for K in (64, 256):
+        for K in (64, 128, 256):
             xk = torch.randn(n, K, device=dev, requires_grad=True)
             go = torch.randn(n, K, device=dev)
             def fb():
@@ -48,12 +48,17 @@ for relabel in (("random", "degree") if "hub" in what else ("random",)):
             with torch.no_grad():
                 f = ev(lambda: eng.c_spmm_max(ei, w, xk))
             line = f"gspmm max K={K:3d}: fwd {f:7.3f}"
-            for name, m, a32 in (("int64 witnesses", 0, 0), ("int32 witnesses", 0, 1), ("winner mask", 1, 0)):
-                eng.set_option("maxbwd_mask", m); eng.set_option("maxbwd_arg32", a32)
+            forms = (("int64 witnesses", dict(maxbwd_mask=0, maxbwd_arg32=0)), ("int32 witnesses", dict(maxbwd_mask=0, maxbwd_arg32=1)),
+                     ("mask fwd-order (select)", dict(maxbwd_mask=1)), ("mask fwd-order (writelane)", dict(maxbwd_mask=1, maxbwd_mask_wlane=1)),
+                     ("mask scattered", dict(maxbwd_mask=1, maxbwd_mask_scatter=1)))
+            for name, opts in forms:
+                for k in ("maxbwd_mask", "maxbwd_arg32", "maxbwd_mask_wlane", "maxbwd_mask_scatter"):
+                    eng.set_option(k, opts.get(k, 0))
                 line += f" | fwd+bwd {name} {ev(fb):7.3f}"
-            eng.set_option("maxbwd_mask", 32); eng.set_option("maxbwd_arg32", 0)
+            eng.set_option("maxbwd_mask", 128); eng.set_option("maxbwd_arg32", 1)
+            eng.set_option("maxbwd_mask_wlane", 0); eng.set_option("maxbwd_mask_scatter", 0)
             print(line, flush=True)
-            # the mask pre-pass alone
+            # the mask pre-pass alone, each form
             with torch.no_grad():
                 _, arg = eng._spmm_fwd("max", gp.fwd, gp.col, w, xk.detach(), n)
                 L = eng.lib
@@ -61,9 +66,13 @@ for relabel in (("random", "degree") if "hub" in what else ("random",)):
                 fs = gp.fwd.c_struct(None)
                 tp = gp.tpos
                 st = eng._stream(dev)
-                t = ev(lambda: eng._check(L.ggl_spmm_max_mask(ctypes.byref(fs), ctypes.c_void_p(gp.col.data_ptr()), ctypes.c_void_p(tp.data_ptr()),
-                                                              ctypes.c_void_p(arg.data_ptr()), K, ctypes.c_void_p(mask.data_ptr()), st)))
-                print(f"   mask pre-pass K={K}: {t:7.3f} ms ({mask.numel() * 4 / 1e9:.2f} GB of mask)", flush=True)
+                for name, tpp, wl in (("fwd-order select", None, 0), ("fwd-order writelane", None, 1), ("scattered", tp, 0)):
+                    eng.set_option("maxbwd_mask_wlane", wl)
+                    t = ev(lambda: eng._check(L.ggl_spmm_max_mask(ctypes.byref(fs), ctypes.c_void_p(gp.col.data_ptr()),
+                                                                  ctypes.c_void_p(tpp.data_ptr()) if tpp is not None else None,
+                                                                  ctypes.c_void_p(arg.data_ptr()), K, ctypes.c_void_p(mask.data_ptr()), st)))
+                    print(f"   mask pre-pass K={K} {name}: {t:7.3f} ms", flush=True)
+                eng.set_option("maxbwd_mask_wlane", 0)
             del xk, go, arg, mask
     eng.clear_caches(); del gp, ei, w
     torch.cuda.empty_cache()
