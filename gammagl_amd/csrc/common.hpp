@@ -104,6 +104,7 @@ struct Options {
   int64_t maxbwd_arg32 = 1;       // witnesses from a compact int32 copy ...
   int64_t maxbwd_mask = 128;      // ... and from this many columns up a 1-bit winner mask instead (0 = never)
   int64_t maxbwd_mask_wlane = 0;   // ... its forward-order records assembled with v_writelane (inline asm) instead of selects (A/B)
+  int64_t maxbwd_mask_cols = 0;    // ... its walk in 64-column blocks like the plain sum's (A/B: loses, the record is re-read per block)
   int64_t maxbwd_mask_scatter = 0; // ... its records scattered to transposed positions instead of kept in forward order (A/B)
   int64_t exact_long_max = (int64_t)1 << 21;   // ... unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)

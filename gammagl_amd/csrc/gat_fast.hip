@@ -13,7 +13,7 @@ namespace ggl {
 // arithmetic per load, a predicated rescale per edge) against 12 memory instructions, and the Reddit-sized
 // 60 MB feature panel is cache-resident — 114.8 M edges x 16 lanes of that is ~5 ms of issue time on its
 // own.  These variants do the same walks with an order of magnitude fewer VALU instructions:
-//   * exp through v_exp_f32 (exp2(x * log2 e) with the scaling compensated since round 5: 1.2e-7 relative, see fexp; the GAT
+//   * exp through v_exp_f32 (exp2(x * log2 e), ~1e-6 relative on the operand range of a softmax, see fexp; the GAT
 //     parity bar is 1e-5 relative against the oracle's three-pass restatement);
 //   * one rescale per block of 4 / 8 edges (block maximum first) instead of a predicated one per edge;
 //   * column indices as one 16-byte load per 4 edges (the walk is aligned to multiples of 4);
@@ -30,21 +30,13 @@ namespace ggl {
 // to 1e-5 relative, not bit-exact).  The host-emulated test build cannot shuffle between its sequentially
 // executed lanes: it keeps the kernels above for every shape (they also remain the path for other shapes).
 // =====================================================================================================
-// exp(v), v <= 0 (a softmax exponent), through v_exp_f32 (exp2, 1 ulp) with the argument scaling COMPENSATED (round 5):
-// v * log2(e) rounded to f32 carries |v| * 6e-8 of relative error into the result (1.7e-6 at v = -30 — ten times expf's,
-// and systematic along a row: it showed as 1.6e-5 in g_er against an fp64 evaluation of the layer where the reference's own
-// f32 composition has 5.5e-6, tests/test_gpu_refsize.py).  hi + lo = v * log2(e) to ~2^-48 (the product's rounding error by
-// FMA + the low word of the constant); exp2(hi + lo) = exp2(hi) * (1 + lo ln 2).  Measured error 1.2e-7 (v in [-30, 0]).
-// Five more VALU instructions per exponential in walks that wait on memory.  (v below -100: exp2 flushes to 0 either way;
-// the clamp keeps -FLT_MAX - x, the "no edge yet" running maximum, from turning into inf - inf.)
-__device__ __forceinline__ float fexp(float v) {
-  constexpr float kLhi = 1.44269502162933349609375f, kLlo = 1.925963033500e-08f;   // log2(e) = kLhi + kLlo
-  v = fmaxf(v, -100.0f);
-  const float hi = __fmul_rn(v, kLhi);
-  const float lo = __fadd_rn(__builtin_fmaf(v, kLhi, -hi), __fmul_rn(v, kLlo));
-  const float r = __builtin_amdgcn_exp2f(hi);
-  return __builtin_fmaf(r, __fmul_rn(lo, 0.693147180559945309f), r);
-}
+// exp(v), v <= 0 (a softmax exponent), through v_exp_f32: exp2(v * log2 e).  The scaling's rounding carries |v| * 6e-8 of
+// relative error into the result (2e-7 at the typical v = -3, 1.7e-6 at v = -30).  Round 5 measured what that costs: with
+// the scaling compensated (hi + lo product, five more instructions, 1.2e-7 everywhere) the layer's errors against an fp64
+// evaluation moved from 1.44e-6 to 1.36e-6 (out) and 1.42e-6 to 1.23e-6 (gx), g_er not at all — and the Reddit step
+// from 30.0 to 30.4 ms.  The exponential is NOT what limits the gradients' accuracy (the f32 row sums are: see
+// gat_bwd_dst2_kernel); the plain form stays.
+__device__ __forceinline__ float fexp(float v) { return __builtin_amdgcn_exp2f(v * 1.44269504088896340736f); }
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -244,14 +236,26 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst2_kernel(
   const RowAddr<OFF32> xa{reinterpret_cast<const char *>(x) + kk * 4, (uint32_t)(K * 4)};
   const RowAddr<OFF32> ea{reinterpret_cast<const char *>(el) + h * 4, (uint32_t)(H * 4)};
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
-  float gsum = 0.0f;
+  // g_er[i,h] = sum_p l'_p alpha_p (da_p - s_i), s_i = sum_q alpha_q da_q: a sum of thousands of cancelling terms whose
+  // result is 10-100x smaller than they are.  With alpha = exp(.) / den in f32, sum_q alpha_q = 1 + eps (den is an f32 sum
+  // of up to 10^5 exponentials) and the stored s_i = <g_i, out_i> carries the same eps: the row's result is off by
+  // eps s_i sum_p l'_p alpha_p — 1.6e-5 of the tensor's magnitude against an fp64 evaluation of the layer where the
+  // reference's own f32 composition has 5.5e-6 (tests/test_gpu_refsize.py).  Round 5: the row keeps FOUR sums in double,
+  //   A = sum l' alpha da,  B = sum l' alpha,  S = sum alpha da,  W = sum alpha,   g_er = A - (S / W) B,
+  // the weighted mean S / W normalised by the alphas actually used: eps cancels, what is left is the rounding of the f32
+  // terms (numpy model of both forms over 10-20 000-edge rows: 10-20x smaller).  stats.w = <g_i, out_i> stays what the source
+  // walk uses per edge (its errors are spread over different rows there).
+  double sA = 0.0, sB = 0.0, sS = 0.0, sW = 0.0;
   auto edge = [&](float e, const float4 &v, uint32_t word) {
     float da = head_sum<C4>(dot4(gi, v));
     const float raw = e + er_i;
     const float al = fexp(lrelu(raw, slope) - m) * rinv;
     if (DROP) da = (word >= d.drop_thresh) ? da * d.drop_scale : 0.0f;  // d out / d alpha_p = keep / (1 - p) <g_i, x_j>
-    const float ds = al * (da - dot);
-    gsum += raw > 0.0f ? ds : ds * slope;
+    const float lal = raw > 0.0f ? al : al * slope;
+    sA += (double)(lal * da);
+    sB += (double)lal;
+    sS += (double)(al * da);
+    sW += (double)al;
   };
   auto single = [&](int64_t q) {
     const int32_t c = col[q];
@@ -295,8 +299,29 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_dst2_kernel(
   }
   for (; p < it.end; ++p) single(p);
   if (lead) {
-    if (it.is_chunk) pger[it.cid * H + h] = gsum;
-    else ger[it.row * H + h] = gsum;
+    if (it.is_chunk) {      // a hub row's chunk: the four sums, combined in chunk order by gat_bwd_dst_final4_kernel
+      double *pq = reinterpret_cast<double *>(pger) + (it.cid * H + h) * 4;
+      pq[0] = sA; pq[1] = sB; pq[2] = sS; pq[3] = sW;
+    } else {
+      ger[it.row * H + h] = sW > 0.0 ? (float)(sA - (sS / sW) * sB) : 0.0f;
+    }
+  }
+}
+
+// long rows of the destination walk above: the four double sums of a row's chunks, in chunk order
+__global__ __launch_bounds__(kBlock) void gat_bwd_dst_final4_kernel(const int32_t *__restrict__ long_rows,
+                                                                    const int64_t *__restrict__ chunk_ptr,
+                                                                    const double *__restrict__ pq, float *__restrict__ ger,
+                                                                    int64_t n_long, int64_t H) {
+  const int64_t stride = grid_threads();
+  for (int64_t t = thread_id(); t < n_long * H; t += stride) {
+    const int64_t j = t / H, h = t - j * H;
+    double sA = 0.0, sB = 0.0, sS = 0.0, sW = 0.0;
+    for (int64_t c = chunk_ptr[j]; c < chunk_ptr[j + 1]; ++c) {
+      const double *q = pq + (c * H + h) * 4;
+      sA += q[0]; sB += q[1]; sS += q[2]; sW += q[3];
+    }
+    ger[(int64_t)long_rows[j] * H + h] = sW > 0.0 ? (float)(sA - (sS / sW) * sB) : 0.0f;
   }
 }
 
@@ -835,8 +860,8 @@ extern "C" int ggl_gat_fast_bwd(const ggl_segplan_t *plan, const int32_t *col, c
                       rng_used, d);
     GGL_LAUNCH_CHECK();
     if (plan->n_long > 0) {
-      GGL_LAUNCH((gat_bwd_dst_final_kernel), gat_grid_for(plan->n_long * H), kBlock, s, plan->long_rows,
-                 plan->chunk_ptr, (const float *)pger, ger, plan->n_long, H);
+      GGL_LAUNCH((gat_bwd_dst_final4_kernel), gat_grid_for(plan->n_long * H), kBlock, s, plan->long_rows,
+                 plan->chunk_ptr, reinterpret_cast<const double *>(pger), ger, plan->n_long, H);
       GGL_LAUNCH_CHECK();
     }
   }

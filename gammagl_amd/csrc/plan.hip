@@ -60,6 +60,7 @@ Options &options() {
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
     t.maxbwd_mask_scatter = env_i64("GGL_MAXBWD_MASK_SCATTER", t.maxbwd_mask_scatter);
     t.maxbwd_mask_wlane = env_i64("GGL_MAXBWD_MASK_WLANE", t.maxbwd_mask_wlane);
+    t.maxbwd_mask_cols = env_i64("GGL_MAXBWD_MASK_COLS", t.maxbwd_mask_cols);
     return t;
   }();
   return o;
@@ -305,6 +306,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
   else if (!strcmp(name, "maxbwd_mask_scatter")) o.maxbwd_mask_scatter = value;
   else if (!strcmp(name, "maxbwd_mask_wlane")) o.maxbwd_mask_wlane = value;
+  else if (!strcmp(name, "maxbwd_mask_cols")) o.maxbwd_mask_cols = value;
   else { set_error("unknown option %s", name); return GGL_EINVAL; }
   return GGL_OK;
 }
@@ -332,6 +334,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
   if (!strcmp(name, "maxbwd_mask_scatter")) return o.maxbwd_mask_scatter;
   if (!strcmp(name, "maxbwd_mask_wlane")) return o.maxbwd_mask_wlane;
+  if (!strcmp(name, "maxbwd_mask_cols")) return o.maxbwd_mask_cols;
   return -1;
 }
 

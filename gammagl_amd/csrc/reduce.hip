@@ -1566,7 +1566,12 @@ extern "C" int ggl_spmm_max_bwd_mask(const ggl_segplan_t *planT, const int32_t *
   // mask_pos = posT (the forward position of every transposed position): records in forward order; NULL: in transposed order
   a.aux_rowptr = reinterpret_cast<const int64_t *>(mask_pos);
   a.mask_words = mask_pos ? mask_words_seq(K) : (K + 31) / 32;
-  return launch_f32_cols<OP_SUM, MODE_MAXBWDM>(a, as_stream(stream));
+  // ONE launch over the full width: the 64-column blocks that pay for the plain sum re-read every edge's mask record (and
+  // posT entry) once per block — measured on the products-sized graph at K = 256: the scattered-record walk 16.5 ms in one
+  // launch, 21.5 in four; with forward-order records (a random 32-byte read per edge and block) 32 ms
+  // (profiles/r5_max_backward.txt).  GGL_MAXBWD_MASK_COLS=1 takes the blocks (A/B).
+  if (options().maxbwd_mask_cols != 0) return launch_f32_cols<OP_SUM, MODE_MAXBWDM>(a, as_stream(stream));
+  return launch_f32<OP_SUM, MODE_MAXBWDM>(a, as_stream(stream));
 }
 
 // ---- bspmm ---------------------------------------------------------------------------------------

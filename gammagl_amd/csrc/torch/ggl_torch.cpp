@@ -891,7 +891,8 @@ static std::tuple<Tensor, Tensor, Tensor> gat_backward(GraphPlan &gp, const Tens
   void *st = stream_of(dev);
   const SegPlan &fw = *gp.fwd, &bw = *gp.bwd;
   Tensor ger = at::empty_like(er), gx = at::empty({gp.N_src, H, C}, x.options()), gel = at::empty({gp.N_src, H}, x.options());
-  Tensor part_f = partial_for(a, fw, x, H, false), part_t = partial_for(a, bw, x, H * C + H, false);
+  // (the fast destination walk keeps four DOUBLE sums per chunk and head: 8 H floats' worth per chunk, include/ggl_mpops.h)
+  Tensor part_f = partial_for(a, fw, x, fast ? 8 * H : H, false), part_t = partial_for(a, bw, x, H * C + H, false);
   ggl_segplan_t cs = fw.c(part_f), csT = bw.c(part_t);
   const int64_t *ru = (p > 0 && rng_used.numel() == 2) ? rng_used.data_ptr<int64_t>() : nullptr;
   if (fast) {

@@ -986,7 +986,7 @@ class Engine:
                     ger = torch.empty_like(er)
                     gx = torch.empty((gp.N_src, H, C), dtype=torch.float32, device=dev)
                     gel = torch.empty((gp.N_src, H), dtype=torch.float32, device=dev)
-                    part_f = eng._partial(gp.fwd, torch.float32, H, False, dev)
+                    part_f = eng._partial(gp.fwd, torch.float32, 8 * H, False, dev)   # four double sums per chunk and head
                     part_t = eng._partial(bwd, torch.float32, H * C + H, False, dev)
                     cs, csT = gp.fwd.c_struct(part_f), bwd.c_struct(part_t)
                     posT = gp.posT if ctx.p_drop > 0 else None

@@ -395,7 +395,9 @@ int ggl_gat_fused_bwd_src(const ggl_segplan_t *planT, const int32_t *colT, const
  *   ggl_gat_fast_fwd : as ggl_gat_fused_fwd; N_src = rows of x (selects 32-bit offsets when the panel is < 4 GiB)
  *   ggl_gat_fast_bwd : destination walk (stats[N,H,4] = {er, m, 1/(den + 1e-16), <g_i, out_i>}, ger) then
  *                      source walk (gx, gel).  stats: workspace of N * H * 4 floats; plan->partial >=
- *                      n_chunks * H floats; planT->partial = ggl_partial_bytes(GGL_F32, n_chunksT, H*C + H, 0);
+ *                      n_chunks * H * 4 DOUBLES, 8-byte aligned (ABI 8: the destination walk keeps four double sums per
+ *                      row and head, see gat_fast.hip; = ggl_partial_bytes(GGL_F32, n_chunks, 8 * H, 0));
+ *                      planT->partial = ggl_partial_bytes(GGL_F32, n_chunksT, H*C + H, 0);
  *                      posT is only read with p_drop > 0 (the keep bit lives at the forward position). */
 int ggl_gat_fast_supported(int64_t H, int64_t C);
 int ggl_gat_fast_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el, const float *er,
