@@ -98,15 +98,17 @@ struct Options {
   // f32 sums: rows longer than the plan's chunk are added up in the reference's serial order (hubf32.hip: bit-identical to
   // the CPU extension on EVERY row) instead of chunk by chunk (within rounding of it); 0 = the chunked walk (A/B switch)
   int64_t exact_long_rows = 1;
-  // hosts: gspmm max backward (products-sized graph, forward + backward, profiles/r5_max_backward.txt):
-  //   K = 64 : int64 witnesses 16.5 ms, int32 witnesses (ggl_spmm_max_bwd32) 12.8, winner mask 15.8 (its pre-pass: 6.4)
-  //   K = 256: int64 67.6, int32 52.2, winner mask (ggl_spmm_max_mask + ggl_spmm_max_bwd_mask) 41.6 (pre-pass: 7.8)
-  int64_t maxbwd_arg32 = 1;       // witnesses from a compact int32 copy ...
-  int64_t maxbwd_mask = 128;      // ... and from this many columns up a 1-bit winner mask instead (0 = never)
-  int64_t maxbwd_mask_wlane = 0;   // ... its forward-order records assembled with v_writelane (inline asm) instead of selects (A/B)
+  // hosts: gspmm max backward (products-sized graph, forward + backward in ms, profiles/r5_max_backward.txt):
+  //             int64 witnesses   int32 witnesses   winner mask: forward order (writelane / select)   scattered
+  //   K =  64        16.8              12.7                        14.0 / 14.4                           15.4
+  //   K = 128        32.4              25.0                        21.6 / 23.1                           22.2
+  //   K = 256        67.1              53.0                        41.1 / 44.4                           41.7
+  int64_t maxbwd_arg32 = 1;        // witnesses from a compact int32 copy (ggl_spmm_max_bwd32) ...
+  int64_t maxbwd_mask = 128;       // ... and from this many columns up a 1-bit winner mask instead (0 = never)
+  int64_t maxbwd_mask_wlane = 1;   // ... its forward-order records assembled with v_writelane (inline asm; 0 = selects)
   int64_t maxbwd_mask_cols = 0;    // ... its walk in 64-column blocks like the plain sum's (A/B: loses, the record is re-read per block)
   int64_t maxbwd_mask_scatter = 0; // ... its records scattered to transposed positions instead of kept in forward order (A/B)
-  int64_t exact_long_max = (int64_t)1 << 21;   // ... unless the plan's longest row is longer than this (0 = no limit)
+  int64_t exact_long_max = (int64_t)1 << 21;   // exact_long_rows: unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
   int64_t gat_sh_waves = 0;       // >= 4: the output-layer GAT backward's source walk (dropout form) built for 4 wavefronts per SIMD (A/B)
   int64_t hub_one_launch = 1;     // ... once per aggregate over the full width where the aggregate runs as column blocks (0 = once per block)

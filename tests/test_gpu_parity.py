@@ -1006,7 +1006,7 @@ def test_max_backward_forms(eng, dev, oracle):
     pc.check_max_backward_forms(eng, dev, oracle)
     with pc.option(eng, "max_grid_x", 3):
         pc.check_max_backward_forms(eng, dev, oracle)
-    with pc.option(eng, "maxbwd_mask_wlane", 1):        # the forward-order records assembled with v_writelane (inline asm)
+    with pc.option(eng, "maxbwd_mask_wlane", 0):        # the forward-order records assembled with selects (default: v_writelane)
         pc.check_max_backward_forms(eng, dev, oracle)
 
 
