@@ -696,7 +696,13 @@ def compact_line(out):
         cc["norm_both"] = _pick(cfg["norm_both"], ("ms_per_step_cached", "ms_per_step_uncached"))
     ex = cfg.get("exchange")
     if isinstance(ex, dict):
-        cc["exchange"] = _pick(ex, ("halo_exposed_ms", "a2a_GB_per_step", "GBps_per_link", "overlap_frac", "chunks"))
+        cc["exchange"] = _pick(ex, ("halo_exposed_ms", "a2a_calls", "a2a_GB_in", "a2a_GB_out", "a2a_isolated_ms_per_step", "overlap_frac"))
+        iso = ex.get("a2a_isolated") or []
+        if iso:      # the widest layer's exchange on its own: GB/s per link (the figure the scaling hinges on)
+            cc["exchange"]["widest"] = _pick(max(iso, key=lambda e: e.get("K", 0)), ("K", "chunks", "fwd_ms", "bwd_ms", "GBps_per_link_fwd"))
+        if ex.get("halo_chunks"):
+            cc["exchange"]["halo_chunks"] = ex["halo_chunks"] if not isinstance(ex["halo_chunks"], dict) else \
+                {k: v for k, v in ex["halo_chunks"].items() if k in ("exchange", "const")}
     c["config"] = cc
     rf = out.get("roofline")
     if rf:
