@@ -347,8 +347,11 @@ def pmc_probe_gcn(args, dev, eng):
     torch.cuda.synchronize()
     # (reps + 1 warm-up) aggregates of `launches` dispatches each were the LAST dispatches of the dominant kernel: the
     # parent averages the counters over exactly those (a clustered order runs the same kernel while it is computed)
-    # ... and the hub walk beside them runs ONCE per aggregate since round 5 (hub_one_launch; once per launch otherwise)
-    hub = 5 * (1 if (launches > 1 and int(eng.lib.ggl_get_option(b"hub_one_launch"))) else launches)
+    # ... and the hub walk beside them runs once per launch — or ONCE per aggregate where the plan's long rows lead the id
+    # range (a degree-sorted order; option hub_one_launch, round 5)
+    ohl = int(eng.lib.ggl_get_option(b"hub_one_launch"))
+    one_hub = launches > 1 and (ohl == 1 or (ohl == 2 and bool(getattr(gp.fwd, "hub_first", False))))
+    hub = 5 * (1 if one_hub else launches)
     print(f"pmc-probe: E={gp.E} rows_in={rows} K={args.hidden} launches/aggregate={launches} ms/aggregate={ms:.3f} "
           f"aggregates=5 dispatches={5 * launches},{hub}", flush=True)
 

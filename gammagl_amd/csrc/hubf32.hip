@@ -82,7 +82,7 @@ template <int PER> struct HfIds { int32_t row[PER], wi[PER]; };       // source 
 // F64 (segment sums of doubles: the two segment modes, no weights): the producers move the row as 4-byte words — a row of
 // K doubles is a row of 2 K words, `a.K` / `a.x_ld` / `a.x` arrive in words — and only the consumer knows better: a lane
 // owns a DOUBLE (two adjacent words of the tile) and adds with __dadd_rn.  Same pipeline, same order of adds.
-template <int MODE, bool VEC4, bool WPC, int PER, int LOG_LPE, bool F64 = false>
+template <int MODE, bool VEC4, bool WPC, int PER, int LOG_LPE, bool F64 = false, bool PIPE = true>
 __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args a) {
   static_assert(!F64 || hub_seg(MODE), "doubles: segment sums only (the SpMMs are f32 in the reference)");
   constexpr int kLpe = 1 << LOG_LPE, kEpl = kWave / kLpe;          // lanes per element, elements per load instruction
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kHfBlock) void hub_rows_f32_kernel(const HubF32Args
     if (lane < ncol && s < nst) {
       const int cnt = (int)((len - s * kHfStage) < kHfStage ? (len - s * kHfStage) : kHfStage);
       int e = 0;
-      if (cnt == kHfStage) {
+      if (PIPE && cnt == kHfStage) {
         // a full stage, software-pipelined (round 5): the NEXT eight ds_read_b32 are in flight while the current eight
         // dependent adds retire — LDS returns in order, so the wait before a group of adds is lgkmcnt(8), not (0).  The
         // add chain (4 cycles per dependent v_add_f32) is then the only thing on the critical path inside a stage; the
@@ -288,17 +288,26 @@ struct HubSide {
   // join-record sequence of one call must not interleave with another's (fork is shared, the FIFO order is the contract)
   std::mutex mu;
 };
-static HubSide *hub_side(bool capturing) {
-  static HubSide sides[16][2];
+static HubSide *hub_side(bool capturing, bool high = false) {
+  static HubSide sides[16][4];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  HubSide &s = sides[dev][capturing ? 1 : 0];
+  HubSide &s = sides[dev][(capturing ? 1 : 0) + (high ? 2 : 0)];
   static std::mutex create_mu;
   std::lock_guard<std::mutex> g(create_mu);
   if (!s.ok) {
     // (a high-priority queue for the hub walk was measured and changes nothing: products step 74.99 vs 75.05 ms, bspmm
     //  16 x 16 forward 17.39 vs 17.56 — profiles/r4_negative_results.txt)
-    bool good = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    // (high: the queue with the device's greatest priority — option hub_priority, for the ONE hub launch of a column-blocked
+    //  aggregate, whose workgroups are handed out over the whole aggregate in competition with the row walks')
+    int least = 0, greatest = 0;
+    bool good = true;
+    if (high) {
+      good = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+             hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, greatest) == hipSuccess;
+    } else {
+      good = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    }
     good = good && hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; good && i < kHubJoinRing; ++i) good = hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) == hipSuccess;
     if (!good) {      // nothing half-made stays behind (and the next call starts from scratch)
@@ -327,7 +336,8 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, int *fo
   if (a.n_long <= 0 || a.K <= 0) return GGL_OK;
   hipStream_t s = stream;
   const bool capturing = beside && stream_is_capturing(stream);
-  HubSide *side = beside ? hub_side(capturing) : nullptr;
+  const bool high = beside && options().hub_priority != 0;
+  HubSide *side = beside ? hub_side(capturing, high) : nullptr;
   std::unique_lock<std::mutex> lock;
   int token = 0;
   if (side != nullptr) {
@@ -335,7 +345,7 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, int *fo
     GGL_HIP_CHECK(hipEventRecord(side->fork, stream));
     GGL_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
     s = side->stream;
-    token = 1 + side->next + (capturing ? kHubJoinRing : 0);
+    token = 1 + side->next + (capturing ? kHubJoinRing : 0) + (high ? 2 * kHubJoinRing : 0);
     side->next = (side->next + 1) % kHubJoinRing;
   }
   const bool narrow = a.K <= 16;                       // 16-column slabs, 4 lanes per element
@@ -351,6 +361,8 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, int *fo
 #define GGL_HF2(M, W, V)                                                                          \
   do {                                                                                             \
     if (narrow) GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 2, 2>), grid, kHfBlock, s, a);            \
+    else if (heavy && options().hub_pipe == 0)  /* A/B: round 4's consumer (read 8, add 8, no overlap) */ \
+      GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 4, 4, false, false>), grid, kHfBlock, s, a);        \
     else if (heavy) GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 4, 4>), grid, kHfBlock, s, a);        \
     else GGL_LAUNCH((hub_rows_f32_kernel<M, V, W, 2, 4>), grid, kHfBlock, s, a);                   \
   } while (0)
@@ -396,7 +408,8 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, int *fo
 
 int hub_f32_join(hipStream_t stream, int token) {
   if (token <= 0) return GGL_OK;
-  HubSide *side = hub_side(token > kHubJoinRing);
+  const int which = (token - 1) / kHubJoinRing;          // bit 0: capturing caller, bit 1: high-priority queue
+  HubSide *side = hub_side((which & 1) != 0, (which & 2) != 0);
   GGL_REQUIRE(side != nullptr, GGL_EHIP, "hub side stream is gone");
   GGL_HIP_CHECK(hipStreamWaitEvent(stream, side->join[(token - 1) % kHubJoinRing], 0));
   return GGL_OK;

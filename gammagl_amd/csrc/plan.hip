@@ -56,6 +56,8 @@ Options &options() {
     t.exact_long_max = env_i64("GGL_EXACT_LONG_MAX", t.exact_long_max);
     t.hub_one_launch = env_i64("GGL_HUB_ONE_LAUNCH", t.hub_one_launch);
     t.gat_sh_waves = env_i64("GGL_GAT_SH_WAVES", t.gat_sh_waves);
+    t.hub_pipe = env_i64("GGL_HUB_PIPE", t.hub_pipe);
+    t.hub_priority = env_i64("GGL_HUB_PRIORITY", t.hub_priority);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
     t.maxbwd_mask_scatter = env_i64("GGL_MAXBWD_MASK_SCATTER", t.maxbwd_mask_scatter);
@@ -302,6 +304,8 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "exact_long_max")) o.exact_long_max = value;
   else if (!strcmp(name, "hub_one_launch")) o.hub_one_launch = value;
   else if (!strcmp(name, "gat_sh_waves")) o.gat_sh_waves = value;
+  else if (!strcmp(name, "hub_pipe")) o.hub_pipe = value;
+  else if (!strcmp(name, "hub_priority")) o.hub_priority = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
   else if (!strcmp(name, "maxbwd_mask_scatter")) o.maxbwd_mask_scatter = value;
@@ -330,6 +334,8 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "exact_long_max")) return o.exact_long_max;
   if (!strcmp(name, "hub_one_launch")) return o.hub_one_launch;
   if (!strcmp(name, "gat_sh_waves")) return o.gat_sh_waves;
+  if (!strcmp(name, "hub_pipe")) return o.hub_pipe;
+  if (!strcmp(name, "hub_priority")) return o.hub_priority;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
   if (!strcmp(name, "maxbwd_mask_scatter")) return o.maxbwd_mask_scatter;

@@ -166,6 +166,7 @@ static bool capturing(const c10::Device &d) {
 
 struct SegPlan {
   int64_t N = 0, E = 0, chunk = 0, n_long = 0, n_chunks = 0, max_len = 0, xcd_run = 0;
+  bool hub_first = false;   // the long rows lead the id range (a degree-sorted node order): ggl_segplan.xcd_run_rows = -1
   bool sorted = false;
   uint64_t uid = 0;
   Tensor rowptr, perm, long_rows, chunk_ptr, long_order;
@@ -195,7 +196,7 @@ struct SegPlan {
       if (!row_order.defined() && ++uses >= 2 && !capturing(rowptr.device())) row_order = row_order_of(counts());
     }
     s.row_order = row_order.defined() ? row_order.data_ptr<int32_t>() : nullptr;
-    s.xcd_run_rows = xcd_run;
+    s.xcd_run_rows = xcd_run > 0 ? xcd_run : ((lng && hub_first) ? -1 : 0);
     s.long_order = (lng && long_order.defined()) ? long_order.data_ptr<int32_t>() : nullptr;
     s.max_len = max_len;
     return s;
@@ -231,6 +232,8 @@ static void fill_long_rows(const Api &a, SegPlan &p, void *st) {
   p.chunk_ptr = at::empty({nl + 1}, p.rowptr.options());
   check(a, a.ggl_plan_long_fill(p.rowptr.data_ptr<int64_t>(), p.N, p.chunk, nl, p.long_rows.data_ptr<int32_t>(),
                                 p.chunk_ptr.data_ptr<int64_t>(), lws.data_ptr(), lwb, st));
+  if (nl >= 8)  // do the long rows lead the id range (degree-sorted order)?  one host read, at plan build only (ops.py)
+    p.hub_first = p.long_rows.select(0, nl - 1).item<int32_t>() < 4 * nl;
   if (nl > 0)   // the serial hub walk starts its longest rows first (ggl_segplan.long_order; ops.py Engine._long_order)
     p.long_order = at::argsort(p.counts().index_select(0, p.long_rows.to(at::kLong)), /*stable=*/true, 0, /*descending=*/true).to(at::kInt);
 }

@@ -43,7 +43,7 @@ class SegPlan:
     """Destination-sorted view of one id vector (struct ggl_segplan + the tensors that own it)."""
 
     __slots__ = ("N", "E", "rowptr", "perm", "is_sorted", "max_len", "chunk", "long_rows",
-                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run", "order_fn", "uses", "wperm", "long_order")
+                 "chunk_ptr", "n_long", "n_chunks", "device", "row_order", "uid", "xcd_run", "order_fn", "uses", "wperm", "long_order", "hub_first")
 
     def c_struct(self, partial=None, perm_override=None, unsplit=False, skip_long=False):
         """`unsplit`: present the plan without its long-row table, every row walked in one piece.
@@ -70,7 +70,9 @@ class SegPlan:
             chunk=((1 << 62) if unsplit else self.chunk),
             partial=(partial.data_ptr() if partial is not None else None), N=self.N, E=self.E,
             row_order=(self.row_order.data_ptr() if self.row_order is not None else None),
-            xcd_run_rows=int(getattr(self, "xcd_run", 0) or 0),
+            # > 0: XCD runs (a node order with locality); -1: no runs, but the long rows LEAD the id range (a degree-sorted
+            # order): the hub walk of a column-blocked aggregate then runs once over the full width (include/ggl_mpops.h)
+            xcd_run_rows=(int(getattr(self, "xcd_run", 0) or 0) or (-1 if (n_long and getattr(self, "hub_first", False)) else 0)),
             long_order=(lo.data_ptr() if (n_long and lo is not None) else None),
             max_len=int(getattr(self, "max_len", 0) or 0))
 
@@ -431,6 +433,8 @@ class Engine:
                                                     _ptr(p.long_rows), _ptr(p.chunk_ptr), _ptr(lws),
                                                     lwb, st))
             p.long_order = self._long_order(p)
+            # do the long rows lead the id range (degree-sorted node order)?  One more host read, at plan build only.
+            p.hub_first = bool(p.n_long >= 8 and int(p.long_rows[-1]) < 4 * p.n_long)
         # scheduling aid: rows by descending length inside id windows, see _row_order / ggl_segplan.row_order —
         # computed when the plan is launched a second time (SegPlan.c_struct)
         p.row_order, p.uses, p.order_fn = None, 0, (self._row_order if N > 1 else None)

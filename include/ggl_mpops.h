@@ -44,7 +44,9 @@ extern "C" {
  *   library a SHORTER struct than it reads: every caller MUST check ggl_abi_version() == GGL_ABI_VERSION before it passes
  *   a ggl_segplan_t (gammagl_amd/_lib.py bind(), ggl_torch.cpp api_for() both refuse a mismatching library). */
 /* 8 (round 5): + ggl_invert_perm, ggl_spmm_max_mask[_bytes], ggl_spmm_max_bwd_mask (gspmm max backward through a 1-bit
- *   winner mask); options hub_one_launch, maxbwd_mask.  No struct change. */
+ *   winner mask), ggl_spmm_max_mask_words; ggl_spmm_max_bwd_mask takes mask_pos; ggl_gat_fast_bwd's plan->partial holds four
+ *   doubles per chunk and head; ggl_segplan_t.xcd_run_rows < 0 is a hint (see the field); options hub_one_launch, hub_priority,
+ *   maxbwd_mask*, gat_sh_waves.  No struct change. */
 #define GGL_ABI_VERSION 8
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
@@ -93,7 +95,9 @@ typedef struct ggl_segplan {
                                row slots are handed to wavefronts — scheduling only, results identical */
   int64_t xcd_run_rows;     /* > 0: the node order carries locality — hand each XCD runs of this many consecutive row
                                slots (its private L2 then serves one neighbourhood instead of 1/8 of every one);
-                               0: the library default (round-robin).  Scheduling only (ABI 5). */
+                               0: the library default (round-robin); < 0 (ABI 8): no runs, but the plan's long rows LEAD the id
+                               range (a degree-sorted node order) — a column-blocked aggregate then walks its hub rows once
+                               over the full width (option hub_one_launch = 2).  Scheduling only (ABI 5). */
   const int32_t *long_order; /* [n_long] positions in long_rows by descending row length, or NULL: the order in which the
                                serial hub walk (hubf32.hip) starts its rows — longest first, so that the one add chain
                                nobody can shorten runs under everything else.  Scheduling only (ABI 6). */
