@@ -129,13 +129,16 @@ def _ref_or_port():
         return None, "port", orc
 
 
-def _torch_fallback(ei, w, x, budget_s=14.0, chunk_edges=4_000_000):
+def _torch_fallback(ei, w, x, budget_s=10.0, chunk_edges=4_000_000):
     """The reference's pure-torch formulation of the same aggregate (mpops/torch.py:16-18,335-342: messages = x[src] * w ->
     zeros(N, K).scatter_add_(0, dst, messages)) on the benchmark graph itself, all host cores.  The [E, K] message tensor
     of the full graph is 129 GB at K = 256, so the edge list is walked in chunks of `chunk_edges` (the same three torch ops
     per chunk, ONE zero-filled output shared by all of them — round 4 zero-filled a fresh 2.5 GB output per 2 M-edge
-    sample and reported that).  Thread count: the best of {32, 64, 128, all} on two chunks each, then chunks until the time
-    budget is used; value = edges done / (their time + the zero fill's share for that many edges)."""
+    sample and reported that).  Thread count: the best of {8, 16, 32, 64, 128, all} on two chunks each (on the 256-thread
+    host of the GPU box FEWER threads win: 32 -> 2.8 M edges/s, 256 -> 1.2 M; the random 1 KiB read-modify-writes into a
+    2.5 GB output are latency-bound and the threads contend), then chunks until the time budget is used; value = edges done
+    / (their time + the zero fill's share for that many edges).  It stays BELOW the reference's serial C++ loop on one core
+    (3.6 M edges/s): that loop streams each message row once, torch materialises [chunk, K] messages and scatters them."""
     cores = os.cpu_count() or 1
     E, n = int(ei.shape[1]), int(x.shape[0])
     src_all, dst_all = ei[0], ei[1]
@@ -151,7 +154,7 @@ def _torch_fallback(ei, w, x, budget_s=14.0, chunk_edges=4_000_000):
     out = torch.zeros_like(x)
     t_zero = time.perf_counter() - t0
     run_chunk(out, 0)                                           # warm-up (allocator, thread pool)
-    cands = sorted({t for t in (32, 64, 128, cores) if t <= cores} or {cores})
+    cands = sorted({t for t in (8, 16, 32, 64, 128, cores) if t <= cores} or {cores})
     sweep = {}
     lo = chunk_edges
     for t in cands:
