@@ -109,6 +109,8 @@ SIGNATURES = {
     "ggl_sample_hop_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_sample_hop": (c_int, [_V, _V, _V, _V, c_int64, c_int64, c_int64, c_int64, c_int64, _V, _V, _V, _V, _V, _V, _V,
                                _V, c_size_t, _V]),
+    "ggl_sample_hop_ex": (c_int, [_V, _V, _V, _V, c_int64, c_int64, c_int64, c_int64, c_int64, _V, _V, _V, _V, _V, _V, _V,
+                                  _V, c_size_t, _V, _V]),
     "ggl_block_transpose_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_block_transpose": (c_int, [_V, _V, c_int64, c_int64, c_int64, _V, _V, _V, c_size_t, _V]),
     "ggl_set_option": (c_int, [c_char_p, c_int64]),

@@ -58,6 +58,7 @@ Options &options() {
     t.gat_sh_waves = env_i64("GGL_GAT_SH_WAVES", t.gat_sh_waves);
     t.hub_pipe = env_i64("GGL_HUB_PIPE", t.hub_pipe);
     t.hub_priority = env_i64("GGL_HUB_PRIORITY", t.hub_priority);
+    t.hop_fused_scans = env_i64("GGL_HOP_FUSED_SCANS", t.hop_fused_scans);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
     t.maxbwd_mask_scatter = env_i64("GGL_MAXBWD_MASK_SCATTER", t.maxbwd_mask_scatter);
@@ -306,6 +307,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "gat_sh_waves")) o.gat_sh_waves = value;
   else if (!strcmp(name, "hub_pipe")) o.hub_pipe = value;
   else if (!strcmp(name, "hub_priority")) o.hub_priority = value;
+  else if (!strcmp(name, "hop_fused_scans")) o.hop_fused_scans = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
   else if (!strcmp(name, "maxbwd_mask_scatter")) o.maxbwd_mask_scatter = value;
@@ -336,6 +338,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "gat_sh_waves")) return o.gat_sh_waves;
   if (!strcmp(name, "hub_pipe")) return o.hub_pipe;
   if (!strcmp(name, "hub_priority")) return o.hub_priority;
+  if (!strcmp(name, "hop_fused_scans")) return o.hop_fused_scans;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
   if (!strcmp(name, "maxbwd_mask_scatter")) return o.maxbwd_mask_scatter;
@@ -365,7 +368,9 @@ extern "C" int64_t ggl_policy_spmm_width(int reduce, int64_t K, int64_t E, int64
 extern "C" int64_t ggl_policy_head_channels(int64_t C, int64_t E, int64_t N_in) {
   return (C % 4 != 0 && C >= 8 && E >= 8 * N_in) ? C + (4 - C % 4) : C;
 }
-extern "C" int ggl_policy_mean_bwd_prescale(int64_t E, int64_t N_in) { return E >= 4 * N_in ? 1 : 0; }
+// (... and only on edge lists whose walk dominates its launches: on a sampled block the four elementwise kernels of the
+//  prescale — counts, clamp, cast, divide — cost more than the per-edge degree lookup they save; round 5)
+extern "C" int ggl_policy_mean_bwd_prescale(int64_t E, int64_t N_in) { return (E >= 4 * N_in && E >= ((int64_t)1 << 22)) ? 1 : 0; }
 extern "C" int ggl_policy_gradw_sorted(int64_t H, int64_t C) {
   return (C % 4 == 0 && (C > 16 || (C > 8 && H * C >= 256))) ? 1 : 0;
 }

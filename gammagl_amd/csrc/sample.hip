@@ -251,7 +251,8 @@ __global__ __launch_bounds__(kBlock) void hop_emit_kernel(const int64_t *__restr
                                                           const int64_t *__restrict__ new_id,
                                                           int64_t S_cap, int64_t *__restrict__ out_nid,
                                                           int64_t *__restrict__ local,
-                                                          int64_t *__restrict__ counts) {
+                                                          int64_t *__restrict__ counts,
+                                                          int64_t *__restrict__ overflow_total) {
   const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
   const int64_t ne = out_rowptr[B_cap];
   const int64_t n_all = new_id[B_cap + E_cap];
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(kBlock) void hop_emit_kernel(const int64_t *__restr
   if (thread_id() == 0) {
     counts[0] = n_nodes;
     counts[1] = ne;
+    const int64_t over = (n_all > S_cap || counts[2] != 0) ? 1 : 0;   // (counts[2]: rows cut at E_cap, set by the first scan)
     if (n_all > S_cap) counts[2] = 1;  // more nodes met than the caller's capacity: the block is truncated
+    // the caller's running count of hops that hit a capacity (BlockSampler.overflow_count): was a torch add per hop
+    if (overflow_total != nullptr) *overflow_total += over;
   }
   for (int64_t t = thread_id(); t < S_cap; t += stride) {
     if (t >= n_nodes) out_nid[t] = 0;  // padding rows gather node 0 (any valid row: nothing reads them)
@@ -563,6 +567,142 @@ extern "C" int ggl_sample_pick(const int64_t *rowptr, const int64_t *col, const 
   return GGL_OK;
 }
 
+#ifndef GGL_EMULATE
+// ---- count / flag + exclusive scan in ONE launch each (round 5) ------------------------------------------------------
+// The hop's two scans ran as [produce values] + rocprim's [init look-back state] + [scan] (+ two clamp kernels after the first):
+// 8 of the hop's 14 launches, ~5 us each in a replayed step whose kernels take less than that.  Here the values are computed
+// inside a single-pass chained scan: a block scans its 2048 values, publishes its total, and adds up its predecessors' by
+// looking back (decoupled look-back: a block waits only for blocks with lower ids, which were dispatched before it).
+// The look-back state needs no initialisation launch: every slot carries a 64-bit TAG made of the hop's rng offset (which the
+// hop's last kernel increments: unique per hop, also across replays of a recorded step), the scan's id and the block — a
+// slot is read only when its tag matches, whatever the buffer held before.
+struct ScanSlot {
+  unsigned long long tag;   // written LAST (release): the slot belongs to this hop, this scan, this block
+  unsigned long long fv;    // (flag << 32) | value; flag 1 = the block's own total, 2 = the total of blocks 0 .. b
+};
+constexpr int kScanIpt = 8, kScanTile = kBlock * kScanIpt;   // values per thread / per block
+__device__ __forceinline__ unsigned long long scan_tag(unsigned long long base, int64_t b) {
+  unsigned long long z = base + 0x9E3779B97F4A7C15ull * (unsigned long long)(b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (z ^ (z >> 31)) | 1ull;
+}
+// exclusive prefix of this thread's partial sum `tsum` over the whole grid (thread order = block-major): returns the sum of
+// everything before this thread.  Every thread of every block must call it once.
+__device__ __forceinline__ uint32_t chained_exclusive(uint32_t tsum, ScanSlot *__restrict__ state, unsigned long long base) {
+  __shared__ uint32_t wsum[kWavesPerBlock];
+  __shared__ uint32_t bprefix;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  uint32_t incl = tsum;
+#pragma unroll
+  for (int dlt = 1; dlt < kWave; dlt <<= 1) {
+    const uint32_t y = __shfl_up(incl, dlt, kWave);
+    if (lane >= dlt) incl += y;
+  }
+  if (lane == kWave - 1) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < kWavesPerBlock; ++q) {
+    if (q < wave) woff += wsum[q];
+    total += wsum[q];
+  }
+  if (threadIdx.x == 0) {
+    const int64_t b = block_id();
+    ScanSlot *mine = state + b;
+    uint32_t run = 0;
+    if (b == 0) {
+      __hip_atomic_store(&mine->fv, (2ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&mine->tag, scan_tag(base, b), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(&mine->fv, (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&mine->tag, scan_tag(base, b), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t j = b - 1; j >= 0; --j) {
+        const unsigned long long want = scan_tag(base, j);
+        while (__hip_atomic_load(&state[j].tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
+        const unsigned long long fv = __hip_atomic_load(&state[j].fv, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        run += (uint32_t)fv;
+        if ((fv >> 32) == 2ull) break;
+      }
+      __hip_atomic_store(&mine->fv, (2ull << 32) | (unsigned long long)(run + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bprefix = run;
+  }
+  __syncthreads();
+  return bprefix + woff + (incl - tsum);
+}
+
+// hop_count_kernel + exclusive scan + hop_clamp_kernel + hop_clamp_last_kernel: out_rowptr[i] = min(E_cap, sum of the first i
+// rows' sample counts), i in [0, B_cap]; counts[2] = 1 when the unclamped total exceeds E_cap
+__global__ __launch_bounds__(kBlock) void hop_count_scan_kernel(const int64_t *__restrict__ rowptr, const int64_t *__restrict__ seeds,
+                                                                const int64_t *__restrict__ n_seeds, int64_t B_cap, int64_t N,
+                                                                int64_t fanout, int64_t E_cap, const int64_t *__restrict__ rng,
+                                                                ScanSlot *__restrict__ state, int64_t *__restrict__ out_rowptr,
+                                                                int64_t *__restrict__ counts) {
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t i0 = block_id() * kScanTile + (int64_t)threadIdx.x * kScanIpt;
+  uint32_t v[kScanIpt], tsum = 0;
+#pragma unroll
+  for (int q = 0; q < kScanIpt; ++q) {
+    const int64_t i = i0 + q;
+    int64_t k = 0;
+    if (i < nb) {
+      const int64_t sd = seeds[i];
+      const int64_t deg = (sd >= 0 && sd < N) ? rowptr[sd + 1] - rowptr[sd] : 0;
+      k = deg < fanout ? deg : fanout;
+    }
+    v[q] = (uint32_t)k;
+    tsum += v[q];
+  }
+  uint64_t p = chained_exclusive(tsum, state, ((unsigned long long)rng[1] << 2) | 1ull);
+#pragma unroll
+  for (int q = 0; q < kScanIpt; ++q) {
+    const int64_t i = i0 + q;
+    if (i <= B_cap) {
+      out_rowptr[i] = (int64_t)p < E_cap ? (int64_t)p : E_cap;
+      if (i == B_cap) counts[2] = (int64_t)p > E_cap ? 1 : 0;
+    }
+    p += v[q];
+  }
+}
+
+// hop_flag_kernel + exclusive scan: flag[t] (this position introduces a node) and new_id[t] (nodes introduced before it),
+// t in [0, B_cap + E_cap]
+__global__ __launch_bounds__(kBlock) void hop_flag_scan_kernel(const int64_t *__restrict__ n_seeds, int64_t B_cap, int64_t E_cap,
+                                                               const int64_t *__restrict__ nbr, const int64_t *__restrict__ out_rowptr,
+                                                               const long long *__restrict__ first_pos, const int64_t *__restrict__ rng,
+                                                               ScanSlot *__restrict__ state, int64_t *__restrict__ flag,
+                                                               int64_t *__restrict__ new_id) {
+  const int64_t nb = *n_seeds < B_cap ? *n_seeds : B_cap;
+  const int64_t ne = out_rowptr[B_cap];
+  const int64_t T = B_cap + E_cap;
+  const int64_t i0 = block_id() * kScanTile + (int64_t)threadIdx.x * kScanIpt;
+  uint32_t v[kScanIpt], tsum = 0;
+#pragma unroll
+  for (int q = 0; q < kScanIpt; ++q) {
+    const int64_t t = i0 + q;
+    uint32_t f = 0;
+    if (t < B_cap) f = t < nb ? 1u : 0u;
+    else if (t < T) {
+      const int64_t e = t - B_cap;
+      f = (e < ne && first_pos[nbr[e]] == (long long)t) ? 1u : 0u;
+    }
+    v[q] = f;
+    tsum += f;
+  }
+  uint32_t p = chained_exclusive(tsum, state, ((unsigned long long)rng[1] << 2) | 2ull);
+#pragma unroll
+  for (int q = 0; q < kScanIpt; ++q) {
+    const int64_t t = i0 + q;
+    if (t <= T) {
+      flag[t] = (int64_t)v[q];
+      new_id[t] = (int64_t)p;
+    }
+    p += v[q];
+  }
+}
+#endif
+
 // ---- static-shape hop -------------------------------------------------------------------------------
 extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t E_cap) {
   if (B_cap < 0 || E_cap < 0) return 0;
@@ -572,15 +712,16 @@ extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t E_cap) {
   b += 2 * up256((size_t)T * 8);                      // flag, new_id
 #ifndef GGL_EMULATE
   b += up256(scan_temp_bytes(T > B_cap + 1 ? T : B_cap + 1));
+  b += 2 * up256((size_t)(ceil_div(T + 1, (int64_t)kScanTile) + 1) * sizeof(ScanSlot));   // look-back slots of the two fused scans
 #endif
   return b + 256;
 }
 
-extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds,
-                              const int64_t *n_seeds_dev, int64_t B_cap, int64_t num_nodes, int64_t fanout,
-                              int64_t E_cap, int64_t S_cap, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
-                              int32_t *out_col, int64_t *out_eid, int64_t *out_nid, int64_t *out_counts,
-                              void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int ggl_sample_hop_ex(const int64_t *rowptr, const int64_t *col, const int64_t *seeds,
+                                 const int64_t *n_seeds_dev, int64_t B_cap, int64_t num_nodes, int64_t fanout,
+                                 int64_t E_cap, int64_t S_cap, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
+                                 int32_t *out_col, int64_t *out_eid, int64_t *out_nid, int64_t *out_counts,
+                                 void *workspace, size_t workspace_bytes, int64_t *overflow_total, void *stream) {
   GGL_REQUIRE(B_cap >= 0 && fanout > 0, GGL_EINVAL, "the static-shape hop needs a positive fan-out");
   GGL_REQUIRE(E_cap > 0 && E_cap <= B_cap * fanout && S_cap >= B_cap && S_cap <= B_cap + E_cap, GGL_EINVAL,
               "capacities: 0 < E_cap <= B_cap * fanout, B_cap <= S_cap <= B_cap + E_cap");
@@ -603,15 +744,34 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   void *tmp = ws + off;
   const size_t tmp_bytes = workspace_bytes - off;
   long long *fp = reinterpret_cast<long long *>(first_pos);
-  GGL_LAUNCH((hop_count_kernel), grid_for(B_cap + 1), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap, num_nodes, fanout,
-             cnt);
-  GGL_LAUNCH_CHECK();
-  int rc = scan_i64(tmp, tmp_bytes, cnt, out_rowptr, B_cap + 1, s);
-  if (rc) return rc;
-  GGL_LAUNCH((hop_clamp_kernel), grid_for(B_cap), kBlock, s, out_rowptr, B_cap, E_cap, out_counts);
-  GGL_LAUNCH_CHECK();
-  GGL_LAUNCH((hop_clamp_last_kernel), 1, 64, s, out_rowptr, B_cap, E_cap);
-  GGL_LAUNCH_CHECK();
+  int rc = GGL_OK;
+#ifndef GGL_EMULATE
+  // the look-back slots of the two fused scans sit behind rocprim's scratch (sized in ggl_sample_hop_workspace_bytes)
+  const size_t slots_bytes = up256((size_t)(ceil_div(T + 1, (int64_t)kScanTile) + 1) * sizeof(ScanSlot));
+  const size_t rp_bytes = up256(scan_temp_bytes(T > B_cap + 1 ? T : B_cap + 1));
+  ScanSlot *slots1 = reinterpret_cast<ScanSlot *>(ws + off + rp_bytes);
+  ScanSlot *slots2 = reinterpret_cast<ScanSlot *>(ws + off + rp_bytes + slots_bytes);
+  const bool fused_scans = options().hop_fused_scans != 0;
+#else
+  const bool fused_scans = false;
+#endif
+  if (fused_scans) {
+#ifndef GGL_EMULATE
+    GGL_LAUNCH((hop_count_scan_kernel), ceil_div(B_cap + 1, (int64_t)kScanTile), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap,
+               num_nodes, fanout, E_cap, (const int64_t *)rng_state, slots1, out_rowptr, out_counts);
+    GGL_LAUNCH_CHECK();
+#endif
+  } else {
+    GGL_LAUNCH((hop_count_kernel), grid_for(B_cap + 1), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap, num_nodes, fanout,
+               cnt);
+    GGL_LAUNCH_CHECK();
+    rc = scan_i64(tmp, tmp_bytes, cnt, out_rowptr, B_cap + 1, s);
+    if (rc) return rc;
+    GGL_LAUNCH((hop_clamp_kernel), grid_for(B_cap), kBlock, s, out_rowptr, B_cap, E_cap, out_counts);
+    GGL_LAUNCH_CHECK();
+    GGL_LAUNCH((hop_clamp_last_kernel), 1, 64, s, out_rowptr, B_cap, E_cap);
+    GGL_LAUNCH_CHECK();
+  }
   const bool in_regs = fanout <= kRegF;
   if (in_regs)
     GGL_LAUNCH((hop_pick_reg_kernel), grid_for(B_cap), kBlock, s, rowptr, col, seeds, n_seeds_dev, B_cap, fanout,
@@ -623,14 +783,22 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
   GGL_LAUNCH((hop_mark_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
              (const int64_t *)out_rowptr, num_nodes, fp);
   GGL_LAUNCH_CHECK();
-  GGL_LAUNCH((hop_flag_kernel), grid_for(T), kBlock, s, n_seeds_dev, B_cap, E_cap, (const int64_t *)nbr,
-             (const int64_t *)out_rowptr, (const long long *)fp, flag);
-  GGL_LAUNCH_CHECK();
-  rc = scan_i64(tmp, tmp_bytes, flag, new_id, T, s);
-  if (rc) return rc;
+  if (fused_scans) {
+#ifndef GGL_EMULATE
+    GGL_LAUNCH((hop_flag_scan_kernel), ceil_div(T, (int64_t)kScanTile), kBlock, s, n_seeds_dev, B_cap, E_cap, (const int64_t *)nbr,
+               (const int64_t *)out_rowptr, (const long long *)fp, (const int64_t *)rng_state, slots2, flag, new_id);
+    GGL_LAUNCH_CHECK();
+#endif
+  } else {
+    GGL_LAUNCH((hop_flag_kernel), grid_for(T), kBlock, s, n_seeds_dev, B_cap, E_cap, (const int64_t *)nbr,
+               (const int64_t *)out_rowptr, (const long long *)fp, flag);
+    GGL_LAUNCH_CHECK();
+    rc = scan_i64(tmp, tmp_bytes, flag, new_id, T, s);
+    if (rc) return rc;
+  }
   GGL_LAUNCH((hop_emit_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, E_cap,
              (const int64_t *)nbr, (const int64_t *)out_rowptr, (const long long *)fp, (const int64_t *)flag,
-             (const int64_t *)new_id, S_cap, out_nid, local, out_counts);
+             (const int64_t *)new_id, S_cap, out_nid, local, out_counts, overflow_total);
   GGL_LAUNCH_CHECK();
   GGL_LAUNCH((hop_reset_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
              (const int64_t *)out_rowptr, num_nodes, fp, rng_state);
@@ -643,6 +811,15 @@ extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const i
                out_col, out_eid);
   GGL_LAUNCH_CHECK();
   return GGL_OK;
+}
+
+extern "C" int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *seeds,
+                              const int64_t *n_seeds_dev, int64_t B_cap, int64_t num_nodes, int64_t fanout,
+                              int64_t E_cap, int64_t S_cap, int64_t *rng_state, int64_t *first_pos, int64_t *out_rowptr,
+                              int32_t *out_col, int64_t *out_eid, int64_t *out_nid, int64_t *out_counts,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+  return ggl_sample_hop_ex(rowptr, col, seeds, n_seeds_dev, B_cap, num_nodes, fanout, E_cap, S_cap, rng_state, first_pos,
+                           out_rowptr, out_col, out_eid, out_nid, out_counts, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" size_t ggl_block_transpose_workspace_bytes(int64_t E_cap, int64_t N_src_cap) {

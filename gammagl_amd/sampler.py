@@ -350,11 +350,11 @@ class BlockSampler:
             counts = torch.empty(3, dtype=torch.int64, device=dev)   # (all three are assigned by the hop's kernels)
             wsb = eng.lib.ggl_sample_hop_workspace_bytes(b_cap, e_cap)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            eng._check(eng.lib.ggl_sample_hop(_ptr(self.rowptr), _ptr(self.col), _ptr(cur), _ptr(n_cur), b_cap,
-                                              self.num_nodes, f, e_cap, s_cap, _ptr(eng._rng_state(dev)), _ptr(self._first_pos),
-                                              _ptr(rowptr), _ptr(col), _ptr(e_pos), _ptr(nid), _ptr(counts), _ptr(ws),
-                                              wsb, st))
-            self._overflow += counts[2]
+            # (the running overflow count is kept by the hop's own kernels: `self._overflow += counts[2]` was a launch per hop)
+            eng._check(eng.lib.ggl_sample_hop_ex(_ptr(self.rowptr), _ptr(self.col), _ptr(cur), _ptr(n_cur), b_cap,
+                                                 self.num_nodes, f, e_cap, s_cap, _ptr(eng._rng_state(dev)), _ptr(self._first_pos),
+                                                 _ptr(rowptr), _ptr(col), _ptr(e_pos), _ptr(nid), _ptr(counts), _ptr(ws),
+                                                 wsb, _ptr(self._overflow), st))
             blk = Block(eng, rowptr, col, e_pos, counts, b_cap, s_cap, f)
             blk.n_id, blk.seeds, blk.n_seeds = nid, cur, n_cur   # global ids of its rows / of its seeds
             blocks.append(blk)

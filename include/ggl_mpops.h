@@ -465,6 +465,12 @@ int ggl_sample_hop(const int64_t *rowptr, const int64_t *col, const int64_t *see
                    int64_t B_cap, int64_t num_nodes, int64_t fanout, int64_t E_cap, int64_t S_cap, int64_t *rng_state,
                    int64_t *first_pos, int64_t *out_rowptr, int32_t *out_col, int64_t *out_eid, int64_t *out_nid,
                    int64_t *out_counts, void *workspace, size_t workspace_bytes, void *stream);
+/* (ABI 8) the same hop; overflow_total (device, or NULL): += 1 when this hop hit a capacity — the caller's running count
+ * of truncated hops, kept by the hop's own kernels instead of a host-side add per hop */
+int ggl_sample_hop_ex(const int64_t *rowptr, const int64_t *col, const int64_t *seeds, const int64_t *n_seeds_dev,
+                      int64_t B_cap, int64_t num_nodes, int64_t fanout, int64_t E_cap, int64_t S_cap, int64_t *rng_state,
+                      int64_t *first_pos, int64_t *out_rowptr, int32_t *out_col, int64_t *out_eid, int64_t *out_nid,
+                      int64_t *out_counts, void *workspace, size_t workspace_bytes, int64_t *overflow_total, void *stream);
 /* CSC of such a block without a host read: rowptrT[N_src_cap + 1], dstT[E_cap] = destination rows of each source
  * row's block edges (ascending); E_cap entries of col of which rowptr[N_dst] are valid. */
 size_t ggl_block_transpose_workspace_bytes(int64_t E_cap, int64_t N_src_cap);
