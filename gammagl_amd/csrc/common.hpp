@@ -111,8 +111,12 @@ struct Options {
   int64_t exact_long_max = (int64_t)1 << 21;   // exact_long_rows: unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
   int64_t gat_sh_waves = 0;       // >= 4: the output-layer GAT backward's source walk (dropout form) built for 4 wavefronts per SIMD (A/B)
-  int64_t hop_fused_scans = 1;    // static-shape sampler hop: count / flag + scan (+ clamp) as ONE launch each (0 = rocprim's scan between separate kernels)
-  int64_t hub_priority = 1;       // the hub walk's side queue created with the device's greatest priority (13.75 -> 13.60 ms per aggregate)
+  // static-shape sampler hop: count / flag + scan (+ clamp) as ONE launch each (single-pass chained scan).  Measured (round 5,
+  // profiles/r5_sage_fused_scans.txt): 76 -> 63 launches per replayed step, but the same 0.17 ms for the two hops — the fused
+  // kernels take the 13-33 us their look-back chains need where five 5-us launches stood.  OFF: no gain to set against a
+  // kernel that spins on its predecessors.
+  int64_t hop_fused_scans = 0;
+  int64_t hub_priority = 1;       // the hub walk's side queue created with the device's greatest priority (big eager launches only: hubf32.hip)
   int64_t hub_pipe = 1;           // hub walk's consumer with its LDS reads software-pipelined (0 = round 4's: A/B, heavy configuration only)
   int64_t hub_one_launch = 2;     // hub walk once per aggregate over the full width: 1 = always, 0 = once per column block, 2 = where the long rows lead the ids
 };

@@ -775,6 +775,10 @@ def test_weight_dtype_guard(eng, dev):
 
 def test_static_shape_block_sampler(eng, dev, oracle):
     pc.check_block_sampler(eng, dev, oracle)
+    # ... and with count / flag + scan (+ clamp) fused into one launch each (single-pass chained scans; an A/B knob, off by
+    # default: same blocks, bit for bit — the checks compare against the dynamic sampler and the oracle)
+    with pc.option(eng, "hop_fused_scans", 1):
+        pc.check_block_sampler(eng, dev, oracle)
 
 
 def test_minibatch_step_captures_into_one_hipgraph(eng, dev):
