@@ -116,7 +116,10 @@ struct Options {
   // kernels take the 13-33 us their look-back chains need where five 5-us launches stood.  OFF: no gain to set against a
   // kernel that spins on its predecessors.
   int64_t hop_fused_scans = 0;
-  int64_t hub_priority = 1;       // the hub walk's side queue created with the device's greatest priority (big eager launches only: hubf32.hip)
+  // the hub walk's side queue created with the device's greatest priority (big eager launches only: hubf32.hip).  OFF: the
+  // isolated aggregate gains 1 % (13.75 -> 13.60 ms) but the products STEP nothing (75.46 vs 75.45 ms) and a partitioned step
+  // LOSES (dry 8-way share 14.3 -> 16.9 ms, 4-way 26.1 -> 29.3: profiles/r5_priority_ab.txt)
+  int64_t hub_priority = 0;
   int64_t hub_pipe = 1;           // hub walk's consumer with its LDS reads software-pipelined (0 = round 4's: A/B, heavy configuration only)
   int64_t hub_one_launch = 2;     // hub walk once per aggregate over the full width: 1 = always, 0 = once per column block, 2 = where the long rows lead the ids
 };

@@ -336,8 +336,8 @@ int hub_f32_launch(const HubF32Args &a, hipStream_t stream, bool beside, int *fo
   if (a.n_long <= 0 || a.K <= 0) return GGL_OK;
   hipStream_t s = stream;
   const bool capturing = beside && stream_is_capturing(stream);
-  // the greatest-priority queue only for the big eager launches it was measured on (products-sized K = 256 aggregate:
-  // 13.75 -> 13.60 ms): a recorded arxiv-sized step (0.3 ms aggregates, replayed from a hipGraph) ran 3.1 -> 4.3 ms with it
+  // the greatest-priority queue (option hub_priority, off by default: common.hpp) only for big eager launches: a recorded
+  // arxiv-sized step (0.3 ms aggregates, replayed from a hipGraph) ran 3.1 -> 4.3 ms with it
   const bool high = beside && options().hub_priority != 0 && !capturing &&
                     a.avg_long_len * a.n_long >= ((int64_t)1 << 22);
   HubSide *side = beside ? hub_side(capturing, high) : nullptr;
