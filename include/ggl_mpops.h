@@ -45,8 +45,8 @@ extern "C" {
  *   a ggl_segplan_t (gammagl_amd/_lib.py bind(), ggl_torch.cpp api_for() both refuse a mismatching library). */
 /* 8 (round 5): + ggl_invert_perm, ggl_spmm_max_mask[_bytes], ggl_spmm_max_bwd_mask (gspmm max backward through a 1-bit
  *   winner mask), ggl_spmm_max_mask_words; ggl_spmm_max_bwd_mask takes mask_pos; ggl_gat_fast_bwd's plan->partial holds four
- *   doubles per chunk and head; ggl_segplan_t.xcd_run_rows < 0 is a hint (see the field); options hub_one_launch, hub_priority,
- *   maxbwd_mask*, gat_sh_waves.  No struct change. */
+ *   doubles per chunk and head; ggl_segplan_t.xcd_run_rows < 0 is a hint (see the field); + ggl_sample_hop_ex; options
+ *   hub_one_launch, hub_priority, hub_pipe, maxbwd_mask*, gat_sh_waves, hop_fused_scans.  No struct change. */
 #define GGL_ABI_VERSION 8
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
