@@ -110,6 +110,11 @@ struct Options {
   int64_t maxbwd_mask_scatter = 0; // ... its records scattered to transposed positions instead of kept in forward order (A/B)
   int64_t exact_long_max = (int64_t)1 << 21;   // exact_long_rows: unless the plan's longest row is longer than this (0 = no limit)
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
+  // the head-mean (output-layer) GAT walks, round 5 (Reddit-sized graph, profiles/r5_gat_sh_forms.txt: layer fwd 5.13 -> 4.64 ms,
+  // fwd + bwd 20.9 -> 18.6 ms, 2-layer step 32.0 -> 29.6 ms):
+  int64_t gat_sh_prefetch = 1;    // forward / destination walks request the next step's ids before this step's gathers
+  int64_t gat_sh_zlds = 1;        // source walk of the backward: the row's z_j in per-lane LDS slots instead of 32 registers (140 -> 125:
+                                  // 4 wavefronts per SIMD without spills) + the same id prefetch
   int64_t gat_sh_waves = 0;       // >= 4: the output-layer GAT backward's source walk (dropout form) built for 4 wavefronts per SIMD (A/B)
   // static-shape sampler hop: count / flag + scan (+ clamp) as ONE launch each (single-pass chained scan).  Measured (round 5,
   // profiles/r5_sage_fused_scans.txt): 76 -> 63 launches per replayed step, but the same 0.17 ms for the two hops — the fused

@@ -526,7 +526,9 @@ __device__ __forceinline__ void sh_block(const int32_t *__restrict__ col, int64_
 }
 
 // forward: A[i,h,:] = sum_p keep_p/(1-pd) exp(s_p - m) x[col[p],:] / (den + 1e-16), den[i,h] = sum_p exp(s_p - m)
-template <bool DROP>
+// PF (round 5, with gat_sh_bwd_src's ZLDS form: option gat_sh_zlds): the NEXT step's column ids are requested before this step's
+// gathers — a step then waits for one memory round trip instead of two dependent ones
+template <bool DROP, bool PF = false>
 __global__ __launch_bounds__(kBlock) void gat_sh_fwd_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ row_order,
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el,
@@ -541,9 +543,15 @@ __global__ __launch_bounds__(kBlock) void gat_sh_fwd_kernel(
 #pragma unroll
   for (int q = 0; q < kShH; ++q) acc[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float den = 0.0f;
+  ShBlock b, nb;
+  if (PF && (it.beg & ~(int64_t)3) < it.end) sh_block(col, it.beg & ~(int64_t)3, it.beg, it.end, nb);
   for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
-    ShBlock b;
-    sh_block(col, p0, it.beg, it.end, b);
+    if (PF) {
+      b = nb;
+      if (p0 + 4 < it.end) sh_block(col, p0 + 4, it.beg, it.end, nb);
+    } else {
+      sh_block(col, p0, it.beg, it.end, b);
+    }
     float4 xv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) xv[u] = act ? *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(kBlock) void gat_sh_fwd_final_kernel(const int32_t 
 }
 
 // destination walk of the backward: ger[i,h] = sum_p de_p with <G_i[h,:], x_j> from the row's G in registers
-template <bool DROP>
+template <bool DROP, bool PF = false>
 __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ row_order,
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el,
@@ -626,9 +634,15 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
   const float4 st = *reinterpret_cast<const float4 *>(stats + (it.row * kShH + h) * 4);  // {er, m, rinv, dot}
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
   float gs = 0.0f;
+  ShBlock b, nb;
+  if (PF && (it.beg & ~(int64_t)3) < it.end) sh_block(col, it.beg & ~(int64_t)3, it.beg, it.end, nb);
   for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
-    ShBlock b;
-    sh_block(col, p0, it.beg, it.end, b);
+    if (PF) {
+      b = nb;
+      if (p0 + 4 < it.end) sh_block(col, p0 + 4, it.beg, it.end, nb);
+    } else {
+      sh_block(col, p0, it.beg, it.end, b);
+    }
     float4 xv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) xv[u] = act ? *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -666,7 +680,11 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
 // WAVES: wavefronts per SIMD the register allocator is asked to leave room for (1 = no request).  With dropout the kernel
 // needs 140 registers = 3 wavefronts per SIMD (without: 127 = 4); asked for 4 it fits 128 with 10 spilled values (44 bytes of
 // scratch).  Option `gat_sh_waves` (A/B, round 5): profiles/r5_gat_sh_waves.txt.
-template <bool DROP, int WAVES = 1>
+// ZLDS (round 5, A/B: option gat_sh_zlds): the row's own transformed features z_j (8 heads x this lane's 4 columns = 32
+// registers that only feed the dot products) live in LDS instead — each lane reads back exactly the slot it wrote, so no barrier
+// is involved: LDS as a per-lane register file.  140 -> ~110 registers = 4 wavefronts per SIMD without spills; costs 16
+// ds_read_b128 per 4-edge step (the LDS pipe is otherwise idle here).
+template <bool DROP, int WAVES = 1, bool ZLDS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void gat_sh_bwd_src_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col /* colT */, const int32_t *__restrict__ posT,
     const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
@@ -675,19 +693,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     float *__restrict__ pacc, float *__restrict__ pgel, const int64_t *__restrict__ rng, const ShDims d) {
   GGL_SH_PROLOGUE();
   const int64_t F = d.F;  // here: padded class width of gy / z rows
-  float4 zr[kShH], acc[kShH];
+  __shared__ float4 zs[ZLDS ? kShH : 1][ZLDS ? kBlock : 1];
+  float4 zr[ZLDS ? 1 : kShH], acc[kShH];
 #pragma unroll
   for (int q = 0; q < kShH; ++q) {
-    zr[q] = act ? *reinterpret_cast<const float4 *>(z + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 zq = act ? *reinterpret_cast<const float4 *>(z + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ZLDS) zs[q][threadIdx.x] = zq; else zr[q] = zq;
     acc[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   const float el_j = el[it.row * kShH + h];
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
   float gl = 0.0f;
+  // (ZLDS: the registers it frees also pay for the NEXT step's ids — requested before this step's gathers, so that a step
+  //  waits for one memory round trip, its gathers', instead of two dependent ones)
+  ShBlock b, fp, nb, nfp;  // fp: the block's FORWARD positions (dropout), fetched beside the column ids, not behind them
+  if (ZLDS && (it.beg & ~(int64_t)3) < it.end) {
+    sh_block(col, it.beg & ~(int64_t)3, it.beg, it.end, nb);
+    if (DROP) sh_block(posT, it.beg & ~(int64_t)3, it.beg, it.end, nfp);
+  }
   for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
-    ShBlock b, fp;  // fp: the block's FORWARD positions (dropout), fetched beside the column ids, not behind them
-    sh_block(col, p0, it.beg, it.end, b);
-    if (DROP) sh_block(posT, p0, it.beg, it.end, fp);
+    if (ZLDS) {
+      b = nb;
+      if (DROP) fp = nfp;
+      if (p0 + 4 < it.end) {
+        sh_block(col, p0 + 4, it.beg, it.end, nb);
+        if (DROP) sh_block(posT, p0 + 4, it.beg, it.end, nfp);
+      }
+    } else {
+      sh_block(col, p0, it.beg, it.end, b);
+      if (DROP) sh_block(posT, p0, it.beg, it.end, fp);
+    }
     float4 gv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) gv[u] = act ? *reinterpret_cast<const float4 *>(gy + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -696,14 +731,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     const float4 st0 = *reinterpret_cast<const float4 *>(stats + ((int64_t)cA * kShH + h) * 4);
     const float4 st1 = *reinterpret_cast<const float4 *>(stats + ((int64_t)cB * kShH + h) * 4);
     float wk[2];
+    if (ZLDS) asm volatile("" ::: "memory");   // (the z slots are re-read every step: hoisted out of the loop they would be the 32 registers again)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       float v[16];
 #pragma unroll
       for (int q = 0; q < kShH; ++q) {
-        v[q] = dot4(zr[q], gv[2 * pr]);
-        v[8 + q] = dot4(zr[q], gv[2 * pr + 1]);
+        const float4 zq = ZLDS ? zs[q][threadIdx.x] : zr[q];
+        v[q] = dot4(zq, gv[2 * pr]);
+        v[8 + q] = dot4(zq, gv[2 * pr + 1]);
       }
+      if (ZLDS) asm volatile("" ::: "memory");
       float da = reduce_scatter16(v, li);
       const float4 st = pr ? st1 : st0;
       const bool ok = pr ? okB : okA;
@@ -950,8 +988,15 @@ extern "C" int ggl_gat_sh_fwd(const ggl_segplan_t *plan, const int32_t *col, con
                (const float *)pmax, rowmax, plan->n_long);
     GGL_LAUNCH_CHECK();
   }
-  if (d.drop_thresh)
+  const bool pf = options().gat_sh_prefetch != 0;
+  if (d.drop_thresh && pf)
+    GGL_LAUNCH((gat_sh_fwd_kernel<true, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows, plan->chunk_ptr,
+               el, er, (const float *)rowmax, x, A, den, pacc, pden, (const int64_t *)rng_state, d);
+  else if (d.drop_thresh)
     GGL_LAUNCH((gat_sh_fwd_kernel<true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows, plan->chunk_ptr,
+               el, er, (const float *)rowmax, x, A, den, pacc, pden, (const int64_t *)rng_state, d);
+  else if (pf)
+    GGL_LAUNCH((gat_sh_fwd_kernel<false, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows, plan->chunk_ptr,
                el, er, (const float *)rowmax, x, A, den, pacc, pden, (const int64_t *)rng_state, d);
   else
     GGL_LAUNCH((gat_sh_fwd_kernel<false>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows, plan->chunk_ptr,
@@ -989,8 +1034,15 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? plan->row_order : nullptr;
-    if (d.drop_thresh)
+    const bool pf = options().gat_sh_prefetch != 0;
+    if (d.drop_thresh && pf)
+      GGL_LAUNCH((gat_sh_bwd_dst_kernel<true, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                 plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+    else if (d.drop_thresh)
       GGL_LAUNCH((gat_sh_bwd_dst_kernel<true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                 plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+    else if (pf)
+      GGL_LAUNCH((gat_sh_bwd_dst_kernel<false, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
                  plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
     else
       GGL_LAUNCH((gat_sh_bwd_dst_kernel<false>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
@@ -1016,11 +1068,17 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? planT->row_order : nullptr;
-    if (d.drop_thresh && options().gat_sh_waves >= 4)
+    if (d.drop_thresh && options().gat_sh_zlds != 0)
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 1, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    else if (d.drop_thresh && options().gat_sh_waves >= 4)
       GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 4>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
                  planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
     else if (d.drop_thresh)
       GGL_LAUNCH((gat_sh_bwd_src_kernel<true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    else if (options().gat_sh_zlds != 0)
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<false, 1, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
                  planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
     else
       GGL_LAUNCH((gat_sh_bwd_src_kernel<false>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,

@@ -56,6 +56,8 @@ Options &options() {
     t.exact_long_max = env_i64("GGL_EXACT_LONG_MAX", t.exact_long_max);
     t.hub_one_launch = env_i64("GGL_HUB_ONE_LAUNCH", t.hub_one_launch);
     t.gat_sh_waves = env_i64("GGL_GAT_SH_WAVES", t.gat_sh_waves);
+    t.gat_sh_zlds = env_i64("GGL_GAT_SH_ZLDS", t.gat_sh_zlds);
+    t.gat_sh_prefetch = env_i64("GGL_GAT_SH_PREFETCH", t.gat_sh_prefetch);
     t.hub_pipe = env_i64("GGL_HUB_PIPE", t.hub_pipe);
     t.hub_priority = env_i64("GGL_HUB_PRIORITY", t.hub_priority);
     t.hop_fused_scans = env_i64("GGL_HOP_FUSED_SCANS", t.hop_fused_scans);
@@ -305,6 +307,8 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "exact_long_max")) o.exact_long_max = value;
   else if (!strcmp(name, "hub_one_launch")) o.hub_one_launch = value;
   else if (!strcmp(name, "gat_sh_waves")) o.gat_sh_waves = value;
+  else if (!strcmp(name, "gat_sh_zlds")) o.gat_sh_zlds = value;
+  else if (!strcmp(name, "gat_sh_prefetch")) o.gat_sh_prefetch = value;
   else if (!strcmp(name, "hub_pipe")) o.hub_pipe = value;
   else if (!strcmp(name, "hub_priority")) o.hub_priority = value;
   else if (!strcmp(name, "hop_fused_scans")) o.hop_fused_scans = value;
@@ -336,6 +340,8 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "exact_long_max")) return o.exact_long_max;
   if (!strcmp(name, "hub_one_launch")) return o.hub_one_launch;
   if (!strcmp(name, "gat_sh_waves")) return o.gat_sh_waves;
+  if (!strcmp(name, "gat_sh_zlds")) return o.gat_sh_zlds;
+  if (!strcmp(name, "gat_sh_prefetch")) return o.gat_sh_prefetch;
   if (!strcmp(name, "hub_pipe")) return o.hub_pipe;
   if (!strcmp(name, "hub_priority")) return o.hub_priority;
   if (!strcmp(name, "hop_fused_scans")) return o.hop_fused_scans;

@@ -814,6 +814,13 @@ def test_minibatch_step_captures_into_one_hipgraph(eng, dev):
     assert bool(torch.isfinite(tr.step(x, y, seeds)))
 
 
+def test_gat_headmean_walk_forms(eng, dev):
+    """The round-5 forms of the head-mean walks (z_j in LDS slots + ids requested a step ahead: options gat_sh_zlds /
+    gat_sh_prefetch, on by default) and the round-4 forms they replace: the same test either way."""
+    with pc.option(eng, "gat_sh_zlds", 0), pc.option(eng, "gat_sh_prefetch", 0):
+        test_gat_headmean_layer_aggregate_then_transform(eng, dev)
+
+
 def test_gat_headmean_layer_aggregate_then_transform(eng, dev):
     """The head-averaging GAT layer aggregated before it is transformed (ggl_gat_sh_*: shared input row, DPP row
     broadcasts, 16-lane reduce-scatter) == the same layer on the transform-then-aggregate kernels == the unfused

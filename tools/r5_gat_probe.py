@@ -18,15 +18,17 @@ def ev(fn, reps=7):
         a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return sorted(ts)[len(ts) // 2]
 conv = layers.FusedGATConv(64, 41, heads=8, concat=False, dropout_rate=0.6).to(dev); conv.train()
+conv0 = layers.FusedGATConv(64, 41, heads=8, concat=False, dropout_rate=0.0).to(dev); conv0.train()
 xf = torch.randn(n, 602, device=dev); yl = torch.randint(0, 41, (n,), device=dev); tidx = torch.arange(0, n, 3, device=dev)
-for waves in (0, 4, 0, 4):
-    eng.set_option("gat_sh_waves", waves)
+for waves, zlds, pf in ((0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 0, 0), (0, 1, 0), (0, 1, 1)):
+    eng.set_option("gat_sh_waves", waves); eng.set_option("gat_sh_zlds", zlds); eng.set_option("gat_sh_prefetch", pf)
     f = ev(lambda: conv(x.detach(), ei, n)); fb = ev(lambda: conv(x, ei, n).sum().backward())
+    fb0 = ev(lambda: conv0(x, ei, n).sum().backward())
     torch.manual_seed(0)
     net = layers.GATModel(602, 8, 41, 8, 0.6, 2, fused=True).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=0.005, weight_decay=5e-4)
     def step():
         net.train(); opt.zero_grad(set_to_none=True)
         F.cross_entropy(net(xf, ei, n)[tidx], yl[tidx]).backward(); opt.step()
-    print(f"gat_sh_waves={waves}: output layer fwd {f:.2f} ms, fwd+bwd {fb:.2f} ms; 2-layer GAT step {ev(step, 5):.2f} ms", flush=True)
-eng.set_option("gat_sh_waves", 0)
+    print(f"gat_sh_waves={waves} gat_sh_zlds={zlds} gat_sh_prefetch={pf}: output layer fwd {f:.2f} ms, fwd+bwd {fb:.2f} ms (no dropout: {fb0:.2f}); 2-layer GAT step {ev(step, 5):.2f} ms", flush=True)
+eng.set_option("gat_sh_waves", 0); eng.set_option("gat_sh_zlds", 0); eng.set_option("gat_sh_prefetch", 0)
