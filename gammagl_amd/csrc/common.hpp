@@ -112,6 +112,7 @@ struct Options {
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
   // the head-mean (output-layer) GAT walks, round 5 (Reddit-sized graph, profiles/r5_gat_sh_forms.txt: layer fwd 5.13 -> 4.64 ms,
   // fwd + bwd 20.9 -> 18.6 ms, 2-layer step 32.0 -> 29.6 ms):
+  int64_t gat_sh_glds = 0;        // destination walk of the backward: the row's G in per-lane LDS slots too (A/B)
   int64_t gat_sh_prefetch = 1;    // forward / destination walks request the next step's ids before this step's gathers
   int64_t gat_sh_zlds = 1;        // source walk of the backward: the row's z_j in per-lane LDS slots instead of 32 registers (140 -> 125:
                                   // 4 wavefronts per SIMD without spills) + the same id prefetch

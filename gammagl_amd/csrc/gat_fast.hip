@@ -619,7 +619,9 @@ __global__ __launch_bounds__(kBlock) void gat_sh_fwd_final_kernel(const int32_t 
 }
 
 // destination walk of the backward: ger[i,h] = sum_p de_p with <G_i[h,:], x_j> from the row's G in registers
-template <bool DROP, bool PF = false>
+// GLDS (option gat_sh_glds, A/B): the row's G (8 heads x this lane's 4 columns, dot-product operands only) in per-lane LDS slots
+// like gat_sh_bwd_src's z_j
+template <bool DROP, bool PF = false, bool GLDS = false>
 __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ row_order,
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el,
@@ -627,10 +629,13 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
     float *__restrict__ ger, float *__restrict__ pger, const int64_t *__restrict__ rng, const ShDims d) {
   GGL_SH_PROLOGUE();
   const int64_t F = d.F;
-  float4 g[kShH];
+  __shared__ float4 gs_lds[GLDS ? kShH : 1][GLDS ? kBlock : 1];
+  float4 g[GLDS ? 1 : kShH];
 #pragma unroll
-  for (int q = 0; q < kShH; ++q)
-    g[q] = act ? *reinterpret_cast<const float4 *>(G + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < kShH; ++q) {
+    const float4 gq = act ? *reinterpret_cast<const float4 *>(G + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (GLDS) gs_lds[q][threadIdx.x] = gq; else g[q] = gq;
+  }
   const float4 st = *reinterpret_cast<const float4 *>(stats + (it.row * kShH + h) * 4);  // {er, m, rinv, dot}
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
   float gs = 0.0f;
@@ -654,10 +659,12 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {  // pair of edges (2 pr, 2 pr + 1): 16 dots -> one per weight lane
       float v[16];
+      if (GLDS) asm volatile("" ::: "memory");   // (re-read every step: hoisted, the slots would be registers again)
 #pragma unroll
       for (int q = 0; q < kShH; ++q) {
-        v[q] = dot4(g[q], xv[2 * pr]);
-        v[8 + q] = dot4(g[q], xv[2 * pr + 1]);
+        const float4 gq = GLDS ? gs_lds[q][threadIdx.x] : g[q];
+        v[q] = dot4(gq, xv[2 * pr]);
+        v[8 + q] = dot4(gq, xv[2 * pr + 1]);
       }
       float da = reduce_scatter16(v, li);
       const float raw = (pr ? s1 : s0) + st.x;
@@ -1035,7 +1042,14 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? plan->row_order : nullptr;
     const bool pf = options().gat_sh_prefetch != 0;
-    if (d.drop_thresh && pf)
+    if (pf && options().gat_sh_glds != 0) {
+      if (d.drop_thresh)
+        GGL_LAUNCH((gat_sh_bwd_dst_kernel<true, true, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                   plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+      else
+        GGL_LAUNCH((gat_sh_bwd_dst_kernel<false, true, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                   plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+    } else if (d.drop_thresh && pf)
       GGL_LAUNCH((gat_sh_bwd_dst_kernel<true, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
                  plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
     else if (d.drop_thresh)

@@ -20,8 +20,8 @@ def ev(fn, reps=7):
 conv = layers.FusedGATConv(64, 41, heads=8, concat=False, dropout_rate=0.6).to(dev); conv.train()
 conv0 = layers.FusedGATConv(64, 41, heads=8, concat=False, dropout_rate=0.0).to(dev); conv0.train()
 xf = torch.randn(n, 602, device=dev); yl = torch.randint(0, 41, (n,), device=dev); tidx = torch.arange(0, n, 3, device=dev)
-for waves, zlds, pf in ((0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 0, 0), (0, 1, 0), (0, 1, 1)):
-    eng.set_option("gat_sh_waves", waves); eng.set_option("gat_sh_zlds", zlds); eng.set_option("gat_sh_prefetch", pf)
+for waves, zlds, pf, glds in ((0, 1, 1, 0), (0, 1, 1, 1), (0, 1, 1, 0), (0, 1, 1, 1)):
+    eng.set_option("gat_sh_waves", waves); eng.set_option("gat_sh_zlds", zlds); eng.set_option("gat_sh_prefetch", pf); eng.set_option("gat_sh_glds", glds)
     f = ev(lambda: conv(x.detach(), ei, n)); fb = ev(lambda: conv(x, ei, n).sum().backward())
     fb0 = ev(lambda: conv0(x, ei, n).sum().backward())
     torch.manual_seed(0)
@@ -30,5 +30,5 @@ for waves, zlds, pf in ((0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 0, 0), (0, 1, 0), (
     def step():
         net.train(); opt.zero_grad(set_to_none=True)
         F.cross_entropy(net(xf, ei, n)[tidx], yl[tidx]).backward(); opt.step()
-    print(f"gat_sh_waves={waves} gat_sh_zlds={zlds} gat_sh_prefetch={pf}: output layer fwd {f:.2f} ms, fwd+bwd {fb:.2f} ms (no dropout: {fb0:.2f}); 2-layer GAT step {ev(step, 5):.2f} ms", flush=True)
-eng.set_option("gat_sh_waves", 0); eng.set_option("gat_sh_zlds", 0); eng.set_option("gat_sh_prefetch", 0)
+    print(f"gat_sh_waves={waves} gat_sh_zlds={zlds} gat_sh_prefetch={pf} gat_sh_glds={glds}: output layer fwd {f:.2f} ms, fwd+bwd {fb:.2f} ms (no dropout: {fb0:.2f}); 2-layer GAT step {ev(step, 5):.2f} ms", flush=True)
+eng.set_option("gat_sh_waves", 0); eng.set_option("gat_sh_zlds", 0); eng.set_option("gat_sh_prefetch", 1); eng.set_option("gat_sh_zlds", 1); eng.set_option("gat_sh_glds", 0)
