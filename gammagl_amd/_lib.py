@@ -102,6 +102,7 @@ SIGNATURES = {
     "ggl_gat_sh_supported": (c_int, [c_int64, c_int64, c_int64]),
     "ggl_gat_sh_partial_bytes": (c_size_t, [c_int64, c_int64]),
     "ggl_gat_sh_fwd": (c_int, [_P, _V, _V, _V, _V, c_int64, c_float, c_float, _V, _V, _V, _V, _V]),
+    "ggl_gat_sh_stats": (c_int, [_V, _V, _V, _V, _V, c_int64, c_int64, _V, _V]),
     "ggl_gat_sh_bwd": (c_int, [_P, _V, _P, _V, _V, _V, _V, c_int64, _V, _V, _V, _V, c_int64, c_float, c_float, _V,
                                _V, _V, _V, _V]),
     "ggl_sample_count": (c_int, [_V, _V, c_int64, c_int64, c_int64, c_int, _V, _V]),

@@ -31,6 +31,10 @@ extern "C" int ggl_gat_sh_fwd(const ggl_segplan_t *, const int32_t *, const floa
                               int64_t, float, float, int64_t *, float *, float *, float *, void *) {
   return no_gpu();
 }
+extern "C" int ggl_gat_sh_stats(const float *, const float *, const float *, const float *, const float *, int64_t, int64_t,
+                                float *, void *) {
+  return no_gpu();
+}
 extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *, const int32_t *, const ggl_segplan_t *, const int32_t *,
                               const int32_t *, const float *, const float *, int64_t, const float *, const float *,
                               const float *, const float *, int64_t, float, float, const int64_t *, float *, float *,

@@ -382,7 +382,8 @@ class FusedGATConv(GATConv):
             # the input per head, transform afterwards (same math, 1408 B -> 256 B gathered per edge on the Reddit GAT)
             y = eng.gat_headmean(edge_index, x, self.w, self.att, self.negative_slope, num_nodes=x.shape[0],
                                  dropout_rate=self.dropout_rate, training=self.training)
-            return y + self.bias if self.bias is not None else y
+            # (bias_add: the bias gradient as the library's two-stage column sum instead of a torch reduce over [N, C])
+            return eng.bias_add(y, self.bias) if self.bias is not None else y
         w = self.w
         pad = (-C) % 4 if C >= 8 else 0
         if pad:  # e.g. 41 classes per head: 44 channels inside the GEMM keep the kernels on 16-byte slices

@@ -1249,7 +1249,10 @@ class Engine:
                 gyh = gy.contiguous() / H
                 gyp = torch.nn.functional.pad(gyh, (0, Cp - C)).contiguous()
                 G = (gyh @ Wst.t()).view(N, H, F).contiguous()               # dL/dA
-                stats = torch.stack([er, rowmax, 1.0 / (den + 1e-16), (G * A).sum(-1)], dim=-1).contiguous()
+                # {er, m, 1 / (den + 1e-16), <G, A>} per (row, head) in one pass (was: product + reduce + reciprocal + stack)
+                stats = torch.empty((N, H, 4), dtype=torch.float32, device=dev)
+                eng._check(eng.lib.ggl_gat_sh_stats(_ptr(er), _ptr(rowmax), _ptr(den), _ptr(G), _ptr(A), N, F, _ptr(stats),
+                                                    eng._stream(dev)))
                 z = torch.nn.functional.pad((x @ W).view(N, H, C), (0, Cp - C)).contiguous()
                 ger = torch.empty((N, H), dtype=torch.float32, device=dev)
                 gel = torch.empty((N, H), dtype=torch.float32, device=dev)

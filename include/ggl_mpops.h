@@ -433,6 +433,10 @@ int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, const ggl_segp
                    const int32_t *posT, const float *el, const float *x, int64_t F, const float *G,
                    const float *stats, const float *z, const float *gy, int64_t Cp, float slope, float p_drop,
                    const int64_t *rng_used, float *ger, float *T, float *gel, void *stream);
+/* (ABI 8) the stats panel ggl_gat_sh_bwd reads, in one pass: stats[i,h,:] = {er, rowmax, 1 / (den + 1e-16), <G[i,h,:], A[i,h,:]>};
+ * er / rowmax / den [N,8], G / A [N,8,F] (F % 4 == 0, 16-byte aligned), stats [N,8,4] */
+int ggl_gat_sh_stats(const float *er, const float *rowmax, const float *den, const float *G, const float *A, int64_t N,
+                     int64_t F, float *stats, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Uniform neighbour sampling — supersedes ops/sparse sample_adj
