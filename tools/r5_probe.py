@@ -56,7 +56,7 @@ for relabel in (("random", "degree") if "hub" in what else ("random",)):
                     eng.set_option(k, opts.get(k, 0))
                 line += f" | fwd+bwd {name} {ev(fb):7.3f}"
             eng.set_option("maxbwd_mask", 128); eng.set_option("maxbwd_arg32", 1)
-            eng.set_option("maxbwd_mask_wlane", 0); eng.set_option("maxbwd_mask_scatter", 0)
+            eng.set_option("maxbwd_mask_wlane", 1); eng.set_option("maxbwd_mask_scatter", 0)
             print(line, flush=True)
             # the mask pre-pass alone, each form
             with torch.no_grad():
@@ -72,7 +72,7 @@ for relabel in (("random", "degree") if "hub" in what else ("random",)):
                                                                   ctypes.c_void_p(tpp.data_ptr()) if tpp is not None else None,
                                                                   ctypes.c_void_p(arg.data_ptr()), K, ctypes.c_void_p(mask.data_ptr()), st)))
                     print(f"   mask pre-pass K={K} {name}: {t:7.3f} ms", flush=True)
-                eng.set_option("maxbwd_mask_wlane", 0)
+                eng.set_option("maxbwd_mask_wlane", 1)
             del xk, go, arg, mask
     eng.clear_caches(); del gp, ei, w
     torch.cuda.empty_cache()
