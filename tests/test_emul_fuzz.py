@@ -88,6 +88,15 @@ def test_gspmm_fuzz(oracle, prob):
     run_gspmm_case(engine(), DEV, oracle, prob)
 
 
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(problems(), st.sampled_from([0, 1]))
+def test_gspmm_max_backward_mask_fuzz(oracle, prob, scatter):
+    """the same cases with the max backward forced through the 1-bit winner mask (round 5), records in forward order / scattered"""
+    eng = engine()
+    with pc.option(eng, "maxbwd_mask", 1), pc.option(eng, "maxbwd_mask_scatter", scatter):
+        run_gspmm_case(eng, DEV, oracle, prob)
+
+
 def run_gspmm_case(eng, DEV, oracle, prob):
     N, E, K, chunk, kind, seed = prob
     rng = np.random.default_rng(seed)

@@ -38,6 +38,14 @@ def test_gspmm_fuzz_gpu(target, oracle, prob):
 
 
 @settings(**_cfg)
+@given(F.problems())
+def test_gspmm_max_backward_mask_fuzz_gpu(target, oracle, prob):
+    """the same cases with the max backward forced through the 1-bit winner mask (round 5: v_writelane-assembled records)"""
+    with F.pc.option(target[0], "maxbwd_mask", 1):
+        F.run_gspmm_case(target[0], target[1], oracle, prob)
+
+
+@settings(**_cfg)
 @given(F.gat_problems())
 def test_gat_fused_fuzz_gpu(target, oracle, prob):
     F.run_gat_case(target[0], target[1], oracle, prob)
