@@ -745,7 +745,14 @@ def compact_line(out):
                     obj[key] = _short(obj[key], 40)
         c["config"]["workload"] = _short(c["config"]["workload"], 60)
         line = json.dumps(c, separators=(",", ":"))
-    assert len(line) <= LINE_LIMIT, f"headline line is {len(line)} bytes"
+    # still too long (cannot happen with today's fields): drop optional side figures one by one — never the contract's
+    # fields, and never raise: a line that is a little long is better than no line
+    for sect, key in (("config", "exchange"), ("config", "orderings"), ("config", "norm_both"), ("config", "aggregate_first"),
+                      (None, "secondary")):
+        if len(line) <= LINE_LIMIT:
+            break
+        (c if sect is None else c.get(sect, {})).pop(key, None)
+        line = json.dumps(c, separators=(",", ":"))
     return line
 
 
