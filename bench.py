@@ -767,10 +767,20 @@ def emit(out):
                     json.dump(out, f, indent=1)
     except OSError as ex:
         print(f"bench.py: could not write the detail file: {ex}", file=sys.stderr)
+    def safe(line_of):
+        try:
+            return compact_line(line_of)
+        except Exception as ex:  # noqa: BLE001 — the contract's fields must reach stdout whatever an optional field holds
+            core = {k: line_of.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+            core["config"] = {"workload": _short((line_of.get("config") or {}).get("workload", ""), 200)}
+            core["compact_line_error"] = f"{type(ex).__name__}: {ex}"[:200]
+            return json.dumps(core, separators=(",", ":"))
+
     for sec in out.get("secondary") or []:
         if "metric" in sec:
-            print(compact_line(sec), flush=True)
-    print(compact_line(out), flush=True)
+            print(safe(sec), flush=True)
+    print(safe(out), flush=True)
 
 
 def main():
