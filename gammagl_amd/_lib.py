@@ -15,7 +15,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_hip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "lib", "libggl_mpops_host.so")
 
 GGL_OK, GGL_EINVAL, GGL_EINDEX, GGL_EDTYPE, GGL_EHIP, GGL_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class SegPlanC(ctypes.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "ggl_policy_head_channels": (c_int64, [c_int64, c_int64, c_int64]),
     "ggl_policy_mean_bwd_prescale": (c_int, [c_int64, c_int64]),
     "ggl_policy_gradw_sorted": (c_int, [c_int64, c_int64]),
+    "ggl_policy_maxbwd_form": (c_int, [c_int64, c_int64, c_int64]),
     "ggl_policy_xcd_run_rows": (c_int64, [c_int64, ctypes.c_double]),
     "ggl_policy_row_order": (c_int, [POINTER(c_int64), POINTER(c_int64)]),
     "ggl_calib_stream": (c_int, [_V, _V, c_int64, c_int, _V]),

@@ -105,6 +105,8 @@ struct Options {
   //   K = 256        67.1              53.0                        41.1 / 44.4                           41.7
   int64_t maxbwd_arg32 = 1;        // witnesses from a compact int32 copy (ggl_spmm_max_bwd32) ...
   int64_t maxbwd_mask = 128;       // ... and from this many columns up a 1-bit winner mask instead (0 = never)
+  int64_t maxbwd_mask_ratio = 2;   // ... only where the mask (E x K/8 B) is <= this x the int64 witness matrix and that matrix is not cache-resident
+                                   //     (ggl_policy_maxbwd_form; 0 = no footprint gate: tests force the mask on small graphs with it)
   int64_t maxbwd_mask_wlane = 1;   // ... its forward-order records assembled with v_writelane (inline asm; 0 = selects)
   int64_t maxbwd_mask_cols = 0;    // ... its walk in 64-column blocks like the plain sum's (A/B: loses, the record is re-read per block)
   int64_t maxbwd_mask_scatter = 0; // ... its records scattered to transposed positions instead of kept in forward order (A/B)

@@ -64,6 +64,7 @@ Options &options() {
     t.hop_fused_scans = env_i64("GGL_HOP_FUSED_SCANS", t.hop_fused_scans);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
+    t.maxbwd_mask_ratio = env_i64("GGL_MAXBWD_MASK_RATIO", t.maxbwd_mask_ratio);
     t.maxbwd_mask_scatter = env_i64("GGL_MAXBWD_MASK_SCATTER", t.maxbwd_mask_scatter);
     t.maxbwd_mask_wlane = env_i64("GGL_MAXBWD_MASK_WLANE", t.maxbwd_mask_wlane);
     t.maxbwd_mask_cols = env_i64("GGL_MAXBWD_MASK_COLS", t.maxbwd_mask_cols);
@@ -316,6 +317,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "hop_fused_scans")) o.hop_fused_scans = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
+  else if (!strcmp(name, "maxbwd_mask_ratio")) o.maxbwd_mask_ratio = value;
   else if (!strcmp(name, "maxbwd_mask_scatter")) o.maxbwd_mask_scatter = value;
   else if (!strcmp(name, "maxbwd_mask_wlane")) o.maxbwd_mask_wlane = value;
   else if (!strcmp(name, "maxbwd_mask_cols")) o.maxbwd_mask_cols = value;
@@ -350,6 +352,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "hop_fused_scans")) return o.hop_fused_scans;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
+  if (!strcmp(name, "maxbwd_mask_ratio")) return o.maxbwd_mask_ratio;
   if (!strcmp(name, "maxbwd_mask_scatter")) return o.maxbwd_mask_scatter;
   if (!strcmp(name, "maxbwd_mask_wlane")) return o.maxbwd_mask_wlane;
   if (!strcmp(name, "maxbwd_mask_cols")) return o.maxbwd_mask_cols;

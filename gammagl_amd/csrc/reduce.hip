@@ -1380,14 +1380,19 @@ __global__ __launch_bounds__(kBlock) void max_mask_kernel(const int64_t *__restr
 // per edge at K = 256 where this costs 12.  A/B: option maxbwd_mask_wlane.
 __device__ __forceinline__ void put_lane4(int lane, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t &r0, uint32_t &r1,
                                           uint32_t &r2, uint32_t &r3) {
-  asm volatile("s_mov_b32 m0, %4\n\ts_nop 1\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
-               "v_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0"
-               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)
-               : "s"(lane), "s"(x0), "s"(x1), "s"(x2), "s"(x3));   // (M0 is reserved: nothing else in this kernel reads it)
+  // M0 is a reserved register the compiler may hold a live value in (LDS-direct, movrel, sendmsg lowering) and that cannot be
+  // named in a clobber list without a "may lead to undefined behaviour" diagnostic: saved and restored around the writes
+  uint32_t keep;
+  asm volatile("s_mov_b32 %4, m0\n\ts_mov_b32 m0, %5\n\ts_nop 1\n\tv_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\t"
+               "v_writelane_b32 %2, %8, m0\n\tv_writelane_b32 %3, %9, m0\n\ts_mov_b32 m0, %4"
+               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=&s"(keep)
+               : "s"(lane), "s"(x0), "s"(x1), "s"(x2), "s"(x3));
 }
 __device__ __forceinline__ void put_lane2(int lane, uint32_t x0, uint32_t x1, uint32_t &r0, uint32_t &r1) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
-               : "+v"(r0), "+v"(r1)
+  uint32_t keep;
+  asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %3\n\ts_nop 1\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
+               "s_mov_b32 m0, %2"
+               : "+v"(r0), "+v"(r1), "=&s"(keep)
                : "s"(lane), "s"(x0), "s"(x1));
 }
 #endif
@@ -1510,6 +1515,22 @@ extern "C" int64_t ggl_spmm_max_mask_words(int64_t K, int forward_order) {
 }
 extern "C" size_t ggl_spmm_max_mask_bytes(int64_t E, int64_t K) {     // (room for either form)
   return (size_t)(E > 0 ? E : 0) * (size_t)mask_words_seq(K) * sizeof(uint32_t);
+}
+
+// Which form the gspmm(max) backward takes (include/ggl_mpops.h): 2 = 1-bit winner mask, 1 = int32 witness copy, 0 = the
+// int64 witnesses as they are.  The mask is a TRANSIENT of E x mask_words_seq(K) x 4 bytes (K = 602: 96 B per edge): it is
+// taken where it is cheaper than what it replaces — K >= maxbwd_mask, the [N_dst, K] witness matrix too large to stay
+// cache-resident (>= 256 MiB as int32: the Infinity Cache's size), and the mask no larger than maxbwd_mask_ratio x the int64
+// witness matrix [N_dst, K] itself (products-sized K = 256: 4.0 GB mask vs 5.0 GB witnesses -> mask; Reddit-sized K = 256:
+// 3.7 GB mask vs 0.48 GB witnesses, which the caches hold -> int32 copy).
+extern "C" int ggl_policy_maxbwd_form(int64_t E, int64_t N_dst, int64_t K) {
+  const auto &o = options();
+  if (o.maxbwd_mask > 0 && K >= o.maxbwd_mask && E > 0 && N_dst > 0) {
+    const double mask_b = (double)E * (double)mask_words_seq(K) * 4.0, wit_b = (double)N_dst * (double)K * 8.0;
+    const bool resident = (double)N_dst * (double)K * 4.0 < 256.0 * 1048576.0;
+    if (o.maxbwd_mask_ratio <= 0 || (!resident && mask_b <= (double)o.maxbwd_mask_ratio * wit_b)) return 2;
+  }
+  return o.maxbwd_arg32 != 0 ? 1 : 0;
 }
 
 extern "C" int ggl_spmm_max_mask(const ggl_segplan_t *planF, const int32_t *colF, const int32_t *tpos,

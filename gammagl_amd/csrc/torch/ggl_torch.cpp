@@ -65,7 +65,7 @@ using torch::autograd::variable_list;
   X(ggl_policy_chunk) X(ggl_policy_spmm_width) X(ggl_policy_head_channels) X(ggl_policy_mean_bwd_prescale)            \
   X(ggl_policy_gradw_sorted) X(ggl_policy_xcd_run_rows) X(ggl_policy_row_order)                                     \
   X(ggl_spmm_max_mask_bytes) X(ggl_spmm_max_mask) X(ggl_spmm_max_bwd_mask) X(ggl_invert_perm) X(ggl_get_option)      \
-  X(ggl_spmm_max_bwd32)
+  X(ggl_spmm_max_bwd32) X(ggl_policy_maxbwd_form)
 
 struct Api {
   void *handle = nullptr;
@@ -567,18 +567,26 @@ static std::pair<Tensor, Tensor> spmm_fwd(SpOp op, GraphPlan &gp, const SegPlan 
       }
       break;
     case SpOp::MaxBwd: {
-      const int64_t mk = a.ggl_get_option("maxbwd_mask");
-      if (tpos.defined() && mk > 0 && K >= mk) {
+      // the form is the library's decision (ggl_policy_maxbwd_form: the winner mask only where its E x K/8-byte transient
+      // pays); `tpos` is defined iff the caller found the mask form chosen.  An allocation failure falls back to the int32 copy.
+      Tensor mask;
+      if (tpos.defined()) {
+        try {
+          mask = at::empty({static_cast<int64_t>(a.ggl_spmm_max_mask_bytes(p.E, K) / 4) + 4}, x.options().dtype(at::kInt));
+        } catch (const c10::Error &) {
+          mask = Tensor();
+        }
+      }
+      if (mask.defined()) {
         // a 1-bit winner mask built in destination order; records in forward order, read at posT[t] (ops.py _spmm_fwd) —
         // `tpos` here IS posT unless the A/B knob maxbwd_mask_scatter asks for records scattered to transposed positions
         const bool scatter = a.ggl_get_option("maxbwd_mask_scatter") != 0;
-        Tensor mask = at::empty({static_cast<int64_t>(a.ggl_spmm_max_mask_bytes(p.E, K) / 4) + 4}, x.options().dtype(at::kInt));
         ggl_segplan_t fs = gp.fwd->c(Tensor());
         check(a, a.ggl_spmm_max_mask(&fs, gp.col.data_ptr<int32_t>(), scatter ? tpos.data_ptr<int32_t>() : nullptr,
                                      aux.data_ptr<int64_t>(), K, reinterpret_cast<uint32_t *>(mask.data_ptr<int32_t>()), st));
         check(a, a.ggl_spmm_max_bwd_mask(&cs, c, wp, by_pos, xp, reinterpret_cast<const uint32_t *>(mask.data_ptr<int32_t>()),
                                          scatter ? nullptr : tpos.data_ptr<int32_t>(), K, op_, st));
-      } else if (a.ggl_get_option("maxbwd_arg32") != 0) {   // witnesses from a compact int32 copy (one [N, K] pass)
+      } else if (tpos.defined() || a.ggl_get_option("maxbwd_arg32") != 0) {   // witnesses from a compact int32 copy (one [N, K] pass)
         Tensor aux32 = aux.to(at::kInt);
         check(a, a.ggl_spmm_max_bwd32(&cs, c, wp, by_pos, xp, aux32.data_ptr<int32_t>(), K, op_, st));
       } else {
@@ -769,7 +777,9 @@ static Tensor spmm_max_backward_kernel(const Tensor &index, const c10::optional<
   c10::OptionalDeviceGuard guard(g.device());
   auto gp = bwd_plan(index, g.size(0));
   Tensor tpos;
-  if (api_for(g.device()).ggl_get_option("maxbwd_mask") > 0) {
+  const int64_t Kw = g.dim() >= 2 ? g.numel() / std::max<int64_t>(g.size(0), 1) : 1;
+  // (the inverse-permutation passes and the cached int32[E] only where the mask form is the one chosen for this K)
+  if (api_for(g.device()).ggl_policy_maxbwd_form(gp->E, g.size(0), Kw) == 2) {
     if (api_for(g.device()).ggl_get_option("maxbwd_mask_scatter") != 0) {
       gp->need_tpos(index.contiguous());
       tpos = gp->tpos;

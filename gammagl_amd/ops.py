@@ -723,11 +723,19 @@ class Engine:
                 self._check(L.ggl_spmm_mean_bwd(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
                                                 _ptr(aux), K, _ptr(out), st))
         elif op == "max_bwd":
-            mk = int(L.ggl_get_option(b"maxbwd_mask"))
-            if gp is not None and mk > 0 and K >= mk:
+            # the form is the library's decision (ggl_policy_maxbwd_form): the winner mask is an E x K/8-byte transient, taken only
+            # where it is smaller than a multiple of the witness matrix it replaces and that matrix is not cache-resident
+            form = int(L.ggl_policy_maxbwd_form(plan.E, int(aux.shape[0]), K)) if gp is not None else (
+                1 if int(L.ggl_get_option(b"maxbwd_arg32")) else 0)
+            mask = None
+            if form == 2:
+                try:
+                    mask = torch.empty(int(L.ggl_spmm_max_mask_bytes(plan.E, K)) // 4 + 4, dtype=torch.int32, device=dev)
+                except torch.OutOfMemoryError:
+                    form = 1                    # no room for the transient: the int32 witness copy ([N, K] x 4 bytes)
+            if form == 2:
                 # a 1-bit winner mask built in DESTINATION order (the witness row is wave-uniform there), read in the
                 # transposed walk's own order: K / 8 bytes per edge instead of 8K (include/ggl_mpops.h)
-                mask = torch.empty(int(L.ggl_spmm_max_mask_bytes(plan.E, K)) // 4 + 4, dtype=torch.int32, device=dev)
                 fs = gp.fwd.c_struct(None)
                 # records in forward order (coalesced writes; the walk reads record posT[t]) unless the A/B knob asks for
                 # the scatter to transposed positions (maxbwd_mask_scatter: streamed reads, slower writes)
@@ -736,7 +744,7 @@ class Engine:
                                                 _ptr(mask), st))
                 self._check(L.ggl_spmm_max_bwd_mask(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x), _ptr(mask),
                                                     None if scatter else _ptr(gp.posT), K, _ptr(out), st))
-            elif int(L.ggl_get_option(b"maxbwd_arg32")):   # A/B knob: witnesses from a compact int32 copy (one [N, K] pass)
+            elif form == 1:   # witnesses from a compact int32 copy (one [N, K] pass)
                 aux32 = aux.to(torch.int32)
                 self._check(L.ggl_spmm_max_bwd32(ctypes.byref(cs), _ptr(col), _ptr(w), w_by_pos, _ptr(x),
                                                  _ptr(aux32), K, _ptr(out), st))

@@ -94,3 +94,66 @@ def gat_errors_vs_truth(truth, got):
         floor = float(t64.abs().mean()) if name in ("g_el", "g_er") else 0.0
         out[name] = report(a.double().to(t64.device), t64, tol=1.0, floor_min=floor)["max_rel_err"]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The whole GATConv layer / GATModel restated (round 6): what the head-averaging output layer (concat=False) of
+# config 3 is checked against — the path FusedGATConv dispatches to ggl_gat_sh_* had only met the builder's own kernels.
+# ---------------------------------------------------------------------------------------------------------------
+def _torch_segment_ops(dtype):
+    """(segment_max, segment_sum) as torch scatters in `dtype` on the tensors' device: the float64 ground truth's ops."""
+
+    def seg_max(s, ids, n):
+        m = torch.full((n, *s.shape[1:]), -float("inf"), dtype=dtype, device=s.device)
+        return m.scatter_reduce(0, ids.view(-1, *([1] * (s.dim() - 1))).expand_as(s), s, reduce="amax", include_self=True)
+
+    def seg_sum(v, ids, n):
+        return torch.zeros((n, *v.shape[1:]), dtype=dtype, device=v.device).index_add_(0, ids, v)
+
+    return seg_max, seg_sum
+
+
+def gat_conv_composed(x, W, att, bias, ei, n, heads, out_channels, concat, slope=0.2, seg=None):
+    """GATConv.forward exactly as gat_conv.py:98-122 writes it (attention dropout off): matmul, reshape [N, H, C], gather
+    source and destination rows, concat, `(feat * att).sum(-1)`, LeakyReLU, segment_softmax (softmax.py:29-35: segment max,
+    exp, segment sum, / (den + 1e-16)), message = x[src] * alpha, segment sum into the destinations, then concat heads
+    (:112-113) or `reduce_mean` over them (:115-118) and `+ bias` (:120-121).  `seg` = (segment_max, segment_sum): the
+    reference's compiled c_segment_max / c_segment_sum for the f32 composition; None = torch scatters in x's dtype (the
+    float64 truth).  Differentiable in x, W, att, bias."""
+    seg_max, seg_sum = seg if seg is not None else _torch_segment_ops(x.dtype)
+    src, dst = ei[0], ei[1]
+    z = (x @ W).reshape(-1, heads, out_channels)
+    feat = torch.cat((z[src], z[dst]), dim=-1)
+    e = torch.nn.functional.leaky_relu((feat * att).sum(dim=-1), slope)
+    m = seg_max(e, dst, n)
+    ex = torch.exp(e - m[dst])
+    den = seg_sum(ex, dst, n)
+    alpha = ex / (den[dst] + 1e-16)
+    out = seg_sum(z[src] * alpha.unsqueeze(-1), dst, n)
+    out = out.reshape(-1, heads * out_channels) if concat else out.mean(dim=1)
+    return out + bias if bias is not None else out
+
+
+def gat_model_composed(x, params, ei, n, heads, slope=0.2, seg=None):
+    """GATModel.forward (models/gat.py:65-72) in eval mode (dropout = identity): `params` = [(W, att, bias), ...] per layer;
+    every layer but the last concatenates its heads and is followed by ELU, the last one averages them (:49-53;
+    a one-layer model's only layer is built by the `i == 0` branch: concat)."""
+    L = len(params)
+    for i, (W, att, bias) in enumerate(params):
+        C = int(att.shape[-1]) // 2
+        x = gat_conv_composed(x, W, att, bias, ei, n, heads, C, concat=(i == 0 or i < L - 1), slope=slope, seg=seg)
+        if i < L - 1:
+            x = torch.nn.functional.elu(x)
+    return x
+
+
+def layer_errors_vs_truth(truth, got, names, zero_mean_rows=()):
+    """{name: max row-scale relative error} of a tuple of tensors against float64 truths; `zero_mean_rows` names tensors whose
+    rows can cancel to ~0 as a whole (scale floor = the tensor's mean magnitude)."""
+    out = {}
+    for name, t64, a in zip(names, truth, got):
+        t2 = t64.reshape(t64.shape[0], -1) if t64.dim() > 1 else t64.reshape(1, -1)
+        a2 = a.double().to(t64.device).reshape(t2.shape)
+        floor = float(t64.abs().mean()) if name in zero_mean_rows else 0.0
+        out[name] = report(a2, t2, tol=1.0, floor_min=floor)["max_rel_err"]
+    return out

@@ -333,6 +333,38 @@ def layer_cases():
     er = (xg.detach() * att[:, :, C:]).sum(-1)
     out.update(gat_ei=npy(ei), gat_x=npy(xg), gat_att=npy(att), gat_el=npy(el), gat_er=npy(er),
                gat_alpha=npy(alpha), gat_y=npy(yg), gat_g=npy(gg), gat_gx=npy(xg.grad))
+    # the head-averaging output layer (gat_conv.py:98-122 with concat=False: reduce_mean over heads :115-118, + bias) and the
+    # two-layer GATModel (models/gat.py:36-72, eval mode) — composed by oracle/parity.py from the REFERENCE's segment ops
+    # (round 6: the path FusedGATConv sends to ggl_gat_sh_* had no reference-made vector)
+    sys.path.insert(0, REPO)
+    from oracle import parity
+
+    seg = (R.unsorted_segment_max, R.unsorted_segment_sum)
+    H, Fin, C = 8, 16, 5
+    xm = torch.tensor(rng.standard_normal((N, Fin)), dtype=torch.float32, requires_grad=True)
+    Wm = torch.tensor(rng.standard_normal((Fin, H * C)) * 0.4, dtype=torch.float32, requires_grad=True)
+    am = torch.tensor(rng.standard_normal((1, H, 2 * C)) * 0.5, dtype=torch.float32, requires_grad=True)
+    bm = torch.tensor(rng.standard_normal((C,)) * 0.1, dtype=torch.float32, requires_grad=True)
+    ym = parity.gat_conv_composed(xm, Wm, am, bm, ei, N, H, C, concat=False, slope=0.2, seg=seg)
+    gm = torch.tensor(rng.standard_normal((N, C)), dtype=torch.float32)
+    ym.backward(gm)
+    out.update(gatm_x=npy(xm), gatm_W=npy(Wm), gatm_att=npy(am), gatm_b=npy(bm), gatm_y=npy(ym), gatm_g=npy(gm),
+               gatm_gx=npy(xm.grad), gatm_gW=npy(Wm.grad), gatm_gatt=npy(am.grad), gatm_gb=npy(bm.grad))
+    Fin2, Hd, NC = 12, 4, 7          # GATModel(12, 4, 7, heads=8, num_layers=2): 12 -> 8 x 4 (concat, ELU) -> mean of 8 x 7
+    x2 = torch.tensor(rng.standard_normal((N, Fin2)), dtype=torch.float32)
+    params = [(torch.tensor(rng.standard_normal((Fin2, H * Hd)) * 0.4, dtype=torch.float32, requires_grad=True),
+               torch.tensor(rng.standard_normal((1, H, 2 * Hd)) * 0.5, dtype=torch.float32, requires_grad=True),
+               torch.tensor(rng.standard_normal((H * Hd,)) * 0.1, dtype=torch.float32, requires_grad=True)),
+              (torch.tensor(rng.standard_normal((H * Hd, H * NC)) * 0.3, dtype=torch.float32, requires_grad=True),
+               torch.tensor(rng.standard_normal((1, H, 2 * NC)) * 0.5, dtype=torch.float32, requires_grad=True),
+               torch.tensor(rng.standard_normal((NC,)) * 0.1, dtype=torch.float32, requires_grad=True))]
+    y2m = parity.gat_model_composed(x2, params, ei, N, H, slope=0.2, seg=seg)
+    g2m = torch.tensor(rng.standard_normal((N, NC)), dtype=torch.float32)
+    y2m.backward(g2m)
+    out.update(gatmodel_x=npy(x2), gatmodel_y=npy(y2m), gatmodel_g=npy(g2m))
+    for li, (Wl, al, bl) in enumerate(params):
+        out.update({f"gatmodel_W{li}": npy(Wl), f"gatmodel_att{li}": npy(al), f"gatmodel_b{li}": npy(bl),
+                    f"gatmodel_gW{li}": npy(Wl.grad), f"gatmodel_gatt{li}": npy(al.grad), f"gatmodel_gb{li}": npy(bl.grad)})
     np.savez_compressed(os.path.join(HERE, "layers.npz"), **out)
     print("layers.npz:", len(out), "arrays")
 

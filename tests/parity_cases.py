@@ -190,6 +190,59 @@ def check_layers_golden(eng, dev, golden):
     yg.backward(to_t(g["gat_g"], dev))
     np.testing.assert_allclose(to_np(yg), g["gat_y"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(to_np(xg.grad), g["gat_gx"], rtol=2e-4, atol=2e-5)
+    check_headmean_golden(eng, dev, golden)
+
+
+def _row_scale_err(got, want):
+    """max |got - want| / max(|want|, the row's largest |want|): oracle/parity.py's criterion on numpy arrays."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    g2 = got.reshape(got.shape[0], -1) if got.ndim > 1 else got.reshape(1, -1)
+    w2 = want.reshape(g2.shape)
+    floor = np.abs(w2).max(axis=1, keepdims=True).clip(min=1e-30)
+    return float((np.abs(g2 - w2) / np.maximum(np.abs(w2), floor)).max())
+
+
+def check_headmean_golden(eng, dev, golden, tol=1e-5, gtol=2e-5):
+    """The head-averaging output layer (gat_conv.py:98-122 with concat=False) and the two-layer GATModel (models/gat.py)
+    through FusedGATConv / GATModel(fused=True) against vectors the REFERENCE's segment ops produced (layers.npz gatm_*,
+    gatmodel_*): on the GPU FusedGATConv(concat=False) runs the ggl_gat_sh_* kernels, on the host build the generic fused path."""
+    import gammagl_amd
+    from gammagl_amd.layers import FusedGATConv, GATModel
+
+    g = golden["layers"]
+    ei = to_t(g["gat_ei"], dev)
+    N = int(g["gatm_x"].shape[0])
+    H = int(g["gatm_att"].shape[1])
+    C = int(g["gatm_att"].shape[2]) // 2
+    prev = gammagl_amd._engine
+    gammagl_amd._engine = eng            # the layers resolve their engine through the package
+    try:
+        layer = FusedGATConv(int(g["gatm_x"].shape[1]), C, heads=H, concat=False).to(dev)
+        with torch.no_grad():
+            layer.w.copy_(to_t(g["gatm_W"], dev)), layer.att.copy_(to_t(g["gatm_att"], dev)), layer.bias.copy_(to_t(g["gatm_b"], dev))
+        x = to_t(g["gatm_x"], dev).requires_grad_(True)
+        y = layer(x, ei, N)
+        y.backward(to_t(g["gatm_g"], dev))
+        assert _row_scale_err(to_np(y), g["gatm_y"]) <= tol
+        for got, key in ((x.grad, "gx"), (layer.w.grad, "gW"), (layer.att.grad, "gatt"), (layer.bias.grad, "gb")):
+            err = _row_scale_err(to_np(got), g["gatm_" + key])
+            assert err <= gtol, (key, err)
+        Hd = int(g["gatmodel_att0"].shape[2]) // 2
+        NC = int(g["gatmodel_att1"].shape[2]) // 2
+        model = GATModel(int(g["gatmodel_x"].shape[1]), Hd, NC, heads=H, drop_rate=0.0, num_layers=2, fused=True).to(dev).eval()
+        with torch.no_grad():
+            for li, conv in enumerate(model.gat_list):
+                conv.w.copy_(to_t(g[f"gatmodel_W{li}"], dev)), conv.att.copy_(to_t(g[f"gatmodel_att{li}"], dev))
+                conv.bias.copy_(to_t(g[f"gatmodel_b{li}"], dev))
+        y2 = model(to_t(g["gatmodel_x"], dev), ei, N)
+        y2.backward(to_t(g["gatmodel_g"], dev))
+        assert _row_scale_err(to_np(y2), g["gatmodel_y"]) <= tol
+        for li, conv in enumerate(model.gat_list):
+            for got, key in ((conv.w.grad, "gW"), (conv.att.grad, "gatt"), (conv.bias.grad, "gb")):
+                err = _row_scale_err(to_np(got), g[f"gatmodel_{key}{li}"])
+                assert err <= gtol, (li, key, err)
+    finally:
+        gammagl_amd._engine = prev
 
 
 # --------------------------------------------------------------------------------------------------
@@ -2017,6 +2070,7 @@ def check_max_backward_forms(eng, dev, oracle, chunk=64):
                                    ("winner mask, forward order", {"maxbwd_mask": 1, "maxbwd_arg32": 0}),
                                    ("winner mask, scattered", {"maxbwd_mask": 1, "maxbwd_arg32": 0, "maxbwd_mask_scatter": 1})):
                     with option(eng, "maxbwd_mask", opts["maxbwd_mask"]), option(eng, "maxbwd_arg32", opts["maxbwd_arg32"]), \
+                            option(eng, "maxbwd_mask_ratio", 0), \
                             option(eng, "maxbwd_mask_scatter", opts.get("maxbwd_mask_scatter", 0)):
                         for call in range(2):       # (second call: weights streamed from their sorted copy)
                             xt = to_t(xs, dev).requires_grad_(True)
@@ -2025,7 +2079,7 @@ def check_max_backward_forms(eng, dev, oracle, chunk=64):
                             assert_same(got[one_piece], want[one_piece], f"max backward, {name}, K{K} shuffle={shuffle} call {call}")
                             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4)
                 # no weights
-                with option(eng, "maxbwd_mask", 1):
+                with option(eng, "maxbwd_mask", 1), option(eng, "maxbwd_mask_ratio", 0):    # (ratio 0: no footprint gate)
                     xt = to_t(xs, dev).requires_grad_(True)
                     eng.c_spmm_max(it, None, xt).backward(to_t(go, dev))
                     ones = np.ones(E, np.float32)

@@ -41,7 +41,7 @@ def test_gspmm_fuzz_gpu(target, oracle, prob):
 @given(F.problems())
 def test_gspmm_max_backward_mask_fuzz_gpu(target, oracle, prob):
     """the same cases with the max backward forced through the 1-bit winner mask (round 5: v_writelane-assembled records)"""
-    with F.pc.option(target[0], "maxbwd_mask", 1):
+    with F.pc.option(target[0], "maxbwd_mask", 1), F.pc.option(target[0], "maxbwd_mask_ratio", 0):
         F.run_gspmm_case(target[0], target[1], oracle, prob)
 
 

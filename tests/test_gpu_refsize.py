@@ -265,3 +265,191 @@ def test_gat_gradients_against_an_fp64_ground_truth(eng, dev, ref):
         for name in e_hip:
             print(f"GAT {H}x{C} {name}: err vs fp64 truth — HIP {e_hip[name]:.3e}, reference f32 composition {e_ref[name]:.3e}")
             assert e_hip[name] <= max(1e-5, 2.0 * e_ref[name]), (H, C, name, e_hip, e_ref)
+
+
+def _host_mem_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    return int(line.split()[1]) / 2**20
+    except OSError:
+        pass
+    return 0.0
+
+
+def _reddit_subgraph(dev, stride):
+    from gammagl_amd.synth import DATASETS, rmat_graph
+
+    n, e, _, _ = DATASETS["reddit"]
+    if torch.cuda.get_device_properties(dev).total_memory < 100 * 2**30:
+        e //= 8
+    return rmat_graph(n, e, seed=0, device=dev)[:, ::stride].contiguous(), n
+
+
+def _ref_seg(ref):
+    return (lambda s, ids, n: ref.c_segment_max(s, ids, n)), (lambda v, ids, n: ref.c_segment_sum(v, ids, n))
+
+
+def test_reddit_size_headmean_output_layer_vs_the_reference_ops(eng, dev, ref):
+    """Row G, the OUTPUT layer of config 3 — FusedGATConv(64, 41, heads=8, concat=False), the path layers.py sends to the
+    ggl_gat_sh_* kernels (aggregate the 64-float input row per head, transform afterwards; 60 % of the Reddit step) — against
+    GATConv.forward as gat_conv.py:98-122 writes it (head mean :115-118, bias :120-121) composed from the reference's own
+    c_segment_max / c_segment_sum under autograd, on every 32nd edge of the Reddit-sized graph: y, gx, gW, gatt, gbias.
+    AND against the same layer in float64: err(HIP) <= max(1e-5, 2 err(reference f32 composition)) for all five.
+    (Rounds 3-5 checked this path only against the builder's other kernels at 2e-4 of the tensor's maximum.)"""
+    from gammagl_amd.layers import FusedGATConv
+    from oracle import parity
+
+    stride = 32 if _host_mem_gb() > 96 else 128      # the composed reference holds ~8 [E, 8, 82] f32 tensors under autograd
+    ei, n = _reddit_subgraph(dev, stride)
+    F, H, C = 64, 8, 41
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(n, F, generator=g, device=dev)
+    W = torch.randn(F, H * C, generator=g, device=dev) * 0.15
+    att = torch.randn(1, H, 2 * C, generator=g, device=dev) * 0.2
+    bias = torch.randn(C, generator=g, device=dev) * 0.1
+    go = torch.randn(n, C, generator=g, device=dev)
+    layer = FusedGATConv(F, C, heads=H, concat=False).to(dev)
+    with torch.no_grad():
+        layer.w.copy_(W), layer.att.copy_(att), layer.bias.copy_(bias)
+    assert eng.gat_headmean_supported(H, F, C), "the head-mean path must be the one under test"
+    calls = {"n": 0}
+    orig = eng.gat_headmean
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    eng.gat_headmean = counted
+    try:
+        xa = x.clone().requires_grad_(True)
+        y = layer(xa, ei, n)
+        y.backward(go)
+    finally:
+        eng.gat_headmean = orig
+    assert calls["n"] == 1, "FusedGATConv(concat=False) did not take the gat_sh_* route"
+    hip = (y.detach(), xa.grad, layer.w.grad, layer.att.grad, layer.bias.grad)
+    # the reference's f32 composition (host, one core)
+    xb, Wb, ab, bb = (t.detach().cpu().requires_grad_(True) for t in (x, W, att, bias))
+    yb = parity.gat_conv_composed(xb, Wb, ab, bb, ei.cpu(), n, H, C, concat=False, slope=0.2, seg=_ref_seg(ref))
+    yb.backward(go.cpu())
+    reff = (yb.detach(), xb.grad, Wb.grad, ab.grad, bb.grad)
+    # the float64 truth (GPU, torch scatters)
+    xd, Wd, ad, bd = (t.detach().double().requires_grad_(True) for t in (x, W, att, bias))
+    yd = parity.gat_conv_composed(xd, Wd, ad, bd, ei, n, H, C, concat=False, slope=0.2)
+    yd.backward(go.double())
+    truth = (yd.detach(), xd.grad, Wd.grad, ad.grad, bd.grad)
+    names = ("y", "gx", "gW", "gatt", "gbias")
+    e_hip = parity.layer_errors_vs_truth(truth, hip, names)
+    e_ref = parity.layer_errors_vs_truth(truth, reff, names)
+    for k in names:
+        print(f"head-mean GAT 64 -> 8 x 41 {k}: err vs fp64 truth — HIP {e_hip[k]:.3e}, reference f32 composition {e_ref[k]:.3e}")
+    for k in names:
+        assert e_hip[k] <= max(1e-5, 2.0 * e_ref[k]), (k, e_hip, e_ref)
+    # and f32 against f32, the north_star's figure: 1e-5 of the row's magnitude forward, 2e-5 for the gradients
+    parity.check(hip[0], reff[0], "head-mean GAT forward vs the composed reference ops", tol=1e-5)
+    parity.check(hip[1], reff[1], "head-mean GAT gx", tol=2e-5)
+    for a, b, k in zip(hip[2:], reff[2:], names[2:]):
+        a2, b2 = (t.reshape(t.shape[0], -1) if t.dim() > 1 else t.reshape(1, -1) for t in (a, b))
+        parity.check(a2, b2.to(dev), f"head-mean GAT {k}", tol=2e-5)
+
+
+def test_reddit_size_gat_model_vs_the_reference_ops(eng, dev, ref):
+    """Config 3's MODEL (models/gat.py:36-72: 8 x 8 concat layer, ELU, head-averaging 41-class output layer; eval mode) forward
+    + every parameter gradient on every 64th edge of the Reddit-sized graph: fused HIP layers against the composed reference
+    ops and against float64 — the same figures bench.py's config-3 `parity` object carries."""
+    from gammagl_amd.layers import GATModel
+    from oracle import parity
+
+    stride = 64 if _host_mem_gb() > 96 else 256
+    ei, n = _reddit_subgraph(dev, stride)
+    torch.manual_seed(5)
+    model = GATModel(602, 8, 41, heads=8, drop_rate=0.0, num_layers=2, fused=True).to(dev).eval()
+    with torch.no_grad():
+        for p in model.parameters():       # trained-like magnitudes (the default init's logits are ~0: a flat softmax)
+            p.copy_(torch.randn_like(p) * (0.1 if p.dim() > 1 else 0.05))
+    g = torch.Generator(device=dev).manual_seed(12)
+    x = torch.randn(n, 602, generator=g, device=dev)
+    go = torch.randn(n, 41, generator=g, device=dev)
+    y = model(x, ei, n)
+    y.backward(go)
+    params = [(l.w, l.att, l.bias) for l in model.gat_list]
+    hip = [y.detach()] + [p.grad for tpl in params for p in tpl]
+    names = ["y"] + [f"g{nm}{li}" for li in range(2) for nm in ("W", "att", "b")]
+
+    def run(dtype, device, seg):
+        ps = [tuple(p.detach().to(device=device, dtype=dtype).requires_grad_(True) for p in tpl) for tpl in params]
+        out = parity.gat_model_composed(x.to(device=device, dtype=dtype), ps, ei.to(device), n, 8, slope=0.2, seg=seg)
+        out.backward(go.to(device=device, dtype=dtype))
+        return [out.detach()] + [p.grad for tpl in ps for p in tpl]
+
+    reff = run(torch.float32, "cpu", _ref_seg(ref))
+    truth = run(torch.float64, dev, None)
+    e_hip = parity.layer_errors_vs_truth(truth, hip, names)
+    e_ref = parity.layer_errors_vs_truth(truth, reff, names)
+    for k in names:
+        print(f"GAT model {k}: err vs fp64 truth — HIP {e_hip[k]:.3e}, reference f32 composition {e_ref[k]:.3e}")
+        assert e_hip[k] <= max(1e-5, 2.0 * e_ref[k]), (k, e_hip, e_ref)
+
+
+@pytest.mark.parametrize("K", [16, 64, 256])
+def test_arxiv_size_spmm_mean_backward_vs_the_pinned_oracle(eng, dev, oracle, arxiv, K):
+    """A6's backward at config 2's size (round-5 verdict, weak #6): gx[src] += g[dst] / count[dst] * w[e] in edge order
+    (spmm_mean_cpu.cpp:63-105).  The reference's own loop calls .item() per (edge, column) — minutes at this size — so the
+    checker is the pinned C restatement (oracle/ggl_oracle.c spmm_mean_bwd, bit-checked against the reference's output on
+    the small goldens): the MODE_MEANBWD walk + prescale at K = 16 / 64 / 256, rows in one piece bit-identical."""
+    from oracle import parity
+
+    ei, w, n = arxiv
+    g = torch.Generator(device=dev).manual_seed(300 + K)
+    x = torch.randn(n, K, generator=g, device=dev)
+    go = torch.randn(n, K, generator=g, device=dev)
+    gp = eng.graph_plan(ei, n)
+    a = x.clone().requires_grad_(True)
+    eng.c_spmm_mean(ei, w, a).backward(go)
+    ei_n, w_n = ei.cpu().numpy(), w.cpu().numpy()
+    _, cnt = oracle.spmm_mean_fwd(ei_n, w_n, x.cpu().numpy())
+    want = torch.from_numpy(oracle.spmm_mean_bwd(ei_n, w_n, go.cpu().numpy(), cnt))
+    r = parity.check(a.grad, want, f"spmm_mean backward K={K}", rows_in_one_piece=_one_piece(gp.bwd))
+    print(f"spmm_mean backward K={K}: {r}")
+
+
+@pytest.mark.parametrize("K", [16, 64, 256])
+def test_arxiv_size_segment_mean_backward_vs_the_reference(eng, dev, ref, oracle, arxiv, K):
+    """A2's backward at config 2's size: grad_out[ids] / bincount(ids)[ids] (segment_mean.cpp:44-63) — a gather and one
+    divide per element, no reduction: every element bit-exact, against the reference's own autograd AND the C oracle."""
+    ei, _, n = arxiv
+    E = int(ei.shape[1])
+    g = torch.Generator(device=dev).manual_seed(400 + K)
+    msg = torch.randn(E, K, generator=g, device=dev)
+    go = torch.randn(n, K, generator=g, device=dev)
+    ids = ei[1].contiguous()
+    a = msg.clone().requires_grad_(True)
+    eng.c_segment_mean(a, ids, n).backward(go)
+    b = msg.cpu().requires_grad_(True)
+    ref.c_segment_mean(b, ids.cpu(), n).backward(go.cpu())
+    assert torch.equal(a.grad.cpu(), b.grad), "segment_mean backward differs from the reference's"
+    want = torch.from_numpy(oracle.segment_mean_bwd(go.cpu().numpy(), ids.cpu().numpy(), n))
+    assert torch.equal(a.grad.cpu(), want), "segment_mean backward differs from the C oracle's"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K", [16, 64])
+def test_arxiv_size_16bit_segment_max_vs_the_reference(eng, dev, ref, arxiv, dtype, K):
+    """A3 for the 16-bit storage types at config 2's size: values bit-exact (a maximum has no rounding) and the
+    first-edge-wins argmax witnessed through the reference's own backward; 16-bit values tie OFTEN (2^16 patterns over
+    2.5 M messages), so this is the tie-break's hardest case."""
+    ei, _, n = arxiv
+    E = int(ei.shape[1])
+    g = torch.Generator(device=dev).manual_seed(500 + K)
+    msg = torch.randn(E, K, generator=g, device=dev).to(dtype)
+    go = torch.randn(n, K, generator=g, device=dev).to(dtype)
+    ids = ei[1].contiguous()
+    a = msg.clone().requires_grad_(True)
+    b = msg.cpu().requires_grad_(True)
+    ya, yb = eng.c_segment_max(a, ids, n), ref.c_segment_max(b, ids.cpu(), n)
+    assert torch.equal(ya.detach().cpu().view(torch.int16), yb.detach().view(torch.int16))
+    ya.backward(go)
+    yb.backward(go.cpu())
+    assert torch.equal(a.grad.cpu().view(torch.int16), b.grad.view(torch.int16)), "16-bit segment_max argmax differs"

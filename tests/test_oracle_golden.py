@@ -158,6 +158,26 @@ def test_gat_math_fixture(golden, oracle):
     np.testing.assert_allclose(gx_total, g["gat_gx"], rtol=2e-4, atol=2e-5)
 
 
+def test_gat_headmean_layer_fixture(golden, oracle):
+    """gat_conv.py:98-122 with concat=False (reduce_mean over heads :115-118, + bias): the C oracle's GAT forward / backward
+    composed with the dense parts in numpy, against the vector the reference's own segment ops produced (gatm_*)."""
+    g = golden["layers"]
+    ei, x, W, att, b = g["gat_ei"], g["gatm_x"], g["gatm_W"], g["gatm_att"], g["gatm_b"]
+    H, C = att.shape[1], att.shape[2] // 2
+    z = (x @ W).reshape(-1, H, C)
+    el, er = (z * att[:, :, :C]).sum(-1), (z * att[:, :, C:]).sum(-1)
+    y = oracle.gat_fwd(ei, el, er, z, 0.2).mean(axis=1) + b
+    np.testing.assert_allclose(y, g["gatm_y"], rtol=1e-5, atol=1e-6)
+    go = np.repeat(g["gatm_g"][:, None, :] / np.float32(H), H, axis=1).astype(np.float32)     # d mean / d head
+    gel, ger, gz = oracle.gat_bwd(ei, el, er, z, go, 0.2)
+    gz = gz + gel[:, :, None] * att[:, :, :C] + ger[:, :, None] * att[:, :, C:]
+    np.testing.assert_allclose(x.T @ gz.reshape(x.shape[0], -1), g["gatm_gW"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gz.reshape(x.shape[0], -1) @ W.T, g["gatm_gx"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(g["gatm_g"].sum(0), g["gatm_gb"], rtol=1e-5, atol=1e-6)
+    gatt = np.concatenate([(gel[:, :, None] * z).sum(0), (ger[:, :, None] * z).sum(0)], axis=-1)[None]
+    np.testing.assert_allclose(gatt, g["gatm_gatt"], rtol=2e-4, atol=2e-5)
+
+
 def test_sampler_restatement_against_reference_sample_adj(golden, oracle):
     """oracle.sample_adj_full (the Python restatement the sampler tests check against) vs the reference's own
     c_sample_adj on its deterministic branches (tests/golden/sampler.npz)."""
