@@ -105,8 +105,8 @@ struct Options {
   //   K = 256        67.1              53.0                        41.1 / 44.4                           41.7
   int64_t maxbwd_arg32 = 1;        // witnesses from a compact int32 copy (ggl_spmm_max_bwd32) ...
   int64_t maxbwd_mask = 128;       // ... and from this many columns up a 1-bit winner mask instead (0 = never)
-  int64_t maxbwd_mask_ratio = 2;   // ... only where the mask (E x K/8 B) is <= this x the int64 witness matrix and that matrix is not cache-resident
-                                   //     (ggl_policy_maxbwd_form; 0 = no footprint gate: tests force the mask on small graphs with it)
+  int64_t maxbwd_mask_kmax = 256;  // ... up to this many columns (the mask is an E x K/8-byte transient; K = 602 measured slower AND 12 GiB on the
+                                   //     Reddit-sized graph: ggl_policy_maxbwd_form; 0 = no upper bound: tests force the mask at any width)
   int64_t maxbwd_mask_wlane = 1;   // ... its forward-order records assembled with v_writelane (inline asm; 0 = selects)
   int64_t maxbwd_mask_cols = 0;    // ... its walk in 64-column blocks like the plain sum's (A/B: loses, the record is re-read per block)
   int64_t maxbwd_mask_scatter = 0; // ... its records scattered to transposed positions instead of kept in forward order (A/B)
@@ -114,6 +114,7 @@ struct Options {
   int64_t exact_side_stream = 1;  // ... launched beside the walk over the other rows (0 = in front of it, same stream)
   // the head-mean (output-layer) GAT walks, round 5 (Reddit-sized graph, profiles/r5_gat_sh_forms.txt: layer fwd 5.13 -> 4.64 ms,
   // fwd + bwd 20.9 -> 18.6 ms, 2-layer step 32.0 -> 29.6 ms):
+  int64_t gat_sh_pk = 1;          // backward walks of the head-mean GAT: dots packed over head pairs (v_pk_fma_f32), select-free reduce-scatter (round 6)
   int64_t gat_sh_glds = 0;        // destination walk of the backward: the row's G in per-lane LDS slots too (A/B)
   int64_t gat_sh_prefetch = 1;    // forward / destination walks request the next step's ids before this step's gathers
   int64_t gat_sh_zlds = 1;        // source walk of the backward: the row's z_j in per-lane LDS slots instead of 32 registers (140 -> 125:

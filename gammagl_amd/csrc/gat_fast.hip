@@ -449,6 +449,88 @@ template <int E> __device__ __forceinline__ void sh_accumulate(float wk, const f
 #undef GGL_SH_ACC
 }
 
+// ---- round 6: the 16 dots of an edge pair as PACKED products over head pairs, reduced without per-step selects ----------
+// The walks of the backward take, per pair of edges (A, B) and per lane, 8 heads x 2 edges dot products of the lane's 4
+// columns, then reduce-scatter the 16 partials over the 16 lanes (lane 8e + h ends with the total for edge e, head h).  ISA of
+// round 5's form, per 4-edge step of the source walk: 444 VALU instructions, of which 128 scalar multiply / FMAs for the dots
+// and 60 v_cndmask + 30 DPP / swizzle adds for the two reduce-scatters (each stage selected "my half" / "the other half" of
+// its values per lane) — the kernel is VALU-bound (26 wave-instructions per edge x 114.8 M edges / 614 G wave-instructions per
+// second = 4.9 ms of its 7.5), not latency-bound as round 5 read it.  Now:
+//   * the row's constant operand (z_j of the source walk, G_i of the destination walk) is kept per lane as head PAIRS
+//     P[c][qp] = (R[2 qp].c, R[2 qp + 1].c), so a dot step is one v_pk_fma_f32 for two heads (the gathered value enters through
+//     op_sel as a splat): 64 packed instead of 128 scalar FMAs per step;
+//   * each lane holds the rows of its constant operand PERMUTED by its own lane id, R[q] = Z[q ^ (lane & 7)] (a permuted load
+//     address, once per row): the three head-splitting stages of the reduce-scatter then need no selects at all — "my" value is
+//     always slot k, "the other lane's" always slot k + half.  Only the edge-splitting stage selects, on the two gathered float4s
+//     (8 v_cndmask per pair instead of 30).
+// Same sums in another association: results move within f32 rounding (tests: fp64 truth, test_gpu_refsize.py).
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct ShPairs { f2v p[4][4]; };   // [column of the lane's float4][head pair]
+
+// P of this lane from an [8, F] row panel (`panel` = row base + the lane's column offset)
+__device__ __forceinline__ void sh_pairs_load(ShPairs &P, const float *__restrict__ panel, int64_t F, int li, bool act) {
+  float4 t[kShH];
+#pragma unroll
+  for (int q = 0; q < kShH; ++q)
+    t[q] = act ? *reinterpret_cast<const float4 *>(panel + (int64_t)(q ^ (li & 7)) * F) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int qp = 0; qp < 4; ++qp) {
+    P.p[0][qp] = f2v{t[2 * qp].x, t[2 * qp + 1].x};
+    P.p[1][qp] = f2v{t[2 * qp].y, t[2 * qp + 1].y};
+    P.p[2][qp] = f2v{t[2 * qp].z, t[2 * qp + 1].z};
+    P.p[3][qp] = f2v{t[2 * qp].w, t[2 * qp + 1].w};
+  }
+}
+// per-lane LDS slots of P (8 float4 per lane: slot 2 c + j holds head pairs 2 j, 2 j + 1 of column c)
+template <typename L> __device__ __forceinline__ void sh_pairs_to_lds(const ShPairs &P, L &lds) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      lds[2 * c + j][threadIdx.x] = make_float4(P.p[c][2 * j].x, P.p[c][2 * j].y, P.p[c][2 * j + 1].x, P.p[c][2 * j + 1].y);
+}
+// the pair's 16 partial dots of this lane: v0[qp] = (head 2 qp, 2 qp + 1) against g0, v1 against g1
+template <bool LDS, typename L>
+__device__ __forceinline__ void sh_pair_dots(const ShPairs &P, L &lds, const float4 &g0, const float4 &g1, f2v (&v0)[4],
+                                             f2v (&v1)[4]) {
+  const float ga[4] = {g0.x, g0.y, g0.z, g0.w}, gb[4] = {g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f2v pc[4];
+    if constexpr (LDS) {
+      const float4 lo = lds[2 * c][threadIdx.x], hi = lds[2 * c + 1][threadIdx.x];
+      pc[0] = f2v{lo.x, lo.y}; pc[1] = f2v{lo.z, lo.w}; pc[2] = f2v{hi.x, hi.y}; pc[3] = f2v{hi.z, hi.w};
+    } else {
+#pragma unroll
+      for (int qp = 0; qp < 4; ++qp) pc[qp] = P.p[c][qp];
+    }
+    const f2v sa = f2v{ga[c], ga[c]}, sb = f2v{gb[c], gb[c]};
+#pragma unroll
+    for (int qp = 0; qp < 4; ++qp) {
+      v0[qp] = c == 0 ? pc[qp] * sa : __builtin_elementwise_fma(pc[qp], sa, v0[qp]);
+      v1[qp] = c == 0 ? pc[qp] * sb : __builtin_elementwise_fma(pc[qp], sb, v1[qp]);
+    }
+  }
+}
+// reduce-scatter of the 16 partials over the row's 16 lanes; lane 8 e + h returns the total of (its slot-0 edge, head h).
+// Slot k of lane l holds head k ^ (l & 7) (sh_pairs_load's permutation) and lanes >= 8 hold the pair's edges swapped.
+__device__ __forceinline__ float sh_pair_reduce(const f2v (&v0)[4], const f2v (&v1)[4]) {
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int qp = 0; qp < 4; ++qp) {
+    a[2 * qp] = v0[qp].x + row_ror8(v1[qp].x);
+    a[2 * qp + 1] = v0[qp].y + row_ror8(v1[qp].y);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = a[k] + __shfl_xor(a[4 + k], 4, 64);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) c[k] = b[k] + dpp_mov<0x4E>(b[2 + k]);
+  return c[0] + dpp_mov<0xB1>(c[1]);
+}
+__device__ __forceinline__ float4 sel4(bool s, const float4 &a, const float4 &b) {
+  return make_float4(s ? a.x : b.x, s ? a.y : b.y, s ? a.z : b.z, s ? a.w : b.w);
+}
+
 struct ShDims {
   float slope;
   int64_t N, F, E;        // rows of this walk, floats per gathered row (<= 64, multiple of 4)
@@ -621,7 +703,8 @@ __global__ __launch_bounds__(kBlock) void gat_sh_fwd_final_kernel(const int32_t 
 // destination walk of the backward: ger[i,h] = sum_p de_p with <G_i[h,:], x_j> from the row's G in registers
 // GLDS (option gat_sh_glds, A/B): the row's G (8 heads x this lane's 4 columns, dot-product operands only) in per-lane LDS slots
 // like gat_sh_bwd_src's z_j
-template <bool DROP, bool PF = false, bool GLDS = false>
+// PK (round 6, option gat_sh_pk): the dots packed over head pairs and reduced without selects (sh_pair_dots / sh_pair_reduce)
+template <bool DROP, bool PF = false, bool GLDS = false, bool PK = false>
 __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const int32_t *__restrict__ row_order,
     const int32_t *__restrict__ long_rows, const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el,
@@ -630,11 +713,17 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
   GGL_SH_PROLOGUE();
   const int64_t F = d.F;
   __shared__ float4 gs_lds[GLDS ? kShH : 1][GLDS ? kBlock : 1];
-  float4 g[GLDS ? 1 : kShH];
+  float4 g[(GLDS || PK) ? 1 : kShH];
+  ShPairs GP;
+  if (PK) {
+    sh_pairs_load(GP, G + it.row * kShH * F + kk, F, li, act);
+    if constexpr (GLDS) sh_pairs_to_lds(GP, gs_lds);
+  } else {
 #pragma unroll
-  for (int q = 0; q < kShH; ++q) {
-    const float4 gq = act ? *reinterpret_cast<const float4 *>(G + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (GLDS) gs_lds[q][threadIdx.x] = gq; else g[q] = gq;
+    for (int q = 0; q < kShH; ++q) {
+      const float4 gq = act ? *reinterpret_cast<const float4 *>(G + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GLDS) gs_lds[q][threadIdx.x] = gq; else g[(GLDS || PK) ? 0 : q] = gq;
+    }
   }
   const float4 st = *reinterpret_cast<const float4 *>(stats + (it.row * kShH + h) * 4);  // {er, m, rinv, dot}
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
@@ -658,15 +747,22 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
     if (DROP) rw = drop_words4(p0 >> 2, kShH, h, offset, seed);
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {  // pair of edges (2 pr, 2 pr + 1): 16 dots -> one per weight lane
-      float v[16];
+      float da;
       if (GLDS) asm volatile("" ::: "memory");   // (re-read every step: hoisted, the slots would be registers again)
+      if (PK) {
+        f2v v0[4], v1[4];
+        sh_pair_dots<GLDS>(GP, gs_lds, sel4(e != 0, xv[2 * pr + 1], xv[2 * pr]), sel4(e != 0, xv[2 * pr], xv[2 * pr + 1]), v0, v1);
+        da = sh_pair_reduce(v0, v1);
+      } else {
+        float v[16];
 #pragma unroll
-      for (int q = 0; q < kShH; ++q) {
-        const float4 gq = GLDS ? gs_lds[q][threadIdx.x] : g[q];
-        v[q] = dot4(gq, xv[2 * pr]);
-        v[8 + q] = dot4(gq, xv[2 * pr + 1]);
+        for (int q = 0; q < kShH; ++q) {
+          const float4 gq = GLDS ? gs_lds[q][threadIdx.x] : g[(GLDS || PK) ? 0 : q];
+          v[q] = dot4(gq, xv[2 * pr]);
+          v[8 + q] = dot4(gq, xv[2 * pr + 1]);
+        }
+        da = reduce_scatter16(v, li);
       }
-      float da = reduce_scatter16(v, li);
       const float raw = (pr ? s1 : s0) + st.x;
       const float al = fexp(lrelu(raw, d.slope) - st.y) * st.z;
       if (DROP) da = (pick_word(rw, e + 2 * pr) >= d.drop_thresh) ? da * d.drop_scale : 0.0f;
@@ -691,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
 // registers that only feed the dot products) live in LDS instead — each lane reads back exactly the slot it wrote, so no barrier
 // is involved: LDS as a per-lane register file.  140 -> ~110 registers = 4 wavefronts per SIMD without spills; costs 16
 // ds_read_b128 per 4-edge step (the LDS pipe is otherwise idle here).
-template <bool DROP, int WAVES = 1, bool ZLDS = false>
+template <bool DROP, int WAVES = 1, bool ZLDS = false, bool PK = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void gat_sh_bwd_src_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col /* colT */, const int32_t *__restrict__ posT,
     const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
@@ -701,11 +797,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
   GGL_SH_PROLOGUE();
   const int64_t F = d.F;  // here: padded class width of gy / z rows
   __shared__ float4 zs[ZLDS ? kShH : 1][ZLDS ? kBlock : 1];
-  float4 zr[ZLDS ? 1 : kShH], acc[kShH];
+  float4 zr[(ZLDS || PK) ? 1 : kShH], acc[kShH];
+  ShPairs ZP;
+  if (PK) {
+    sh_pairs_load(ZP, z + it.row * kShH * F + kk, F, li, act);
+    if constexpr (ZLDS) sh_pairs_to_lds(ZP, zs);
+  }
 #pragma unroll
   for (int q = 0; q < kShH; ++q) {
-    const float4 zq = act ? *reinterpret_cast<const float4 *>(z + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ZLDS) zs[q][threadIdx.x] = zq; else zr[q] = zq;
+    if (!PK) {
+      const float4 zq = act ? *reinterpret_cast<const float4 *>(z + (it.row * kShH + q) * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ZLDS) zs[q][threadIdx.x] = zq; else zr[(ZLDS || PK) ? 0 : q] = zq;
+    }
     acc[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   const float el_j = el[it.row * kShH + h];
@@ -714,17 +817,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
   // (ZLDS: the registers it frees also pay for the NEXT step's ids — requested before this step's gathers, so that a step
   //  waits for one memory round trip, its gathers', instead of two dependent ones)
   ShBlock b, fp, nb, nfp;  // fp: the block's FORWARD positions (dropout), fetched beside the column ids, not behind them
+  // (PK: a weight lane needs the forward positions of ITS two edges only, p0 + e and p0 + 2 + e: two dwords instead of the
+  //  block's four — 4 registers that keep the dropout form at 128 = 4 wavefronts per SIMD)
+  int32_t fq2[2] = {0, 0}, nfq2[2] = {0, 0};
+  auto own_pos = [&](int64_t p0, int32_t (&o)[2]) {
+    const int64_t a = p0 + e, c = p0 + 2 + e;
+    o[0] = (a >= it.beg && a < it.end) ? posT[a] : 0;
+    o[1] = (c >= it.beg && c < it.end) ? posT[c] : 0;
+  };
   if (ZLDS && (it.beg & ~(int64_t)3) < it.end) {
     sh_block(col, it.beg & ~(int64_t)3, it.beg, it.end, nb);
-    if (DROP) sh_block(posT, it.beg & ~(int64_t)3, it.beg, it.end, nfp);
+    if (DROP && !PK) sh_block(posT, it.beg & ~(int64_t)3, it.beg, it.end, nfp);
+    if (DROP && PK) own_pos(it.beg & ~(int64_t)3, nfq2);
   }
   for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
     if (ZLDS) {
       b = nb;
-      if (DROP) fp = nfp;
+      if (DROP && !PK) fp = nfp;
+      if (DROP && PK) { fq2[0] = nfq2[0]; fq2[1] = nfq2[1]; }
       if (p0 + 4 < it.end) {
         sh_block(col, p0 + 4, it.beg, it.end, nb);
-        if (DROP) sh_block(posT, p0 + 4, it.beg, it.end, nfp);
+        if (DROP && !PK) sh_block(posT, p0 + 4, it.beg, it.end, nfp);
+        if (DROP && PK) own_pos(p0 + 4, nfq2);
       }
     } else {
       sh_block(col, p0, it.beg, it.end, b);
@@ -741,22 +855,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     if (ZLDS) asm volatile("" ::: "memory");   // (the z slots are re-read every step: hoisted out of the loop they would be the 32 registers again)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-      float v[16];
+      float da;
+      if (PK) {
+        f2v v0[4], v1[4];
+        sh_pair_dots<ZLDS>(ZP, zs, sel4(e != 0, gv[2 * pr + 1], gv[2 * pr]), sel4(e != 0, gv[2 * pr], gv[2 * pr + 1]), v0, v1);
+        if (ZLDS) asm volatile("" ::: "memory");
+        da = sh_pair_reduce(v0, v1);
+      } else {
+        float v[16];
 #pragma unroll
-      for (int q = 0; q < kShH; ++q) {
-        const float4 zq = ZLDS ? zs[q][threadIdx.x] : zr[q];
-        v[q] = dot4(zq, gv[2 * pr]);
-        v[8 + q] = dot4(zq, gv[2 * pr + 1]);
+        for (int q = 0; q < kShH; ++q) {
+          const float4 zq = ZLDS ? zs[q][threadIdx.x] : zr[(ZLDS || PK) ? 0 : q];
+          v[q] = dot4(zq, gv[2 * pr]);
+          v[8 + q] = dot4(zq, gv[2 * pr + 1]);
+        }
+        if (ZLDS) asm volatile("" ::: "memory");
+        da = reduce_scatter16(v, li);
       }
-      if (ZLDS) asm volatile("" ::: "memory");
-      float da = reduce_scatter16(v, li);
       const float4 st = pr ? st1 : st0;
       const bool ok = pr ? okB : okA;
       const float raw = el_j + st.x;
       const float al = fexp(lrelu(raw, d.slope) - st.y) * st.z;
       float alk = al;
       if (DROP) {  // the keep bit lives at the FORWARD position of the edge
-        const int32_t fq = pr ? (e ? fp.c[3] : fp.c[2]) : (e ? fp.c[1] : fp.c[0]);
+        const int32_t fq = (PK && ZLDS) ? fq2[pr] : (pr ? (e ? fp.c[3] : fp.c[2]) : (e ? fp.c[1] : fp.c[0]));
         const bool keep = ok && drop_word((int64_t)fq, kShH, h, offset, seed) >= d.drop_thresh;
         alk = keep ? al * d.drop_scale : 0.0f;
         da = keep ? da * d.drop_scale : 0.0f;
@@ -1080,7 +1202,14 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? plan->row_order : nullptr;
     const bool pf = options().gat_sh_prefetch != 0;
-    if (pf && options().gat_sh_glds != 0) {
+    if (pf && options().gat_sh_pk != 0 && options().gat_sh_glds == 0) {   // round 6 default: packed pair dots, select-free reduce
+      if (d.drop_thresh)
+        GGL_LAUNCH((gat_sh_bwd_dst_kernel<true, true, false, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                   plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+      else
+        GGL_LAUNCH((gat_sh_bwd_dst_kernel<false, true, false, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
+                   plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
+    } else if (pf && options().gat_sh_glds != 0) {
       if (d.drop_thresh)
         GGL_LAUNCH((gat_sh_bwd_dst_kernel<true, true, true>), grid, kBlock, s, plan->rowptr, col, order, plan->long_rows,
                    plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
@@ -1120,7 +1249,17 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? planT->row_order : nullptr;
-    if (d.drop_thresh && options().gat_sh_zlds != 0)
+    const bool pk = options().gat_sh_pk != 0 && options().gat_sh_zlds != 0;
+    if (pk && d.drop_thresh && options().gat_sh_waves >= 4)   // (A/B: built for 4 wavefronts per SIMD — 128 registers + 12 spilled values)
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 4, true, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    else if (pk && d.drop_thresh)
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 1, true, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    else if (pk)
+      GGL_LAUNCH((gat_sh_bwd_src_kernel<false, 1, true, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                 planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    else if (d.drop_thresh && options().gat_sh_zlds != 0)
       GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 1, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
                  planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
     else if (d.drop_thresh && options().gat_sh_waves >= 4)

@@ -57,6 +57,7 @@ Options &options() {
     t.hub_one_launch = env_i64("GGL_HUB_ONE_LAUNCH", t.hub_one_launch);
     t.gat_sh_waves = env_i64("GGL_GAT_SH_WAVES", t.gat_sh_waves);
     t.gat_sh_zlds = env_i64("GGL_GAT_SH_ZLDS", t.gat_sh_zlds);
+    t.gat_sh_pk = env_i64("GGL_GAT_SH_PK", t.gat_sh_pk);
     t.gat_sh_prefetch = env_i64("GGL_GAT_SH_PREFETCH", t.gat_sh_prefetch);
     t.gat_sh_glds = env_i64("GGL_GAT_SH_GLDS", t.gat_sh_glds);
     t.hub_pipe = env_i64("GGL_HUB_PIPE", t.hub_pipe);
@@ -64,7 +65,7 @@ Options &options() {
     t.hop_fused_scans = env_i64("GGL_HOP_FUSED_SCANS", t.hop_fused_scans);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
-    t.maxbwd_mask_ratio = env_i64("GGL_MAXBWD_MASK_RATIO", t.maxbwd_mask_ratio);
+    t.maxbwd_mask_kmax = env_i64("GGL_MAXBWD_MASK_KMAX", t.maxbwd_mask_kmax);
     t.maxbwd_mask_scatter = env_i64("GGL_MAXBWD_MASK_SCATTER", t.maxbwd_mask_scatter);
     t.maxbwd_mask_wlane = env_i64("GGL_MAXBWD_MASK_WLANE", t.maxbwd_mask_wlane);
     t.maxbwd_mask_cols = env_i64("GGL_MAXBWD_MASK_COLS", t.maxbwd_mask_cols);
@@ -310,6 +311,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "hub_one_launch")) o.hub_one_launch = value;
   else if (!strcmp(name, "gat_sh_waves")) o.gat_sh_waves = value;
   else if (!strcmp(name, "gat_sh_zlds")) o.gat_sh_zlds = value;
+  else if (!strcmp(name, "gat_sh_pk")) o.gat_sh_pk = value;
   else if (!strcmp(name, "gat_sh_prefetch")) o.gat_sh_prefetch = value;
   else if (!strcmp(name, "gat_sh_glds")) o.gat_sh_glds = value;
   else if (!strcmp(name, "hub_pipe")) o.hub_pipe = value;
@@ -317,7 +319,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "hop_fused_scans")) o.hop_fused_scans = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
-  else if (!strcmp(name, "maxbwd_mask_ratio")) o.maxbwd_mask_ratio = value;
+  else if (!strcmp(name, "maxbwd_mask_kmax")) o.maxbwd_mask_kmax = value;
   else if (!strcmp(name, "maxbwd_mask_scatter")) o.maxbwd_mask_scatter = value;
   else if (!strcmp(name, "maxbwd_mask_wlane")) o.maxbwd_mask_wlane = value;
   else if (!strcmp(name, "maxbwd_mask_cols")) o.maxbwd_mask_cols = value;
@@ -345,6 +347,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "hub_one_launch")) return o.hub_one_launch;
   if (!strcmp(name, "gat_sh_waves")) return o.gat_sh_waves;
   if (!strcmp(name, "gat_sh_zlds")) return o.gat_sh_zlds;
+  if (!strcmp(name, "gat_sh_pk")) return o.gat_sh_pk;
   if (!strcmp(name, "gat_sh_prefetch")) return o.gat_sh_prefetch;
   if (!strcmp(name, "gat_sh_glds")) return o.gat_sh_glds;
   if (!strcmp(name, "hub_pipe")) return o.hub_pipe;
@@ -352,7 +355,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "hop_fused_scans")) return o.hop_fused_scans;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
-  if (!strcmp(name, "maxbwd_mask_ratio")) return o.maxbwd_mask_ratio;
+  if (!strcmp(name, "maxbwd_mask_kmax")) return o.maxbwd_mask_kmax;
   if (!strcmp(name, "maxbwd_mask_scatter")) return o.maxbwd_mask_scatter;
   if (!strcmp(name, "maxbwd_mask_wlane")) return o.maxbwd_mask_wlane;
   if (!strcmp(name, "maxbwd_mask_cols")) return o.maxbwd_mask_cols;

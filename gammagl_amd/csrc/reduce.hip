@@ -1518,18 +1518,16 @@ extern "C" size_t ggl_spmm_max_mask_bytes(int64_t E, int64_t K) {     // (room f
 }
 
 // Which form the gspmm(max) backward takes (include/ggl_mpops.h): 2 = 1-bit winner mask, 1 = int32 witness copy, 0 = the
-// int64 witnesses as they are.  The mask is a TRANSIENT of E x mask_words_seq(K) x 4 bytes (K = 602: 96 B per edge): it is
-// taken where it is cheaper than what it replaces — K >= maxbwd_mask, the [N_dst, K] witness matrix too large to stay
-// cache-resident (>= 256 MiB as int32: the Infinity Cache's size), and the mask no larger than maxbwd_mask_ratio x the int64
-// witness matrix [N_dst, K] itself (products-sized K = 256: 4.0 GB mask vs 5.0 GB witnesses -> mask; Reddit-sized K = 256:
-// 3.7 GB mask vs 0.48 GB witnesses, which the caches hold -> int32 copy).
+// int64 witnesses as they are.  The mask is a TRANSIENT of E x mask_words_seq(K) x 4 bytes: taken for maxbwd_mask <= K <=
+// maxbwd_mask_kmax (128 .. 256: at most 32 bytes per edge, twice what the plan itself holds per edge).  Measured on both
+// benchmark graphs (profiles/r6_maxbwd_forms.txt, fwd + bwd, int32 witnesses vs mask): products-sized K = 128 / 256 / 602:
+// 24.8 / 52.9 / 193.5 vs 21.8 / 41.4 / 213.6 ms; Reddit-sized (dense: its 0.48 GB witness matrix is cache-resident) 16.5 /
+// 40.8 / 136.9 vs 15.3 / 30.5 / 159.9 ms — the mask wins up to K = 256 on both and loses at K = 602 on both (96 B per edge:
+// +11.9 GiB on the Reddit-sized graph).  The hosts fall back to form 1 when the transient cannot be allocated.
 extern "C" int ggl_policy_maxbwd_form(int64_t E, int64_t N_dst, int64_t K) {
   const auto &o = options();
-  if (o.maxbwd_mask > 0 && K >= o.maxbwd_mask && E > 0 && N_dst > 0) {
-    const double mask_b = (double)E * (double)mask_words_seq(K) * 4.0, wit_b = (double)N_dst * (double)K * 8.0;
-    const bool resident = (double)N_dst * (double)K * 4.0 < 256.0 * 1048576.0;
-    if (o.maxbwd_mask_ratio <= 0 || (!resident && mask_b <= (double)o.maxbwd_mask_ratio * wit_b)) return 2;
-  }
+  (void)N_dst;
+  if (o.maxbwd_mask > 0 && K >= o.maxbwd_mask && (o.maxbwd_mask_kmax <= 0 || K <= o.maxbwd_mask_kmax) && E > 0) return 2;
   return o.maxbwd_arg32 != 0 ? 1 : 0;
 }
 

@@ -48,7 +48,7 @@ extern "C" {
  *   doubles per chunk and head; ggl_segplan_t.xcd_run_rows < 0 is a hint (see the field); + ggl_sample_hop_ex; options
  *   hub_one_launch, hub_priority, hub_pipe, maxbwd_mask*, gat_sh_waves, hop_fused_scans.  No struct change. */
 /* 9 (round 6): + ggl_policy_maxbwd_form (the gspmm-max backward's form gated on the winner mask's footprint; option
- *   maxbwd_mask_ratio), + ggl_gat_sh_* unchanged.  No struct change. */
+ *   maxbwd_mask_kmax), + ggl_gat_sh_* unchanged.  No struct change. */
 #define GGL_ABI_VERSION 9
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
@@ -513,9 +513,9 @@ int64_t ggl_policy_head_channels(int64_t C, int64_t E, int64_t N_in);
 int ggl_policy_mean_bwd_prescale(int64_t E, int64_t N_in);
 /* form of the gspmm(max) backward over E edges into [N_dst, K] witnesses: 2 = 1-bit winner mask (ggl_spmm_max_mask +
  * ggl_spmm_max_bwd_mask; a transient of ggl_spmm_max_mask_bytes(E, K)), 1 = int32 witness copy (ggl_spmm_max_bwd32),
- * 0 = int64 witnesses (ggl_spmm_max_bwd).  The mask where K >= option maxbwd_mask, the witness matrix is too large to stay
- * cache-resident (N_dst K 4 B >= 256 MiB) and the mask is <= maxbwd_mask_ratio x N_dst K 8 B (products-sized K = 256: 4.0
- * vs 5.0 GB -> mask; Reddit-sized: 3.7 vs 0.48 GB -> int32).  Hosts also fall back to 1 when the mask cannot be allocated. */
+ * 0 = int64 witnesses (ggl_spmm_max_bwd).  The mask for option maxbwd_mask (128) <= K <= option maxbwd_mask_kmax (256):
+ * measured faster on the products- AND the Reddit-sized graph up to K = 256, slower and 96 B per edge at K = 602
+ * (profiles/r6_maxbwd_forms.txt).  Hosts also fall back to 1 when the mask cannot be allocated. */
 int ggl_policy_maxbwd_form(int64_t E, int64_t N_dst, int64_t K);
 /* 1: the bspmm weight gradient walks the destination-sorted plan with LDS-staged strips (edgedot.hip); 0: one thread
  * per (edge, head) in COO order — channel counts that are not multiples of 4, and heads of <= 16 channels unless they

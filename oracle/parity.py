@@ -147,13 +147,14 @@ def gat_model_composed(x, params, ei, n, heads, slope=0.2, seg=None):
     return x
 
 
-def layer_errors_vs_truth(truth, got, names, zero_mean_rows=()):
+def layer_errors_vs_truth(truth, got, names, zero_mean_rows=(), abs_floor=0.0):
     """{name: max row-scale relative error} of a tuple of tensors against float64 truths; `zero_mean_rows` names tensors whose
-    rows can cancel to ~0 as a whole (scale floor = the tensor's mean magnitude)."""
+    rows can cancel to ~0 as a whole (scale floor = the tensor's mean magnitude, at least `abs_floor`: a one-edge graph's logit
+    gradients are exactly 0 everywhere, and rounding noise of the cancelling terms is all there is to compare)."""
     out = {}
     for name, t64, a in zip(names, truth, got):
         t2 = t64.reshape(t64.shape[0], -1) if t64.dim() > 1 else t64.reshape(1, -1)
         a2 = a.double().to(t64.device).reshape(t2.shape)
-        floor = float(t64.abs().mean()) if name in zero_mean_rows else 0.0
+        floor = max(float(t64.abs().mean()), float(abs_floor)) if name in zero_mean_rows else 0.0
         out[name] = report(a2, t2, tol=1.0, floor_min=floor)["max_rel_err"]
     return out

@@ -2070,7 +2070,7 @@ def check_max_backward_forms(eng, dev, oracle, chunk=64):
                                    ("winner mask, forward order", {"maxbwd_mask": 1, "maxbwd_arg32": 0}),
                                    ("winner mask, scattered", {"maxbwd_mask": 1, "maxbwd_arg32": 0, "maxbwd_mask_scatter": 1})):
                     with option(eng, "maxbwd_mask", opts["maxbwd_mask"]), option(eng, "maxbwd_arg32", opts["maxbwd_arg32"]), \
-                            option(eng, "maxbwd_mask_ratio", 0), \
+                            option(eng, "maxbwd_mask_kmax", 0), \
                             option(eng, "maxbwd_mask_scatter", opts.get("maxbwd_mask_scatter", 0)):
                         for call in range(2):       # (second call: weights streamed from their sorted copy)
                             xt = to_t(xs, dev).requires_grad_(True)
@@ -2079,7 +2079,7 @@ def check_max_backward_forms(eng, dev, oracle, chunk=64):
                             assert_same(got[one_piece], want[one_piece], f"max backward, {name}, K{K} shuffle={shuffle} call {call}")
                             np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4)
                 # no weights
-                with option(eng, "maxbwd_mask", 1), option(eng, "maxbwd_mask_ratio", 0):    # (ratio 0: no footprint gate)
+                with option(eng, "maxbwd_mask", 1), option(eng, "maxbwd_mask_kmax", 0):    # (kmax 0: no upper bound on the width)
                     xt = to_t(xs, dev).requires_grad_(True)
                     eng.c_spmm_max(it, None, xt).backward(to_t(go, dev))
                     ones = np.ones(E, np.float32)

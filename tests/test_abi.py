@@ -90,21 +90,20 @@ def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
 
 
 def test_maxbwd_form_policy_gates_the_winner_mask_on_its_footprint():
-    """ggl_policy_maxbwd_form (round 6, advisor): the 1-bit winner mask is an E x K/8-byte transient — chosen on the
-    products-sized graph (4.0 GB mask vs a 5.0 GB int64 witness matrix), NOT on the Reddit-sized one (3.7 GB mask vs a
-    0.48 GB witness matrix the caches hold) nor at K = 602 there (11 GB); narrow K never; ratio 0 removes the gate (tests)."""
+    """ggl_policy_maxbwd_form (round 6, advisor): the 1-bit winner mask is an E x K/8-byte transient — chosen for
+    128 <= K <= 256 (measured faster on the products- and the Reddit-sized graph, <= 32 B per edge), not at K = 602 (slower on
+    both, 96 B per edge = 11.9 GiB on the Reddit-sized graph), never for narrow K; kmax 0 removes the bound (tests)."""
     from gammagl_amd import _lib
 
     lib = _lib.bind(_lib.HOST_LIB_PATH)
     form = lib.ggl_policy_maxbwd_form
-    assert form(126_167_309, 2_449_029, 256) == 2
+    assert form(126_167_309, 2_449_029, 256) == 2 and form(114_848_857, 232_965, 256) == 2
+    assert form(126_167_309, 2_449_029, 128) == 2
     assert form(126_167_309, 2_449_029, 64) == 1
-    assert form(114_848_857, 232_965, 256) == 1
-    assert form(114_848_857, 232_965, 602) == 1
-    assert form(400, 64, 256) == 1
-    old = lib.ggl_get_option(b"maxbwd_mask_ratio")
+    assert form(114_848_857, 232_965, 602) == 1 and form(126_167_309, 2_449_029, 602) == 1
+    old = lib.ggl_get_option(b"maxbwd_mask_kmax")
     try:
-        lib.ggl_set_option(b"maxbwd_mask_ratio", 0)
-        assert form(400, 64, 256) == 2
+        lib.ggl_set_option(b"maxbwd_mask_kmax", 0)
+        assert form(400, 64, 602) == 2
     finally:
-        lib.ggl_set_option(b"maxbwd_mask_ratio", old)
+        lib.ggl_set_option(b"maxbwd_mask_kmax", old)

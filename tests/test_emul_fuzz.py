@@ -93,7 +93,7 @@ def test_gspmm_fuzz(oracle, prob):
 def test_gspmm_max_backward_mask_fuzz(oracle, prob, scatter):
     """the same cases with the max backward forced through the 1-bit winner mask (round 5), records in forward order / scattered"""
     eng = engine()
-    with pc.option(eng, "maxbwd_mask", 1), pc.option(eng, "maxbwd_mask_ratio", 0), pc.option(eng, "maxbwd_mask_scatter", scatter):
+    with pc.option(eng, "maxbwd_mask", 1), pc.option(eng, "maxbwd_mask_kmax", 0), pc.option(eng, "maxbwd_mask_scatter", scatter):
         run_gspmm_case(eng, DEV, oracle, prob)
 
 

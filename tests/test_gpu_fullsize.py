@@ -125,9 +125,17 @@ def test_reddit_size_gat_output_layer_headmean(eng, dev, reddit):
             res.append([y.detach(), xa.grad, fg.w.grad.clone(), fg.att.grad.clone()])
     finally:
         eng.gat_fast = True
+    # round 6: the row-scale criterion (rounds 3-5: 3e-4 of the tensor's maximum) — y / gx at 2e-5; the parameter gradients are
+    # f32 sums over 233 k nodes and 114.8 M edges on both sides (each ~6e-5 from the float64 truth at the subgraph size,
+    # test_gpu_refsize.py): 2e-4 between two such evaluations.  The path's CORRECTNESS is pinned in test_gpu_refsize.py against
+    # the reference ops and float64; this test holds the two HIP paths together at the full edge count.
+    from oracle import parity
+
     for a, b, nm in zip(res[0], res[1], ("y", "gx", "gW", "gatt")):
-        tol = 3e-4 * float(b.abs().max()) + 1e-6
-        assert float((a - b).abs().max()) <= tol, (nm, float((a - b).abs().max()), tol)
+        a2, b2 = (t.reshape(t.shape[0], -1) if t.dim() > 1 else t.reshape(1, -1) for t in (a, b))
+        r = parity.report(a2, b2, tol=(2e-5 if nm in ("y", "gx") else 2e-4), floor_min=float(b2.abs().mean()))
+        print(f"full-size head-mean vs transform-first {nm}: {r['max_rel_err']:.3e}")
+        assert r["ok"], (nm, r)
     assert bool(torch.isfinite(res[0][0]).all())
 
 
