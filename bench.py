@@ -686,6 +686,12 @@ def compact_line(out):
                           "rank0_owned_rows", "rank0_halo_rows", "rank0_send_rows", "rank0_peak_edges_during_build",
                           "rank0_halo_GB_per_step", "matmul_precision", "loss", "batch",
                           "launches_per_step")))
+    if cfg.get("route"):
+        cc["route"] = _short(str(cfg["route"]), 16)
+    if isinstance(cfg.get("routes"), dict):
+        cc["routes_ms"] = {("cpp" if "ggl" in k else "ctypes"): v for k, v in cfg["routes"].items() if k != "unit"}
+    if "engine" in c:
+        c["engine"] = _short(c["engine"], 40)
     if "hipgraph" in cc:
         cc["hipgraph"] = _short(cc["hipgraph"], 24)
     if "matmul_precision" in cc:
@@ -897,7 +903,11 @@ def main():
         if world > 1:
             diagnostic(err)
         raise
-    out["engine"] = "host-emulation (launcher test, not a measurement)" if emul else "hip"
+    pg0 = ctx.get("pg") if isinstance(ctx, dict) else None
+    route = getattr(pg0, "route", None) if (pg0 is not None and not getattr(pg0, "comm", True)) else None
+    out["engine"] = ("host-emulation (launcher test, not a measurement)" if emul else
+                     ("torch.ops.ggl (dispatcher -> libggl_torch.so -> C ABI -> libggl_mpops_hip.so: the route compat/_torch_ext.py binds)"
+                      if route == "cpp" else "hip (ctypes engine -> C ABI -> libggl_mpops_hip.so)"))
     out["config"]["tuned_gemm_selection"] = tuned
     out["config"]["matmul_precision"] = args.matmul_precision + (" (IEEE f32)" if args.matmul_precision == "highest"
                                                                    else " (hipBLASLt f32 emulated with bf16 triples: NOT the line of record)")

@@ -31,6 +31,7 @@ def engine(like=None):
         from .ops import Engine
 
         _engine = Engine(_lib.hip_lib(), require_cuda=True)
+        _engine.is_product = True     # bound to gammagl_amd/lib/libggl_mpops_hip.so: the library torch.ops.ggl serves GPU tensors from
     return _engine
 
 
@@ -42,4 +43,5 @@ def host_engine():
         from .ops import Engine
 
         _host_engine = Engine(_lib.host_lib(), require_cuda=False, cpu_only=True)
+        _host_engine.is_product = True
     return _host_engine

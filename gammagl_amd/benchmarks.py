@@ -415,6 +415,19 @@ def run_gcn(args, dev, rank, world, eng=None):
                              "reference's association, reported beside the headline only") if not af_main else
                             "every layer A (X W) as gcn_conv.py:79 writes it"}
         del tr2
+    routes = None
+    if not pg.comm and getattr(pg, "route", None) == "cpp" and not getattr(args, "no_comparison", False) and not emul:
+        # the same step through the other host implementation (the ctypes engine's autograd Functions), so that the line says
+        # what the choice of route costs: both end in the same C ABI calls
+        pg.route = "ctypes"
+        try:
+            tr3 = trainer(af_main)
+            dt3, _ = _time_steps(tr3, data, args, dev, world)
+            del tr3
+        finally:
+            pg.route = "cpp"
+        routes = {"torch.ops.ggl (headline)": round(dt / args.steps * 1e3, 4), "ctypes engine": round(dt3 / args.steps * 1e3, 4),
+                  "unit": "ms_per_step"}
     del tr
 
     # dominant kernel (K = hidden), hipEvents on the launch stream
@@ -446,6 +459,8 @@ def run_gcn(args, dev, rank, world, eng=None):
         "hipgraph": ("the whole step (fwd + bwd + Adam) recorded once into a hipGraph, the timed steps are its replays"
                      if graphed else "no: eager launches"),
         "aggregations_per_step": n_agg,
+        "route": getattr(pg, "route", None) if not pg.comm else "ctypes engine (partitioned: in-place / accumulating forms)",
+        "routes": routes,
         "aggregate_first" if not af_main else "transform_first": side,
         "parallelism": (f"node-partition x{world}, 1-hop halo all-to-all-v, per-rank graph construction" if world > 1 else
                         (f"1 GPU playing rank {play} of {parts}" if parts else "1 GPU")),

@@ -307,6 +307,7 @@ class Engine:
     def __init__(self, lib, require_cuda=True, cpu_only=False):
         self.lib = lib
         self.require_cuda = require_cuda
+        self.is_product = False       # set by gammagl_amd.engine() / host_engine(): bound to the shipped library (dist._default_route)
         self.cpu_only = cpu_only      # the host build: its kernels dereference host pointers
         self.seg_cache = _PlanCache()
         self.graph_cache = _PlanCache()

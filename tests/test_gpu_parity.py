@@ -1109,3 +1109,40 @@ def test_sage_replica_step_as_two_graphs_around_the_allreduce(eng, dev):
         assert per < 2000
     finally:
         pass
+
+
+def test_one_rank_training_step_through_torch_ops_ggl_equals_the_ctypes_engine(eng, dev):
+    """The route bench.py's headline takes on one GPU (dist._default_route -> "cpp": DistGCN's aggregates through
+    torch.ops.ggl.spmm_epi, the operator library the zero-edit drop-in binds) against the ctypes engine's autograd Functions:
+    same C ABI calls underneath, so the loss and every weight gradient of a training step are bit-identical (hub rows on the
+    chunk-free serial walk included; dropout off — the two hosts keep separate counter streams)."""
+    from gammagl_amd import cpp_ops, dist as gdist
+    from gammagl_amd.layers import calc_gcn_norm
+    from gammagl_amd.synth import rmat_graph
+
+    ops = cpp_ops.load()
+    N = 60000
+    ei = rmat_graph(N, 1_500_000, seed=3, device=dev)
+    w = calc_gcn_norm(ei, N).contiguous()
+    pg = gdist.PartitionedGraph(ei, w, N, eng=eng)
+    assert pg.route == "cpp" and not pg.comm and pg.gp_loc.fwd.n_long > 0
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn(N, 100, generator=g, device=dev)
+    y = torch.randint(0, 47, (N,), generator=g, device=dev)
+    idx = torch.arange(0, N, 3, device=dev)
+    res = {}
+    for route in ("cpp", "ctypes"):
+        pg.route = route
+        tr = gdist.DistGCNTrainer(pg, 100, 256, 47, num_layers=3, drop_rate=0.0, seed=1, device=dev)
+        before = list(ops.plan_stats())
+        loss = tr.step(x, y, idx, int(idx.numel()))
+        if route == "cpp":
+            assert list(ops.plan_stats()) != before, "the step did not reach the C++ operator library's plan cache"
+        tr.opt.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(tr.net(x, pg)[idx], y[idx], reduction="sum").backward()
+        tr.net.join()
+        res[route] = (float(loss), [p.grad.clone() for p in tr.net.parameters()])
+    assert res["cpp"][0] == res["ctypes"][0]
+    for a, b in zip(res["cpp"][1], res["ctypes"][1]):
+        assert torch.equal(a, b)
+    ops.clear_caches()
