@@ -903,8 +903,7 @@ def main():
         if world > 1:
             diagnostic(err)
         raise
-    pg0 = ctx.get("pg") if isinstance(ctx, dict) else None
-    route = getattr(pg0, "route", None) if (pg0 is not None and not getattr(pg0, "comm", True)) else None
+    route = (out.get("config") or {}).get("route")
     out["engine"] = ("host-emulation (launcher test, not a measurement)" if emul else
                      ("torch.ops.ggl (dispatcher -> libggl_torch.so -> C ABI -> libggl_mpops_hip.so: the route compat/_torch_ext.py binds)"
                       if route == "cpp" else "hip (ctypes engine -> C ABI -> libggl_mpops_hip.so)"))

@@ -59,6 +59,7 @@ SIGNATURES = {
     "ggl_segment_mean": (c_int, [c_int, _V, _P, c_int64, _V, _V]),
     "ggl_segment_max": (c_int, [c_int, _V, _P, c_int64, _V, _V, c_int64, _V]),
     "ggl_spmm_col_blocks": (c_int64, [c_int64, c_int64, c_int64]),
+    "ggl_spmm_col_blocks_plan": (c_int64, [c_void_p, c_int64]),
     "ggl_segment_hub16_supported": (c_int, [c_int, c_int64, _V, _V]),
     "ggl_segment_hub16": (c_int, [c_int, c_int, _V, _P, c_int64, _V, _V]),
     "ggl_segment_sum_bwd": (c_int, [c_int, _V, _V, c_int64, c_int64, _V, _V]),

@@ -319,7 +319,10 @@ def dominant_spmm(pg, eng, K, gen, dev, reps=10):
     gp, w, rows = (pg.gp_halo, pg.w_halo, pg.n_halo) if use_halo else (pg.gp_loc, pg.w_loc, pg.n_local)
     h = torch.randn(rows, K, generator=gen, device=dev)
     ms = eng.time_spmm_sum(gp, w, h, reps=reps)
-    launches = int(eng.lib.ggl_spmm_col_blocks(gp.E, K, pg.n_local))
+    import ctypes
+
+    cs = gp.fwd.c_struct(None)    # (the plan decides: 128-column blocks where its node order carries locality)
+    launches = int(eng.lib.ggl_spmm_col_blocks_plan(ctypes.byref(cs), K))
     del h
     return ms, launches, gp, rows, use_halo
 

@@ -852,12 +852,17 @@ static int launch_f32(const ReduceArgs &a, hipStream_t stream) {
 // gather whatever the width), as do blocks that are not line multiples (K = 96 as 2 x 48: 5.5 -> 7.3 ms).  The
 // columns of a row are independent sums: same bits; the dropout word of element (row, col) is the full-width one
 // (epi_K / epi_col0).  Small graphs (an arxiv-sized launch is 0.3 ms) take two 128-wide blocks at most.
-static int64_t col_block_width(int64_t E, int64_t K, int64_t N) {   // 0 = one launch
+// `xcd_run_rows` > 0 (the plan's node order carries locality: every XCD walks runs of consecutive rows): the L2 hits then come
+// from the communities' own rows, not from keeping hub rows resident, and narrower blocks only re-read the indices — blocks twice
+// as wide (products-sized planted-community graph in its native order, K = 256, profiles/r6_planted_knobs.txt: 32 / 64 / 128 /
+// 256-wide blocks 11.8 / 9.8 / 9.3 / 9.7 ms; the randomly labelled R-MAT graph keeps 64: 13.4 vs 14.7 one launch).
+static int64_t col_block_width(int64_t E, int64_t K, int64_t N, int64_t xcd_run_rows = 0) {   // 0 = one launch
   // the blocks pay through L2 reuse of hub rows: a walk with few edges per row (a rank's local-source block of the
   // papers100M-sized partition: 4.6) has little to reuse and only re-reads its indices per block (10.9 -> 12.6 ms)
   if (N > 0 && E < options().col_block_min_degree * N) return 0;
   int64_t bw = options().col_block;
   if (bw > 0 && E < options().col_block_min_edges) bw *= 2;
+  else if (bw > 0 && xcd_run_rows > 0 && K >= 4 * bw && K % (2 * bw) == 0) bw *= 2;
   if (bw <= 0 || bw % 4 != 0 || K < 2 * bw || K % 4 != 0) return 0;
   // up to 256 columns a row is walked once by its lane group: blocks must tile it exactly (a narrow remainder block
   // would cost a launch of its own for a few columns).  Wider rows are walked once per 256 columns anyway, the last
@@ -871,11 +876,17 @@ extern "C" int64_t ggl_spmm_col_blocks(int64_t E, int64_t K, int64_t N) {
   return bw > 0 ? (K + bw - 1) / bw : 1;
 }
 
+extern "C" int64_t ggl_spmm_col_blocks_plan(const ggl_segplan_t *plan, int64_t K) {
+  if (plan == nullptr) return 1;
+  const int64_t bw = col_block_width(plan->E, K, plan->N, plan->xcd_run_rows);
+  return bw > 0 ? (K + bw - 1) / bw : 1;
+}
+
 template <int OP, int MODE>
 static int launch_f32_cols(const ReduceArgs &a0, hipStream_t stream) {
   static_assert(OP != OP_MAX && (MODE == MODE_SPMM || MODE == MODE_SPMM_EPI || MODE == MODE_MAXBWDM),
                 "column blocks: sum / mean SpMM and the masked max backward (a sum) only");
-  const int64_t bw = col_block_width(a0.E, a0.K, a0.N);
+  const int64_t bw = col_block_width(a0.E, a0.K, a0.N, a0.xcd_run_rows);
   if (bw <= 0 || a0.N <= 0) return launch_f32<OP, MODE>(a0, stream);
   // The hub rows are walked ONCE per aggregate, over the full width (round 5): one hub launch forked in front of the first
   // column block, every slab of every hub row an independent workgroup — the K / 64 add chains of the longest row run

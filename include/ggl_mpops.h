@@ -48,7 +48,8 @@ extern "C" {
  *   doubles per chunk and head; ggl_segplan_t.xcd_run_rows < 0 is a hint (see the field); + ggl_sample_hop_ex; options
  *   hub_one_launch, hub_priority, hub_pipe, maxbwd_mask*, gat_sh_waves, hop_fused_scans.  No struct change. */
 /* 9 (round 6): + ggl_policy_maxbwd_form (the gspmm-max backward's form gated on the winner mask's footprint; option
- *   maxbwd_mask_kmax), + ggl_gat_sh_* unchanged.  No struct change. */
+ *   maxbwd_mask_kmax), + ggl_spmm_col_blocks_plan (128-column blocks for plans whose node order carries locality), option gat_sh_pk.
+ *   No struct change. */
 #define GGL_ABI_VERSION 9
 
 /* dtype codes (AT_DISPATCH_ALL_TYPES_AND2(Half, BFloat16), segment_sum_cpu.cpp:32-33) */
@@ -186,6 +187,8 @@ int ggl_segment_mean(int dtype, const void *x, const ggl_segplan_t *plan, int64_
  * "col_block" / "col_block_min_edges" / "col_block_min_degree"): the number of kernel launches one call over E edges,
  * K columns and N output rows makes. */
 int64_t ggl_spmm_col_blocks(int64_t E, int64_t K, int64_t N);
+/* ... for a plan: as above, blocks twice as wide where plan->xcd_run_rows > 0 (a node order with locality; ABI 9) */
+int64_t ggl_spmm_col_blocks_plan(const ggl_segplan_t *plan, int64_t K);
 
 /* f16 / bf16 sums accumulate in the storage type (segment_sum_cpu.cpp:47-56), so their hub rows cannot be chunked:
  * ggl_segment_hub16 reduces the plan's LONG rows (plan->long_rows) in the reference's serial order with a workgroup

@@ -76,3 +76,31 @@ if "gat" in what:
         print(f"gat_sh_pk={pk} gat_sh_waves={waves}: output layer fwd {f:.2f} ms, fwd+bwd dropout 0.6 {fb:.2f} ms, no dropout {fb0:.2f} ms; 2-layer GAT step {ev(step, 5):.2f} ms", flush=True)
     eng.set_option("gat_sh_pk", 1); eng.set_option("gat_sh_waves", 0)
     eng.clear_caches()
+
+if "planted" in what:
+    # a graph WITH locality (hierarchical planted communities, products-sized, native order): K = 256 aggregate under the knobs that
+    # decide how much of it reaches the L2s — rows per XCD run (policy: 2048 where locality > 0.5) and the column-block width
+    from gammagl_amd.layers import calc_gcn_norm
+    from gammagl_amd.synth import DATASETS, planted_pairs
+    n = DATASETS["products"][0]
+    s, d = planted_pairs(n, seed=0, device=dev)
+    loops = torch.arange(n, device=dev)
+    ei = torch.stack([torch.cat([s, loops]), torch.cat([d, loops])]).contiguous()
+    del s, d
+    w = calc_gcn_norm(ei, n).contiguous()
+    x = torch.randn(n, 256, device=dev)
+    print(f"planted graph: N={n} E={ei.shape[1]}", flush=True)
+    with torch.no_grad():
+        for run in (-1, 0, 256, 512, 1024, 2048, 4096, 8192, 16384):
+            eng.xcd_run_rows = run
+            eng.clear_caches()
+            gp = eng.graph_plan(ei, n)
+            eng.c_spmm_sum(ei, w, x)
+            line = f"xcd_run_rows={run:6d} (plan: {int(getattr(gp.fwd, 'xcd_run', 0) or 0):5d}):"
+            for cb in (32, 64, 128, 0):
+                eng.set_option("col_block", cb)
+                line += f"  col_block {cb:3d}: {ev(lambda: eng.c_spmm_sum(ei, w, x)):6.2f} ms"
+            eng.set_option("col_block", 64)
+            print(line, flush=True)
+        eng.xcd_run_rows = -1
+    eng.clear_caches()
