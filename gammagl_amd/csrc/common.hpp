@@ -123,7 +123,8 @@ struct Options {
   // static-shape sampler hop: count / flag + scan (+ clamp) as ONE launch each (single-pass chained scan).  Measured (round 5,
   // profiles/r5_sage_fused_scans.txt): 76 -> 63 launches per replayed step, but the same 0.17 ms for the two hops — the fused
   // kernels take the 13-33 us their look-back chains need where five 5-us launches stood.  OFF: no gain to set against a
-  // kernel that spins on its predecessors.
+  // kernel that spins on its predecessors (an A/B knob only: its look-back assumes lower-numbered blocks are resident or
+  // will be scheduled, and its slots are told apart by a tag of (seed, offset, scan, block) instead of being zeroed per hop).
   int64_t hop_fused_scans = 0;
   // the hub walk's side queue created with the device's greatest priority (big eager launches only: hubf32.hip).  OFF: the
   // isolated aggregate gains 1 % (13.75 -> 13.60 ms) but the products STEP nothing (75.46 vs 75.45 ms) and a partitioned step

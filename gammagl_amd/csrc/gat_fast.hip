@@ -424,6 +424,13 @@ template <int N> __device__ __forceinline__ float row_bcast(float v) {  // value
 }
 __device__ __forceinline__ float row_ror8(float v) { return dpp_mov<0x128>(v); }  // lane ^ 8 of the row
 
+__device__ __forceinline__ double row_ror8_f64(double v) {   // lane ^ 8 of the row, both halves of the double
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), 0x128, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x128, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
 // v[k] (k = 0..15) summed over the 16 lanes of the row; lane l returns the total of v[l]
 __device__ __forceinline__ float reduce_scatter16(const float (&v)[16], int li) {
   const bool b3 = li & 8, b2 = li & 4, b1 = li & 2, b0 = li & 1;
@@ -727,7 +734,12 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
   }
   const float4 st = *reinterpret_cast<const float4 *>(stats + (it.row * kShH + h) * 4);  // {er, m, rinv, dot}
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
-  float gs = 0.0f;
+  // g_er[i,h] = sum_p l'_p alpha_p (da_p - s_i) is a sum of up to 10^5 cancelling terms; with the stored s_i = <G_i, A_i> and f32
+  // sums the row's result carried the eps of `sum alpha = 1 + eps` (gat_bwd_dst2_kernel's comment: the hidden-layer kernels keep
+  // FOUR sums in double since round 5).  Round 6: the same four sums here — A = sum l' alpha da, B = sum l' alpha, S = sum alpha da,
+  // W = sum alpha, g_er = A - (S / W) B — after the full-size comparison with the transform-first kernels showed this walk's f32
+  // sum 1.5e-2 of a row's scale apart on 10^5-edge rows (profiles/r6_gat_fullsize_forms.txt).  stats.w is no longer read here.
+  double sA = 0.0, sB = 0.0, sS = 0.0, sW = 0.0;
   ShBlock b, nb;
   if (PF && (it.beg & ~(int64_t)3) < it.end) sh_block(col, it.beg & ~(int64_t)3, it.beg, it.end, nb);
   for (int64_t p0 = it.beg & ~(int64_t)3; p0 < it.end; p0 += 4) {
@@ -766,15 +778,22 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
       const float raw = (pr ? s1 : s0) + st.x;
       const float al = fexp(lrelu(raw, d.slope) - st.y) * st.z;
       if (DROP) da = (pick_word(rw, e + 2 * pr) >= d.drop_thresh) ? da * d.drop_scale : 0.0f;
-      const float ds = al * (da - st.w);
-      const float dv = raw > 0.0f ? ds : ds * d.slope;
-      gs += (pr ? okB : okA) ? dv : 0.0f;
+      const float alo = (pr ? okB : okA) ? al : 0.0f;
+      const float lal = raw > 0.0f ? alo : alo * d.slope;
+      sA += (double)(lal * da);
+      sB += (double)lal;
+      sS += (double)(alo * da);
+      sW += (double)alo;
     }
   }
-  gs += row_ror8(gs);
+  sA += row_ror8_f64(sA); sB += row_ror8_f64(sB); sS += row_ror8_f64(sS); sW += row_ror8_f64(sW);   // both edge parities of head h
   if (e == 0) {
-    if (it.is_chunk) pger[it.cid * kShH + h] = gs;
-    else ger[it.row * kShH + h] = gs;
+    if (it.is_chunk) {   // a hub row's chunk: the four sums, combined in chunk order by gat_bwd_dst_final4_kernel
+      double *pq = reinterpret_cast<double *>(pger) + (it.cid * kShH + h) * 4;
+      pq[0] = sA; pq[1] = sB; pq[2] = sS; pq[3] = sW;
+    } else {
+      ger[it.row * kShH + h] = sW > 0.0 ? (float)(sA - (sS / sW) * sB) : 0.0f;
+    }
   }
 }
 
@@ -813,7 +832,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
   }
   const float el_j = el[it.row * kShH + h];
   const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
-  float gl = 0.0f;
+  double gl = 0.0;   // (round 6: the row's sum of signed logit-gradient terms in double, like the destination walk's)
   // (ZLDS: the registers it frees also pay for the NEXT step's ids — requested before this step's gathers, so that a step
   //  waits for one memory round trip, its gathers', instead of two dependent ones)
   ShBlock b, fp, nb, nfp;  // fp: the block's FORWARD positions (dropout), fetched beside the column ids, not behind them
@@ -885,7 +904,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
       }
       const float ds = al * (da - st.w);
       const float dv = raw > 0.0f ? ds : ds * d.slope;
-      gl += ok ? dv : 0.0f;
+      gl += (double)(ok ? dv : 0.0f);
       wk[pr] = ok ? alk : 0.0f;
     }
     sh_accumulate<0>(wk[0], gv[0], acc);
@@ -893,20 +912,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     sh_accumulate<0>(wk[1], gv[2], acc);
     sh_accumulate<1>(wk[1], gv[3], acc);
   }
-  gl += row_ror8(gl);
+  gl += row_ror8_f64(gl);
   if (it.is_chunk) {
     if (act) {
 #pragma unroll
       for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(pacc + (it.cid * kShH + q) * F + kk) = acc[q];
     }
-    if (e == 0) pgel[it.cid * kShH + h] = gl;
+    if (e == 0) pgel[it.cid * kShH + h] = (float)gl;
     return;
   }
   if (act) {
 #pragma unroll
     for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(T + (it.row * kShH + q) * F + kk) = acc[q];
   }
-  if (e == 0) gel[it.row * kShH + h] = gl;
+  if (e == 0) gel[it.row * kShH + h] = (float)gl;
 }
 
 }  // namespace ggl
@@ -1196,8 +1215,9 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     ShDims d{};
     int rc = sh_dims(d, plan, F, slope, p_drop, rng_used);
     if (rc) return rc;
+    // (forward plan's partial: FOUR doubles per chunk and head since round 6 = 256 bytes per chunk: ggl_gat_sh_partial_bytes(n_chunks, 8))
     float *pger = plan->n_long > 0 ? static_cast<float *>(plan->partial) : nullptr;
-    GGL_REQUIRE(al16(x) && al16(G) && al16(stats) && al16(col), GGL_EINVAL, "shared-row GAT path needs 16-byte aligned buffers");
+    GGL_REQUIRE(al16(x) && al16(G) && al16(stats) && al16(col) && al16(pger), GGL_EINVAL, "shared-row GAT path needs 16-byte aligned buffers");
     const int64_t grid = ceil_div((d.n_chunks + d.N) * 16, (int64_t)kBlock);
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? plan->row_order : nullptr;
@@ -1230,8 +1250,8 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
                  plan->chunk_ptr, el, x, G, stats, ger, pger, rng_used, d);
     GGL_LAUNCH_CHECK();
     if (plan->n_long > 0) {
-      GGL_LAUNCH((gat_bwd_dst_final_kernel), gat_grid_for(plan->n_long * 8), kBlock, s, plan->long_rows, plan->chunk_ptr,
-                 (const float *)pger, ger, plan->n_long, (int64_t)8);
+      GGL_LAUNCH((gat_bwd_dst_final4_kernel), gat_grid_for(plan->n_long * 8), kBlock, s, plan->long_rows, plan->chunk_ptr,
+                 reinterpret_cast<const double *>(pger), ger, plan->n_long, (int64_t)8);
       GGL_LAUNCH_CHECK();
     }
   }

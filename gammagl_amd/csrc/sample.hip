@@ -654,7 +654,9 @@ __global__ __launch_bounds__(kBlock) void hop_count_scan_kernel(const int64_t *_
     v[q] = (uint32_t)k;
     tsum += v[q];
   }
-  uint64_t p = chained_exclusive(tsum, state, ((unsigned long long)rng[1] << 2) | 1ull);
+  // (tag base = scan id + the stream's offset AND its seed: after a reseed / state restore the offset repeats, and the caching
+  //  allocator hands back the same workspace — a tag without the seed would accept a stale predecessor slot; round-5 advisor)
+  uint64_t p = chained_exclusive(tsum, state, ((((unsigned long long)rng[1] << 2) | 1ull) ^ ((unsigned long long)rng[0] * 0xD6E8FEB86659FD93ull)));
 #pragma unroll
   for (int q = 0; q < kScanIpt; ++q) {
     const int64_t i = i0 + q;
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void hop_flag_scan_kernel(const int64_t *__
     v[q] = f;
     tsum += f;
   }
-  uint32_t p = chained_exclusive(tsum, state, ((unsigned long long)rng[1] << 2) | 2ull);
+  uint32_t p = chained_exclusive(tsum, state, ((((unsigned long long)rng[1] << 2) | 2ull) ^ ((unsigned long long)rng[0] * 0xD6E8FEB86659FD93ull)));
 #pragma unroll
   for (int q = 0; q < kScanIpt; ++q) {
     const int64_t t = i0 + q;

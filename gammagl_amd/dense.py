@@ -39,6 +39,34 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw
 
 
+class _MatmulFn(torch.autograd.Function):
+    """x @ w for node features x [N, in] and a weight w [in, out] (GATConv's `tlx.matmul(x, self.w)`, gat_conv.py:99): the weight
+    gradient x^T g is a reduction over N = 10^5 .. 10^6 nodes — taken through `wgrad` (the node axis split into slabs, partial
+    products summed: a two-level sum) instead of ONE GEMM with an N-long accumulation per output element.  Round 6: with
+    bench.py's tuned GEMM selection the single-GEMM form picked kernels whose sequential f32 accumulation over 233 k terms left the
+    GAT model's weight gradients 2.5e-4 .. 1.2e-3 from a float64 evaluation (the default heuristics: 1.5e-5); the slab form does
+    not depend on the selection."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g @ w.t() if ctx.needs_input_grad[0] else None
+        gw = wgrad(x, g.contiguous()) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def node_matmul(x, w):
+    """x @ w with the weight gradient as a slab-split sum (see _MatmulFn) where x is a contiguous [N, in] float matrix."""
+    if x.dim() == 2 and x.is_contiguous() and w.dim() == 2 and x.is_floating_point() and x.dtype == w.dtype:
+        return _MatmulFn.apply(x, w)
+    return x @ w
+
+
 class Linear(torch.nn.Linear):
     """torch.nn.Linear (same parameters / state_dict) whose weight gradient uses `wgrad` for 2-D inputs."""
 

@@ -288,6 +288,10 @@ class PartitionedGraph:
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
         return out, work
 
+    def release(self):
+        """Undo what constructing this graph changed process-wide (the GGL_DIST_EXACT=0 switch of `exact_long_rows`)."""
+        _restore_dist_exact(self)
+
     def aggregate(self, h, bias=None, relu=False, p_drop=0.0, training=True, halo_included=False):
         """out[i] = dropout(relu(sum_{j->i} w_ij h[j] + bias)) for the local rows i (autograd-aware).  The
         epilogue (gcn_conv.py:105-106, models/gcn.py:55-59) rides on the store of the LAST edge block added:
@@ -303,6 +307,13 @@ class PartitionedGraph:
         return _HaloAggregate.apply(h, self, bias, bool(relu), p, bool(halo_included))
 
 
+def _restore_dist_exact(pg):
+    before = getattr(pg.eng, "_exact_before_dist", None)
+    if before is not None:
+        pg.eng.lib.ggl_set_option(b"exact_long_rows", int(before))
+        del pg.eng._exact_before_dist
+
+
 def _apply_dist_exact(pg):
     """A/B switch (GGL_DIST_EXACT=0): partitioned aggregates walk their f32 hub rows CHUNKED.  A row of a partitioned graph is
     the sum of two launches — its local-source edges, then its halo-source edges added on top — so the reference's serial
@@ -312,7 +323,15 @@ def _apply_dist_exact(pg):
     a partitioned graph with a communicator is constructed — a rank is a process, and the option is process-wide (round 4
     flipped it around every forward / backward, which other threads' launches could observe half-way)."""
     if pg.comm and not DIST_EXACT:
+        # process-wide: remembered so that release() can put it back (round-5 advisor: every later non-partitioned aggregate
+        # of the process, and bench.py's parity leg, silently lost the reference-order hub walk)
+        if not hasattr(pg.eng, "_exact_before_dist"):
+            pg.eng._exact_before_dist = int(pg.eng.lib.ggl_get_option(b"exact_long_rows"))
         pg.eng.lib.ggl_set_option(b"exact_long_rows", 0)
+        import warnings
+
+        warnings.warn("GGL_DIST_EXACT=0: library option exact_long_rows set to 0 for this process until "
+                      "PartitionedGraph.release() (partitioned hub rows walk chunked)", stacklevel=3)
 
 
 class _HaloAggregate(torch.autograd.Function):

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import engine as _engine
-from .dense import Linear, _LinearFn
+from .dense import Linear, _LinearFn, node_matmul
 from .sampler import Block
 from .mpops import (bspmm, gspmm, unsorted_segment_max, unsorted_segment_mean,  # noqa: F401
                     unsorted_segment_sum, use_ext)
@@ -350,7 +350,7 @@ class GATConv(MessagePassing):
         return x + self.bias if self.bias is not None else x
 
     def forward(self, x, edge_index, num_nodes=None):
-        x = (x @ self.w).reshape(-1, self.heads, self.out_channels)
+        x = node_matmul(x, self.w).reshape(-1, self.heads, self.out_channels)
         node_src, node_dst = edge_index[0, :], edge_index[1, :]
         feat = torch.cat((x[node_src], x[node_dst]), dim=-1)
         e = (feat * self.att).sum(dim=-1)
@@ -388,7 +388,7 @@ class FusedGATConv(GATConv):
         pad = (-C) % 4 if C >= 8 else 0
         if pad:  # e.g. 41 classes per head: 44 channels inside the GEMM keep the kernels on 16-byte slices
             w = torch.nn.functional.pad(w.reshape(-1, H, C), (0, pad)).reshape(-1, H * (C + pad))
-        x = (x @ w).reshape(-1, H, C + pad)
+        x = node_matmul(x, w).reshape(-1, H, C + pad)
         el = (x[:, :, :C] * self.att[:, :, :C]).sum(dim=-1)   # source term  a_src . x_j
         er = (x[:, :, :C] * self.att[:, :, C:]).sum(dim=-1)   # destination term a_dst . x_i
         x = _engine(x).gat_fused(edge_index, el, er, x, self.negative_slope, num_nodes=num_nodes,

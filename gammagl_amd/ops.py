@@ -1267,7 +1267,10 @@ class Engine:
                 gel = torch.empty((N, H), dtype=torch.float32, device=dev)
                 T = torch.empty((N, H, Cp), dtype=torch.float32, device=dev)
                 bwd = gp.bwd
-                part_f = eng._partial(gp.fwd, torch.float32, H, False, dev)
+                # forward plan's partial: four doubles per hub chunk and head (the destination walk's row sums, round 6)
+                part_f = None
+                if gp.fwd.n_long > 0:
+                    part_f = torch.empty(eng.lib.ggl_gat_sh_partial_bytes(gp.fwd.n_chunks, 8) + 16, dtype=torch.uint8, device=dev)
                 part_t = None
                 if bwd.n_long > 0:
                     part_t = torch.empty(eng.lib.ggl_gat_sh_partial_bytes(bwd.n_chunks, Cp) + 16, dtype=torch.uint8,
@@ -1279,8 +1282,12 @@ class Engine:
                                                   _ptr(gyp), Cp, ctx.slope, ctx.p_drop, _ptr(ctx.rng_used), _ptr(ger),
                                                   _ptr(T), _ptr(gel), eng._stream(dev)))
                 gx = torch.einsum("nhc,fhc->nf", T[:, :, :C], Wr) + gel @ U.t() + ger @ V.t()
-                gU, gV = x.t() @ gel, x.t() @ ger                           # [F, H]
-                gW = (A.view(N, H * F).t() @ gyh).view(H, F, C).permute(1, 0, 2) \
+                # reductions over the N nodes: slab-split two-level sums (dense.wgrad), not one GEMM with an N-long accumulation per
+                # element (round 6: a tuned kernel choice for the latter left these 1e-3 from a float64 evaluation)
+                from .dense import wgrad
+
+                gU, gV = wgrad(x, gel), wgrad(x, ger)                       # x^T gel, x^T ger: [F, H]
+                gW = wgrad(A.view(N, H * F), gyh).view(H, F, C).permute(1, 0, 2) \
                     + gU.unsqueeze(-1) * a_src + gV.unsqueeze(-1) * a_dst
                 gatt = torch.cat([torch.einsum("fh,fhc->hc", gU, Wr), torch.einsum("fh,fhc->hc", gV, Wr)], dim=-1)
                 return None, gx, gW.reshape(F, H * C), gatt.unsqueeze(0), None, None

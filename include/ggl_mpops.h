@@ -48,7 +48,7 @@ extern "C" {
  *   doubles per chunk and head; ggl_segplan_t.xcd_run_rows < 0 is a hint (see the field); + ggl_sample_hop_ex; options
  *   hub_one_launch, hub_priority, hub_pipe, maxbwd_mask*, gat_sh_waves, hop_fused_scans.  No struct change. */
 /* 9 (round 6): + ggl_policy_maxbwd_form (the gspmm-max backward's form gated on the winner mask's footprint; option
- *   maxbwd_mask_kmax), + ggl_spmm_col_blocks_plan (128-column blocks for plans whose node order carries locality), option gat_sh_pk.
+ *   maxbwd_mask_kmax), ggl_gat_sh_bwd's forward-plan partial holds four doubles per chunk and head, + ggl_spmm_col_blocks_plan (128-column blocks for plans whose node order carries locality), option gat_sh_pk.
  *   No struct change. */
 #define GGL_ABI_VERSION 9
 
@@ -428,7 +428,8 @@ int ggl_gat_fast_bwd(const ggl_segplan_t *plan, const int32_t *col, const ggl_se
  *   ggl_gat_sh_bwd : ger[N,8] (destination walk: G[N,8,F] = dL/dA and stats[N,8,4] = {er, m, 1/(den+1e-16),
  *                    <G_ih, A_ih>} per row, x gathered) and T[N_src,8,Cp] = sum_i alpha_ijh gy_i, gel[N_src,8]
  *                    (source walk: z[N_src,8,Cp] = the rows' own x_j W_h, gy[N,Cp] gathered); partial buffers:
- *                    plan->partial >= n_chunks * 8 floats, planT->partial = ggl_gat_sh_partial_bytes(n_chunksT, Cp) */
+ *                    plan->partial >= n_chunks * 8 * 4 DOUBLES (ABI 9: the destination walk keeps four row sums in double; ggl_gat_sh_partial_bytes(
+ *                    n_chunks, 8) is enough), planT->partial = ggl_gat_sh_partial_bytes(n_chunksT, Cp) */
 int ggl_gat_sh_supported(int64_t H, int64_t F, int64_t C);
 size_t ggl_gat_sh_partial_bytes(int64_t n_chunks, int64_t F);
 int ggl_gat_sh_fwd(const ggl_segplan_t *plan, const int32_t *col, const float *el, const float *er, const float *x,

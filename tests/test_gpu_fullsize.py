@@ -125,18 +125,78 @@ def test_reddit_size_gat_output_layer_headmean(eng, dev, reddit):
             res.append([y.detach(), xa.grad, fg.w.grad.clone(), fg.att.grad.clone()])
     finally:
         eng.gat_fast = True
-    # round 6: the row-scale criterion (rounds 3-5: 3e-4 of the tensor's maximum) — y / gx at 2e-5; the parameter gradients are
-    # f32 sums over 233 k nodes and 114.8 M edges on both sides (each ~6e-5 from the float64 truth at the subgraph size,
-    # test_gpu_refsize.py): 2e-4 between two such evaluations.  The path's CORRECTNESS is pinned in test_gpu_refsize.py against
-    # the reference ops and float64; this test holds the two HIP paths together at the full edge count.
+    # The partner here — 8 x 44 padded channels = 352 columns — is NOT on the fast kernels (H C <= 256): it is the round-1 generic
+    # pair with an [E, H, 2] alpha / de buffer and f32 row sums, whose own gradients sit ~1e-4 of the tensor's maximum from an exact
+    # evaluation on 10^5-edge rows.  So: the OUTPUT at the row-scale criterion (2e-5; measured 2.2e-6), the gradients at 3e-4 of the
+    # tensor's maximum as in rounds 3-5 (measured: gx 1.2e-4, gW 4.3e-5, gatt 2.3e-4 of the maximum; round 6 probed both packed /
+    # unpacked forms of the head-mean walks and its double row sums against this partner: the differences did not move by a bit,
+    # i.e. they are the partner's — profiles/r6_gat_fullsize_forms.txt).  The head-mean path's CORRECTNESS is pinned against the
+    # reference ops and float64 in test_gpu_refsize.py (3.6 M edges) and below at 14 M edges (rows of 19 k edges).
     from oracle import parity
 
-    for a, b, nm in zip(res[0], res[1], ("y", "gx", "gW", "gatt")):
-        a2, b2 = (t.reshape(t.shape[0], -1) if t.dim() > 1 else t.reshape(1, -1) for t in (a, b))
-        r = parity.report(a2, b2, tol=(2e-5 if nm in ("y", "gx") else 2e-4), floor_min=float(b2.abs().mean()))
-        print(f"full-size head-mean vs transform-first {nm}: {r['max_rel_err']:.3e}")
-        assert r["ok"], (nm, r)
+    r = parity.report(res[0][0], res[1][0], tol=2e-5)
+    print(f"full-size head-mean vs transform-first y: row-scale {r['max_rel_err']:.3e}")
+    assert r["ok"], r
+    for a, b, nm in zip(res[0][1:], res[1][1:], ("gx", "gW", "gatt")):
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        print(f"full-size head-mean vs transform-first {nm}: {err / scale:.3e} of the tensor's maximum")
+        assert err <= 3e-4 * scale + 1e-6, (nm, err, scale)
     assert bool(torch.isfinite(res[0][0]).all())
+
+
+def test_reddit_eighth_headmean_layer_vs_float64(eng, dev):
+    """The head-mean output layer (ggl_gat_sh_*) against GROUND TRUTH at the largest size a float64 evaluation fits in 288 GB:
+    every 8th edge of the Reddit-sized graph (14.4 M edges, hub rows of 19 k edges, hub chunks of 1024) — the layer in float64
+    (oracle/parity.py gat_conv_lean: torch scatters) and, as the yardstick, the same composition in float32 (torch ops, none of this
+    library's kernels): err(HIP) <= max(1e-5, 2 err(torch f32)) for y, gx, gW, gatt, gbias."""
+    if not _big(dev):
+        pytest.skip("needs > 100 GB of HBM")
+    from gammagl_amd import layers
+    from gammagl_amd.synth import DATASETS, rmat_graph
+    from oracle import parity
+
+    n, e, _, _ = DATASETS["reddit"]
+    ei = rmat_graph(n, e, seed=0, device=dev)[:, ::8].contiguous()
+    F, H, C = 64, 8, 41
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.randn(n, F, generator=g, device=dev)
+    W = torch.randn(F, H * C, generator=g, device=dev) * 0.15
+    att = torch.randn(1, H, 2 * C, generator=g, device=dev) * 0.2
+    bias = torch.randn(C, generator=g, device=dev) * 0.1
+    go = torch.randn(n, C, generator=g, device=dev)
+    # (edges whose logit is within 1e-4 of LeakyReLU's kink are left out: oracle/parity.py kink_free_edges — at this size a few
+    #  dozen f32 logits fall on the other side of 0 than their float64 values, and BOTH f32 evaluations then sit 7e-2 from the
+    #  "truth" by the same jump)
+    ei, dropped = parity.kink_free_edges(ei, x, W, att, H, C)
+    print(f"14 M-edge test: {dropped} near-kink edges of {int(ei.shape[1]) + dropped} left out")
+    layer = layers.FusedGATConv(F, C, heads=H, concat=False).to(dev)
+    with torch.no_grad():
+        layer.w.copy_(W), layer.att.copy_(att), layer.bias.copy_(bias)
+    assert eng.gat_headmean_supported(H, F, C)
+    xa = x.clone().requires_grad_(True)
+    y = layer(xa, ei, n)
+    y.backward(go)
+    hip = (y.detach(), xa.grad, layer.w.grad, layer.att.grad, layer.bias.grad)
+    eng.clear_caches()
+
+    def composed(dtype):
+        ps = [t.detach().to(dtype).requires_grad_(True) for t in (x, W, att, bias)]
+        out = parity.gat_conv_lean(*ps, ei, n, H, C, concat=False, slope=0.2)
+        out.backward(go.to(dtype))
+        res_ = [out.detach()] + [p.grad for p in ps]
+        del out, ps
+        torch.cuda.empty_cache()
+        return res_
+
+    f32 = composed(torch.float32)
+    truth = composed(torch.float64)
+    names = ("y", "gx", "gW", "gatt", "gbias")
+    e_hip = parity.layer_errors_vs_truth(truth, hip, names, zero_mean_rows=("gx",))
+    e_f32 = parity.layer_errors_vs_truth(truth, f32, names, zero_mean_rows=("gx",))
+    for k in names:
+        print(f"head-mean GAT at 14 M edges {k}: err vs fp64 truth — HIP {e_hip[k]:.3e}, torch f32 composition {e_f32[k]:.3e}")
+    for k in names:
+        assert e_hip[k] <= max(1e-5, 2.0 * e_f32[k]), (k, e_hip, e_f32)
 
 
 def test_products_size_sampler_and_sage_blocks(eng, dev):

@@ -104,3 +104,133 @@ if "planted" in what:
             print(line, flush=True)
         eng.xcd_run_rows = -1
     eng.clear_caches()
+
+if "gatfull" in what:
+    # full Reddit-sized graph, output layer 64 -> 8 x 41 (default init, no dropout): head-mean path with gat_sh_pk = 1 / 0 and the
+    # transform-first kernels, pairwise — which differences are the packed form's and which are two f32 evaluations' own
+    from gammagl_amd import layers
+    from oracle import parity
+    n, e, _, _ = DATASETS["reddit"]
+    ei = rmat_graph(n, e, seed=0, device=dev)
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(n, 64, generator=g, device=dev)
+    go = torch.randn(n, 41, generator=g, device=dev)
+    torch.manual_seed(0)
+    fg = layers.FusedGATConv(64, 41, heads=8, concat=False).to(dev)
+    res = {}
+    for name, fast, pk in (("headmean pk=1", True, 1), ("headmean pk=0", True, 0), ("transform-first", False, 1)):
+        eng.gat_fast = fast; eng.set_option("gat_sh_pk", pk)
+        for p_ in fg.parameters(): p_.grad = None
+        xa = x.clone().requires_grad_(True)
+        y = fg(xa, ei, n); y.backward(go)
+        res[name] = [y.detach(), xa.grad, fg.w.grad.clone(), fg.att.grad.clone()]
+    eng.gat_fast = True; eng.set_option("gat_sh_pk", 1)
+    names = list(res)
+    for i in range(3):
+        for j in range(i + 1, 3):
+            line = f"{names[i]} vs {names[j]}:"
+            for a, b, nm in zip(res[names[i]], res[names[j]], ("y", "gx", "gW", "gatt")):
+                a2, b2 = (t.reshape(t.shape[0], -1) if t.dim() > 1 else t.reshape(1, -1) for t in (a, b))
+                r = parity.report(a2, b2, tol=1.0, floor_min=float(b2.abs().mean()))
+                line += f"  {nm} row-scale {r['max_rel_err']:.2e} (abs {r['max_abs_err']:.2e}, max|b| {float(b2.abs().max()):.2e}, mean|b| {float(b2.abs().mean()):.2e})"
+            print(line, flush=True)
+    eng.clear_caches()
+
+if "gatdbg" in what:
+    from gammagl_amd import layers
+    n, e, _, _ = DATASETS["reddit"]
+    for stride in (64, 8, 1):
+        ei = rmat_graph(n, e, seed=0, device=dev)[:, ::stride].contiguous()
+        gp = eng.graph_plan(ei, n)
+        print(f"stride {stride}: E={ei.shape[1]} fwd n_long={gp.fwd.n_long} n_chunks={gp.fwd.n_chunks} chunk={gp.fwd.chunk} | bwd n_long={gp.bwd.n_long} n_chunks={gp.bwd.n_chunks}", flush=True)
+        x = torch.randn(n, 64, device=dev, requires_grad=True)
+        fg = layers.FusedGATConv(64, 41, heads=8, concat=False).to(dev)
+        y = fg(x, ei, n); torch.cuda.synchronize(); print("  fwd ok", flush=True)
+        y.sum().backward(); torch.cuda.synchronize(); print("  bwd ok", float(x.grad.abs().max()), flush=True)
+        eng.clear_caches()
+
+if "gatacc" in what:
+    # WHERE the head-mean layer's gradient error at 14 M edges comes from: its internal T / gel / ger (and A, den of the forward)
+    # against float64 evaluations of the same quantities
+    import ctypes
+    from gammagl_amd.ops import _ptr
+    n, e, _, _ = DATASETS["reddit"]
+    stride = int(os.environ.get("STRIDE", "8"))
+    ei = rmat_graph(n, e, seed=0, device=dev)[:, ::stride].contiguous()
+    F, H, C = 64, 8, 41
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.randn(n, F, generator=g, device=dev)
+    W = torch.randn(F, H * C, generator=g, device=dev) * 0.15
+    att = torch.randn(1, H, 2 * C, generator=g, device=dev) * 0.2
+    gy = torch.randn(n, C, generator=g, device=dev)
+    src, dst = ei[0], ei[1]
+    # ---- float64 truths of the intermediates
+    xd, Wd, ad = x.double(), W.double(), att.double()
+    zd = (xd @ Wd).view(n, H, C)
+    eld, erd = (zd * ad[:, :, :C]).sum(-1), (zd * ad[:, :, C:]).sum(-1)
+    raw = eld[src] + erd[dst]
+    ed = torch.nn.functional.leaky_relu(raw, 0.2)
+    md = torch.full((n, H), -float("inf"), dtype=torch.float64, device=dev).scatter_reduce(0, dst.view(-1, 1).expand_as(ed), ed, reduce="amax")
+    exd = torch.exp(ed - md[dst]); dend = torch.zeros(n, H, dtype=torch.float64, device=dev).index_add_(0, dst, exd)
+    alpha = exd / (dend[dst] + 1e-16)                                    # [E, H]
+    gyh = gy.double() / H
+    T_true = torch.zeros(n, H, C, dtype=torch.float64, device=dev)
+    da = torch.empty_like(alpha)
+    for h in range(H):
+        T_true[:, h, :].index_add_(0, src, alpha[:, h:h + 1] * gyh[dst])
+        da[:, h] = (gyh[dst] * zd[src, h, :]).sum(-1)                     # <gy_i / H, z_jh>
+    s = torch.zeros(n, H, dtype=torch.float64, device=dev).index_add_(0, dst, alpha * da)
+    de = alpha * (da - s[dst]) * torch.where(raw > 0, 1.0, 0.2)
+    gel_true = torch.zeros(n, H, dtype=torch.float64, device=dev).index_add_(0, src, de)
+    ger_true = torch.zeros(n, H, dtype=torch.float64, device=dev).index_add_(0, dst, de)
+    del exd, raw, ed
+    # ---- the library's pieces (GATHeadMean.forward / backward, ops.py)
+    gp = eng.graph_plan(ei, n)
+    Wr = W.view(F, H, C); a_src, a_dst = att[0, :, :C], att[0, :, C:]
+    U, V = (Wr * a_src).sum(-1), (Wr * a_dst).sum(-1)
+    el, er = (x @ U).contiguous(), (x @ V).contiguous()
+    rowmax = torch.empty((n, H), device=dev); den = torch.empty((n, H), device=dev); A = torch.empty((n, H, F), device=dev)
+    part = torch.empty(eng.lib.ggl_gat_sh_partial_bytes(gp.fwd.n_chunks, F) + 16, dtype=torch.uint8, device=dev) if gp.fwd.n_long else None
+    cs = gp.fwd.c_struct(part)
+    eng._check(eng.lib.ggl_gat_sh_fwd(ctypes.byref(cs), _ptr(gp.col), _ptr(el), _ptr(er), _ptr(x), F, 0.2, 0.0, None, _ptr(rowmax), _ptr(A), _ptr(den), eng._stream(dev)))
+    Cp = 44
+    Wst = Wr.permute(1, 0, 2).reshape(H * F, C)
+    gyh32 = gy / H
+    gyp = torch.nn.functional.pad(gyh32, (0, Cp - C)).contiguous()
+    G = (gyh32 @ Wst.t()).view(n, H, F).contiguous()
+    stats = torch.empty((n, H, 4), device=dev)
+    eng._check(eng.lib.ggl_gat_sh_stats(_ptr(er), _ptr(rowmax), _ptr(den), _ptr(G), _ptr(A), n, F, _ptr(stats), eng._stream(dev)))
+    z = torch.nn.functional.pad((x @ W).view(n, H, C), (0, Cp - C)).contiguous()
+    ger = torch.empty((n, H), device=dev); gel = torch.empty((n, H), device=dev); T = torch.empty((n, H, Cp), device=dev)
+    bwd = gp.bwd
+    part_f = torch.empty(eng.lib.ggl_gat_sh_partial_bytes(gp.fwd.n_chunks, 8) + 16, dtype=torch.uint8, device=dev) if gp.fwd.n_long else None
+    part_t = torch.empty(eng.lib.ggl_gat_sh_partial_bytes(bwd.n_chunks, Cp) + 16, dtype=torch.uint8, device=dev) if bwd.n_long else None
+    cs, csT = gp.fwd.c_struct(part_f), bwd.c_struct(part_t)
+    eng._check(eng.lib.ggl_gat_sh_bwd(ctypes.byref(cs), _ptr(gp.col), ctypes.byref(csT), _ptr(gp.colT), None, _ptr(el), _ptr(x), F, _ptr(G), _ptr(stats), _ptr(z),
+                                      _ptr(gyp), Cp, 0.2, 0.0, None, _ptr(ger), _ptr(T), _ptr(gel), eng._stream(dev)))
+    torch.cuda.synchronize()
+    from oracle import parity
+    def err(a, t, nm):
+        a2, t2 = a.double().reshape(a.shape[0], -1), t.reshape(t.shape[0], -1)
+        r = parity.report(a2, t2, tol=1.0, floor_min=float(t2.abs().mean()))
+        print(f"  {nm:28s} row-scale err {r['max_rel_err']:.3e}  abs {r['max_abs_err']:.3e}  mean|truth| {float(t2.abs().mean()):.3e}", flush=True)
+    print(f"stride {stride}: E={ei.shape[1]}, longest row {int(gp.fwd.counts().max())}", flush=True)
+    err(el, eld, "el = x (W a_src)"); err(er, erd, "er")
+    err(rowmax, md, "rowmax"); err(den, dend, "den")
+    s32 = stats[:, :, 3]
+    err(s32, s, "s_i = <G_i, A_i> (stats.w)")
+    err(T[:, :, :C], T_true, "T (source walk)"); err(gel, gel_true, "gel (source walk)"); err(ger, ger_true, "ger (destination walk)")
+    # the same logit gradients by plain f32 torch ops (the yardstick)
+    raw32 = el[src] + er[dst]; e32 = torch.nn.functional.leaky_relu(raw32, 0.2)
+    m32 = torch.full((n, H), -float("inf"), device=dev).scatter_reduce(0, dst.view(-1, 1).expand_as(e32), e32, reduce="amax")
+    ex32 = torch.exp(e32 - m32[dst]); den32 = torch.zeros(n, H, device=dev).index_add_(0, dst, ex32)
+    al32 = ex32 / (den32[dst] + 1e-16)
+    da32 = torch.empty_like(al32)
+    for h in range(H):
+        da32[:, h] = (gyh32[dst] * z[src, h, :C]).sum(-1)
+    s_32 = torch.zeros(n, H, device=dev).index_add_(0, dst, al32 * da32)
+    de32 = al32 * (da32 - s_32[dst]) * torch.where(raw32 > 0, 1.0, 0.2)
+    err(torch.zeros(n, H, device=dev).index_add_(0, src, de32), gel_true, "gel, plain torch f32")
+    err(torch.zeros(n, H, device=dev).index_add_(0, dst, de32), ger_true, "ger, plain torch f32")
+    err(s_32, s, "s_i, plain torch f32")
+    eng.clear_caches()
