@@ -555,7 +555,9 @@ struct ShDims {
   GatItem it;                                                                                    \
   if (!gat_item(gd, rowptr, row_order, long_rows, chunk_ptr, item, it)) return;                  \
   const int e = li >> 3, h = li & 7;                                                             \
-  const bool act = 4 * li < (int)d.F; /* channel lanes past the row width idle along */          \
+  const bool act = 4 * li < (int)d.F; /* channel lanes past the row width idle along: they gather columns 0-3 again (kk = 0) \
+     instead of being zero-filled — 16 v_mov + an exec-mask dance per 4-edge step (round 6) — which is harmless because the row's \
+     constant operand IS zero-filled for them (their dots vanish) and nothing they accumulate is stored */ \
   const int kk = act ? 4 * li : 0
 
 // pass 0: m[i,h] = max_p LeakyReLU(el[col[p],h] + er[i,h])   (-FLT_MAX for an empty row: unsorted_segment_max)
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void gat_sh_fwd_kernel(
     }
     float4 xv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xv[u] = act ? *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk);   // (idle channel lanes re-read columns 0-3: kk = 0; their sums are never stored)
     // this weight lane's two edges of the block: u = e and u = e + 2
     const int32_t cA = e ? b.c[1] : b.c[0], cB = e ? b.c[3] : b.c[2];
     const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(kBlock) void gat_sh_bwd_dst_kernel(
     }
     float4 xv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xv[u] = act ? *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + (int64_t)b.c[u] * F + kk);   // (idle channel lanes re-read columns 0-3: kk = 0; their sums are never stored)
     const int32_t cA = e ? b.c[1] : b.c[0], cB = e ? b.c[3] : b.c[2];
     const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
     const float s0 = el[(int64_t)cA * kShH + h], s1 = el[(int64_t)cB * kShH + h];
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     }
     float4 gv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) gv[u] = act ? *reinterpret_cast<const float4 *>(gy + (int64_t)b.c[u] * F + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; ++u) gv[u] = *reinterpret_cast<const float4 *>(gy + (int64_t)b.c[u] * F + kk);   // (idle channel lanes: kk = 0; z' = 0 there, so their dots are 0 and their T is never stored)
     const int32_t cA = e ? b.c[1] : b.c[0], cB = e ? b.c[3] : b.c[2];
     const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
     const float4 st0 = *reinterpret_cast<const float4 *>(stats + ((int64_t)cA * kShH + h) * 4);

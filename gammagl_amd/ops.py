@@ -1457,8 +1457,15 @@ class Engine:
         return st
 
     def reseed(self, seed=None):
-        """Forget the fused-dropout RNG state (the next use draws a new seed from torch's generator)."""
+        """Forget the fused-dropout RNG state (the next use draws a new seed from torch's generator) — of this engine AND, for
+        a product engine, of the C++ operator library (torch.ops.ggl keeps its own counter stream; since round 6 a one-rank
+        training step takes that route, dist._default_route, so a reseed that skipped it was no reseed)."""
         self._rng.clear()
+        if getattr(self, "is_product", False):
+            from . import cpp_ops
+
+            if cpp_ops._loaded:
+                torch.ops.ggl.reseed()
         if seed is not None:
             torch.manual_seed(seed)
 

@@ -420,3 +420,32 @@ def test_one_rank_training_step_takes_the_cpp_route_and_equals_the_ctypes_engine
     assert res["cpp"][0] == res["ctypes"][0]
     for a, b in zip(res["cpp"][1], res["ctypes"][1]):
         assert torch.equal(a, b)
+
+
+def test_reseed_reaches_the_cpp_route_dropout_stream(cpp):
+    """Engine.reseed() of a product engine also resets torch.ops.ggl's dropout counter stream: two one-rank training runs
+    (dropout ON, the cpp route) from the same seeds are bit-identical — round 6: with the step on the operator library a reseed
+    that only cleared the ctypes engine's state left the second run on a different mask stream."""
+    import gammagl_amd
+    from gammagl_amd import dist as gdist
+    from gammagl_amd.layers import add_self_loops, calc_gcn_norm
+
+    eng = gammagl_amd.host_engine()
+    g = torch.Generator().manual_seed(5)
+    N = 200
+    ei = add_self_loops(torch.randint(0, N, (2, 3000), generator=g), N)
+    w = calc_gcn_norm(ei, N).contiguous()
+    pg = gdist.PartitionedGraph(ei, w, N, eng=eng)
+    assert pg.route == "cpp"
+    x = torch.randn(N, 16, generator=g)
+    y = torch.randint(0, 5, (N,), generator=g)
+    idx = torch.arange(0, N, 2)
+    runs = []
+    for _ in range(2):
+        eng.reseed(77)
+        tr = gdist.DistGCNTrainer(pg, 16, 32, 5, num_layers=3, drop_rate=0.5, seed=0, device="cpu")
+        losses = [float(tr.step(x, y, idx, int(idx.numel()))) for _ in range(3)]
+        runs.append((losses, [p.detach().clone() for p in tr.net.parameters()]))
+    assert runs[0][0] == runs[1][0], runs
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
