@@ -234,3 +234,22 @@ if "gatacc" in what:
     err(torch.zeros(n, H, device=dev).index_add_(0, dst, de32), ger_true, "ger, plain torch f32")
     err(s_32, s, "s_i, plain torch f32")
     eng.clear_caches()
+
+if "arxivchunk" in what:
+    # arxiv-sized graph: the K = 256 aggregate under different long-row thresholds (hub walk vs row walk balance)
+    from gammagl_amd.layers import calc_gcn_norm
+    n, e, _, _ = DATASETS["arxiv"]
+    ei = rmat_graph(n, e, seed=0, device=dev)
+    w = calc_gcn_norm(ei, n).contiguous()
+    old = eng.chunk
+    with torch.no_grad():
+        for K in (256, 128, 48):
+            x = torch.randn(n, K, device=dev)
+            line = f"arxiv K={K}:"
+            for chunk in (0, 128, 256, 512, 1024, 2048, 4096):
+                eng.chunk = chunk; eng.clear_caches()
+                gp = eng.graph_plan(ei, n)
+                eng.c_spmm_sum(ei, w, x); eng.c_spmm_sum(ei, w, x)
+                line += f"  chunk {chunk if chunk else 'auto(' + str(gp.fwd.chunk) + ')'}: {ev(lambda: eng.c_spmm_sum(ei, w, x), 20) * 1e3:6.1f} us (n_long {gp.fwd.n_long})"
+            print(line, flush=True)
+    eng.chunk = old; eng.clear_caches()
