@@ -1272,7 +1272,14 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
     GGL_REQUIRE(grid < ((int64_t)1 << 31), GGL_EINVAL, "too many rows for one launch");
     const int32_t *order = options().row_order ? planT->row_order : nullptr;
     const bool pk = options().gat_sh_pk != 0 && options().gat_sh_zlds != 0;
-    if (pk && d.drop_thresh && options().gat_sh_waves >= 4)   // (A/B: built for 4 wavefronts per SIMD — 128 registers + 12 spilled values)
+    if (options().gat_sh_pk != 0 && options().gat_sh_zlds == 0) {   // A/B: packed pair dots with the row's z_j pairs in REGISTERS (no LDS slots)
+      if (d.drop_thresh)
+        GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 1, false, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                   planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+      else
+        GGL_LAUNCH((gat_sh_bwd_src_kernel<false, 1, false, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                   planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    } else if (pk && d.drop_thresh && options().gat_sh_waves >= 4)   // (A/B: built for 4 wavefronts per SIMD — 128 registers + 12 spilled values)
       GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 4, true, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
                  planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
     else if (pk && d.drop_thresh)

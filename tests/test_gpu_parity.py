@@ -820,9 +820,11 @@ def test_minibatch_step_captures_into_one_hipgraph(eng, dev):
 def test_gat_headmean_walk_forms(eng, dev):
     """The round-5 forms of the head-mean walks (z_j in LDS slots + ids requested a step ahead: options gat_sh_zlds /
     gat_sh_prefetch, on by default) and the round-4 forms they replace: the same test either way."""
-    with pc.option(eng, "gat_sh_zlds", 0), pc.option(eng, "gat_sh_prefetch", 0):
+    with pc.option(eng, "gat_sh_zlds", 0), pc.option(eng, "gat_sh_prefetch", 0):     # packed pair dots, z_j pairs in registers (A/B)
         test_gat_headmean_layer_aggregate_then_transform(eng, dev)
     with pc.option(eng, "gat_sh_pk", 0):     # round 5's dots + 16-value reduce-scatter with selects (round 6 default: packed pairs)
+        test_gat_headmean_layer_aggregate_then_transform(eng, dev)
+    with pc.option(eng, "gat_sh_pk", 0), pc.option(eng, "gat_sh_zlds", 0), pc.option(eng, "gat_sh_prefetch", 0):   # round 4's forms
         test_gat_headmean_layer_aggregate_then_transform(eng, dev)
 
 
