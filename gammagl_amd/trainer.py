@@ -131,7 +131,9 @@ class SAGEBlockTrainer:
         self.opt.zero_grad(set_to_none=True)
         n_id, blocks, _ = self.sampler.sample(seeds, caps=self.caps)
         logits = self.net(x.index_select(0, n_id), blocks)
-        loss = F.cross_entropy(logits[: seeds.shape[0]], y.index_select(0, seeds))
+        if logits.shape[0] != seeds.shape[0]:     # (a full-range slice still records a SliceBackward: a zero-fill + a copy per step)
+            logits = logits[: seeds.shape[0]]
+        loss = F.cross_entropy(logits, y.index_select(0, seeds))
         loss.backward()
         if self.world > 1:
             import torch.distributed as dist
@@ -170,7 +172,9 @@ class SAGEBlockTrainer:
         self.opt.zero_grad(set_to_none=True)
         n_id, blocks, _ = self.sampler.sample(seeds, caps=self.caps)
         logits = self.net(x.index_select(0, n_id), blocks)
-        loss = F.cross_entropy(logits[: seeds.shape[0]], y.index_select(0, seeds))
+        if logits.shape[0] != seeds.shape[0]:     # (a full-range slice still records a SliceBackward: a zero-fill + a copy per step)
+            logits = logits[: seeds.shape[0]]
+        loss = F.cross_entropy(logits, y.index_select(0, seeds))
         loss.backward()
         self._grads_to_flat()
         return loss.detach()
