@@ -253,3 +253,22 @@ if "arxivchunk" in what:
                 line += f"  chunk {chunk if chunk else 'auto(' + str(gp.fwd.chunk) + ')'}: {ev(lambda: eng.c_spmm_sum(ei, w, x), 20) * 1e3:6.1f} us (n_long {gp.fwd.n_long})"
             print(line, flush=True)
     eng.chunk = old; eng.clear_caches()
+
+if "prodchunk" in what:
+    # products-sized graph: the K = 256 aggregate under different long-row thresholds (which rows the serial hub walk takes)
+    from gammagl_amd.layers import calc_gcn_norm
+    n, e, _, _ = DATASETS["products"]
+    ei = rmat_graph(n, e, seed=0, device=dev)
+    w = calc_gcn_norm(ei, n).contiguous()
+    x = torch.randn(n, 256, device=dev)
+    old = eng.chunk
+    with torch.no_grad():
+        for chunk in (0, 512, 1024, 2048, 4096, 8192, 16384):
+            eng.chunk = chunk; eng.clear_caches()
+            gp = eng.graph_plan(ei, n)
+            for _ in range(3): eng.c_spmm_sum(ei, w, x)
+            t = ev(lambda: eng.c_spmm_sum(ei, w, x), 10)
+            cnt = gp.fwd.counts()
+            share = float(cnt[cnt > gp.fwd.chunk].sum()) / float(cnt.sum())
+            print(f"products K=256 chunk {chunk if chunk else 'auto(' + str(gp.fwd.chunk) + ')'}: {t:7.3f} ms  (n_long {gp.fwd.n_long}, {share * 100:.1f} % of the edges in long rows)", flush=True)
+    eng.chunk = old; eng.clear_caches()
