@@ -272,3 +272,44 @@ if "prodchunk" in what:
             share = float(cnt[cnt > gp.fwd.chunk].sum()) / float(cnt.sum())
             print(f"products K=256 chunk {chunk if chunk else 'auto(' + str(gp.fwd.chunk) + ')'}: {t:7.3f} ms  (n_long {gp.fwd.n_long}, {share * 100:.1f} % of the edges in long rows)", flush=True)
     eng.chunk = old; eng.clear_caches()
+
+if "phases" in what:
+    # SOURCE-RANGE PHASES on the real (skewed) products-sized graph: the K = 256 aggregate as P accumulating launches, phase p over the
+    # edges whose source lies in the p-th slice of the id range (edges arrive sorted by source, so a row's phases continue its serial
+    # chain in the reference's order: accumulate mode seeds the row from `out`).  Round 5's range probe used UNIFORM sources; here
+    # every slice keeps its share of the hubs, so an XCD's L2 holds the 16 K hottest rows of 1/P of the sources instead of all of them.
+    from gammagl_amd.layers import calc_gcn_norm
+    from oracle import parity
+    n, e, _, _ = DATASETS["products"]
+    ei = rmat_graph(n, e, seed=0, device=dev)
+    w = calc_gcn_norm(ei, n).contiguous()
+    E0 = int(ei.shape[1]) - n                       # rmat_graph: E0 edges sorted by source, then the n self-loops (add_self_loops order)
+    src = ei[0, :E0].contiguous()
+    assert bool((src[1:] >= src[:-1]).all()), "edge list is not sorted by source"
+    assert bool((ei[0, E0:] == ei[1, E0:]).all())
+    x = torch.randn(n, 256, device=dev)
+    with torch.no_grad():
+        ref = eng.c_spmm_sum(ei, w, x); ref = eng.c_spmm_sum(ei, w, x)
+        t1 = ev(lambda: eng.c_spmm_sum(ei, w, x), 8)
+        print(f"single plan: {t1:7.3f} ms", flush=True)
+        for P in (2, 3, 4, 6, 8):
+            plans = []
+            for p in range(P):
+                lo, hi = (n * p) // P, (n * (p + 1)) // P
+                a = int(torch.searchsorted(src, torch.tensor([lo], device=dev))[0]); b = int(torch.searchsorted(src, torch.tensor([hi], device=dev))[0])
+                ei_p = ei[:, a:b]; w_p = w[a:b]
+                if p == P - 1:                           # the loops come last in every row's original order: behind the last slice
+                    ei_p = torch.cat([ei_p, ei[:, E0:]], dim=1); w_p = torch.cat([w_p, w[E0:]])
+                ei_p = ei_p.contiguous(); w_p = w_p.contiguous()
+                plans.append((eng.graph_plan(ei_p, n, n), w_p, ei_p))
+            out = torch.empty_like(x)
+            def run():
+                for p, (gp, w_p, _) in enumerate(plans):
+                    eng.spmm_sum_into(gp.fwd, gp.col, w_p, x, out, accumulate=(p > 0))
+            run(); run(); run()
+            t = ev(run, 8)
+            r = parity.report(out, ref)
+            nl = [int(gp.fwd.n_long) for gp, _, _ in plans]
+            print(f"P={P}: {t:7.3f} ms  rows bit-identical to the single walk {r['rows_bit_exact_frac']:.6f}  max row-scale err {r['max_rel_err']:.2e}  long rows per phase {nl}", flush=True)
+            del plans, out
+            eng.clear_caches(); torch.cuda.empty_cache()
