@@ -115,6 +115,7 @@ struct Options {
   // the head-mean (output-layer) GAT walks, round 5 (Reddit-sized graph, profiles/r5_gat_sh_forms.txt: layer fwd 5.13 -> 4.64 ms,
   // fwd + bwd 20.9 -> 18.6 ms, 2-layer step 32.0 -> 29.6 ms):
   int64_t gat_sh_pk = 1;          // backward walks of the head-mean GAT: dots packed over head pairs (v_pk_fma_f32), select-free reduce-scatter (round 6)
+  int64_t gat_sh_pipe = 0;        // source walk of the head-mean backward with its gathers software-pipelined one step ahead (A/B, round 6)
   int64_t gat_sh_glds = 0;        // destination walk of the backward: the row's G in per-lane LDS slots too (A/B)
   int64_t gat_sh_prefetch = 1;    // forward / destination walks request the next step's ids before this step's gathers
   int64_t gat_sh_zlds = 1;        // source walk of the backward: the row's z_j in per-lane LDS slots instead of 32 registers (140 -> 125:

@@ -930,6 +930,130 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
   if (e == 0) gel[it.row * kShH + h] = (float)gl;
 }
 
+// PIPE (round 6, option gat_sh_pipe, A/B): the source walk above with its GATHERS software-pipelined — the gy rows and the stats panels of
+// step i + 1 are requested before step i's dots (their ids two steps ahead), so a wavefront's own arithmetic hides its own memory round trip
+// instead of relying on the 2-3 other wavefronts of the SIMD; costs ~24 more registers (the in-flight step's rows).  Packed pair dots, z_j pairs
+// in LDS slots (the PK + ZLDS form); same arithmetic in the same order: same bits.
+template <bool DROP>
+__global__ __launch_bounds__(kBlock) void gat_sh_bwd_src_pipe_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col /* colT */, const int32_t *__restrict__ posT,
+    const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+    const int64_t *__restrict__ chunk_ptr, const float *__restrict__ el, const float *__restrict__ z,
+    const float *__restrict__ gy, const float *__restrict__ stats, float *__restrict__ T, float *__restrict__ gel,
+    float *__restrict__ pacc, float *__restrict__ pgel, const int64_t *__restrict__ rng, const ShDims d) {
+  GGL_SH_PROLOGUE();
+  const int64_t F = d.F;
+  __shared__ float4 zs[kShH][kBlock];
+  float4 acc[kShH];
+  ShPairs ZP;
+  sh_pairs_load(ZP, z + it.row * kShH * F + kk, F, li, act);
+  sh_pairs_to_lds(ZP, zs);
+#pragma unroll
+  for (int q = 0; q < kShH; ++q) acc[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const float el_j = el[it.row * kShH + h];
+  const uint64_t seed = DROP ? (uint64_t)rng[0] : 0, offset = DROP ? (uint64_t)rng[1] : 0;
+  double gl = 0.0;
+  const int64_t pfirst = it.beg & ~(int64_t)3;
+  if (pfirst >= it.end) {   // an empty row: zeros
+    if (!it.is_chunk) {
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(T + (it.row * kShH + q) * F + kk) = acc[q];
+      }
+      if (e == 0) gel[it.row * kShH + h] = 0.0f;
+    } else {
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(pacc + (it.cid * kShH + q) * F + kk) = acc[q];
+      }
+      if (e == 0) pgel[it.cid * kShH + h] = 0.0f;
+    }
+    return;
+  }
+  auto own_pos = [&](int64_t p0, int32_t (&o)[2]) {
+    const int64_t a = p0 + e, c = p0 + 2 + e;
+    o[0] = (a >= it.beg && a < it.end) ? posT[a] : 0;
+    o[1] = (c >= it.beg && c < it.end) ? posT[c] : 0;
+  };
+  // in flight: the rows / stats of the step about to be computed (N = "next"), and the ids of the step after it (nb)
+  ShBlock bN, nb;
+  int32_t fqN[2] = {0, 0}, nfq[2] = {0, 0};
+  float4 gvN[4], st0N, st1N;
+  auto request = [&](const ShBlock &b) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gvN[u] = *reinterpret_cast<const float4 *>(gy + (int64_t)b.c[u] * F + kk);
+    const int32_t cA = e ? b.c[1] : b.c[0], cB = e ? b.c[3] : b.c[2];
+    st0N = *reinterpret_cast<const float4 *>(stats + ((int64_t)cA * kShH + h) * 4);
+    st1N = *reinterpret_cast<const float4 *>(stats + ((int64_t)cB * kShH + h) * 4);
+  };
+  sh_block(col, pfirst, it.beg, it.end, bN);
+  if (DROP) own_pos(pfirst, fqN);
+  request(bN);
+  if (pfirst + 4 < it.end) {
+    sh_block(col, pfirst + 4, it.beg, it.end, nb);
+    if (DROP) own_pos(pfirst + 4, nfq);
+  }
+  for (int64_t p0 = pfirst; p0 < it.end; p0 += 4) {
+    // this step's operands leave the in-flight set ...
+    const ShBlock b = bN;
+    const int32_t fq2[2] = {fqN[0], fqN[1]};
+    float4 gv[4] = {gvN[0], gvN[1], gvN[2], gvN[3]};
+    const float4 st0 = st0N, st1 = st1N;
+    // ... and the next step's are requested before this step's arithmetic
+    if (p0 + 4 < it.end) {
+      bN = nb;
+      if (DROP) { fqN[0] = nfq[0]; fqN[1] = nfq[1]; }
+      request(bN);
+      if (p0 + 8 < it.end) {
+        sh_block(col, p0 + 8, it.beg, it.end, nb);
+        if (DROP) own_pos(p0 + 8, nfq);
+      }
+    }
+    const bool okA = e ? b.ok[1] : b.ok[0], okB = e ? b.ok[3] : b.ok[2];
+    float wk[2];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      f2v v0[4], v1[4];
+      sh_pair_dots<true>(ZP, zs, sel4(e != 0, gv[2 * pr + 1], gv[2 * pr]), sel4(e != 0, gv[2 * pr], gv[2 * pr + 1]), v0, v1);
+      asm volatile("" ::: "memory");
+      float da = sh_pair_reduce(v0, v1);
+      const float4 st = pr ? st1 : st0;
+      const bool ok = pr ? okB : okA;
+      const float raw = el_j + st.x;
+      const float al = fexp(lrelu(raw, d.slope) - st.y) * st.z;
+      float alk = al;
+      if (DROP) {
+        const bool keep = ok && drop_word((int64_t)fq2[pr], kShH, h, offset, seed) >= d.drop_thresh;
+        alk = keep ? al * d.drop_scale : 0.0f;
+        da = keep ? da * d.drop_scale : 0.0f;
+      }
+      const float ds = al * (da - st.w);
+      const float dv = raw > 0.0f ? ds : ds * d.slope;
+      gl += (double)(ok ? dv : 0.0f);
+      wk[pr] = ok ? alk : 0.0f;
+    }
+    sh_accumulate<0>(wk[0], gv[0], acc);
+    sh_accumulate<1>(wk[0], gv[1], acc);
+    sh_accumulate<0>(wk[1], gv[2], acc);
+    sh_accumulate<1>(wk[1], gv[3], acc);
+  }
+  gl += row_ror8_f64(gl);
+  if (it.is_chunk) {
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(pacc + (it.cid * kShH + q) * F + kk) = acc[q];
+    }
+    if (e == 0) pgel[it.cid * kShH + h] = (float)gl;
+    return;
+  }
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < kShH; ++q) *reinterpret_cast<float4 *>(T + (it.row * kShH + q) * F + kk) = acc[q];
+  }
+  if (e == 0) gel[it.row * kShH + h] = (float)gl;
+}
+
 }  // namespace ggl
 
 using namespace ggl;
@@ -1278,6 +1402,13 @@ extern "C" int ggl_gat_sh_bwd(const ggl_segplan_t *plan, const int32_t *col, con
                    planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
       else
         GGL_LAUNCH((gat_sh_bwd_src_kernel<false, 1, false, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                   planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+    } else if (pk && options().gat_sh_pipe != 0) {    // A/B: gathers software-pipelined one step ahead
+      if (d.drop_thresh)
+        GGL_LAUNCH((gat_sh_bwd_src_pipe_kernel<true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
+                   planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
+      else
+        GGL_LAUNCH((gat_sh_bwd_src_pipe_kernel<false>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,
                    planT->chunk_ptr, el, z, gy, stats, T, gel, pacc, pgel, rng_used, d);
     } else if (pk && d.drop_thresh && options().gat_sh_waves >= 4)   // (A/B: built for 4 wavefronts per SIMD — 128 registers + 12 spilled values)
       GGL_LAUNCH((gat_sh_bwd_src_kernel<true, 4, true, true>), grid, kBlock, s, planT->rowptr, colT, posT, order, planT->long_rows,

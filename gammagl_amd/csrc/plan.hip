@@ -58,6 +58,7 @@ Options &options() {
     t.gat_sh_waves = env_i64("GGL_GAT_SH_WAVES", t.gat_sh_waves);
     t.gat_sh_zlds = env_i64("GGL_GAT_SH_ZLDS", t.gat_sh_zlds);
     t.gat_sh_pk = env_i64("GGL_GAT_SH_PK", t.gat_sh_pk);
+    t.gat_sh_pipe = env_i64("GGL_GAT_SH_PIPE", t.gat_sh_pipe);
     t.gat_sh_prefetch = env_i64("GGL_GAT_SH_PREFETCH", t.gat_sh_prefetch);
     t.gat_sh_glds = env_i64("GGL_GAT_SH_GLDS", t.gat_sh_glds);
     t.hub_pipe = env_i64("GGL_HUB_PIPE", t.hub_pipe);
@@ -312,6 +313,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "gat_sh_waves")) o.gat_sh_waves = value;
   else if (!strcmp(name, "gat_sh_zlds")) o.gat_sh_zlds = value;
   else if (!strcmp(name, "gat_sh_pk")) o.gat_sh_pk = value;
+  else if (!strcmp(name, "gat_sh_pipe")) o.gat_sh_pipe = value;
   else if (!strcmp(name, "gat_sh_prefetch")) o.gat_sh_prefetch = value;
   else if (!strcmp(name, "gat_sh_glds")) o.gat_sh_glds = value;
   else if (!strcmp(name, "hub_pipe")) o.hub_pipe = value;
@@ -348,6 +350,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "gat_sh_waves")) return o.gat_sh_waves;
   if (!strcmp(name, "gat_sh_zlds")) return o.gat_sh_zlds;
   if (!strcmp(name, "gat_sh_pk")) return o.gat_sh_pk;
+  if (!strcmp(name, "gat_sh_pipe")) return o.gat_sh_pipe;
   if (!strcmp(name, "gat_sh_prefetch")) return o.gat_sh_prefetch;
   if (!strcmp(name, "gat_sh_glds")) return o.gat_sh_glds;
   if (!strcmp(name, "hub_pipe")) return o.hub_pipe;

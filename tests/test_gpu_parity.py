@@ -824,6 +824,8 @@ def test_gat_headmean_walk_forms(eng, dev):
         test_gat_headmean_layer_aggregate_then_transform(eng, dev)
     with pc.option(eng, "gat_sh_pk", 0):     # round 5's dots + 16-value reduce-scatter with selects (round 6 default: packed pairs)
         test_gat_headmean_layer_aggregate_then_transform(eng, dev)
+    with pc.option(eng, "gat_sh_pipe", 1):   # the source walk with its gathers software-pipelined one step ahead (A/B)
+        test_gat_headmean_layer_aggregate_then_transform(eng, dev)
     with pc.option(eng, "gat_sh_pk", 0), pc.option(eng, "gat_sh_zlds", 0), pc.option(eng, "gat_sh_prefetch", 0):   # round 4's forms
         test_gat_headmean_layer_aggregate_then_transform(eng, dev)
 
