@@ -127,6 +127,11 @@ struct Options {
   // kernel that spins on its predecessors (an A/B knob only: its look-back assumes lower-numbered blocks are resident or
   // will be scheduled, and its slots are told apart by a tag of (seed, offset, scan, block) instead of being zeroed per hop).
   int64_t hop_fused_scans = 0;
+  // small hops (round 6, A/B): the first scan + clamp + clamp_last as ONE single-workgroup launch (<= 65 536 rows: both hops of the reference's
+  // [25, 10] mini-batch), the flag scan likewise while it covers <= 32 768 positions.  Measured in three forms (values computed inside the
+  // workgroup: step 0.62 -> 0.76 ms; thread-contiguous scan: +0.055 ms; coalesced wave-slice scan: +0.02 .. +0.1 ms against the rocprim
+  // launches in paired runs) — a single workgroup on one CU is not faster than four 5-us launches it replaces.  OFF.
+  int64_t hop_small_scans = 0;
   // the hub walk's side queue created with the device's greatest priority (big eager launches only: hubf32.hip).  OFF: the
   // isolated aggregate gains 1 % (13.75 -> 13.60 ms) but the products STEP nothing (75.46 vs 75.45 ms) and a partitioned step
   // LOSES (dry 8-way share 14.3 -> 16.9 ms, 4-way 26.1 -> 29.3: profiles/r5_priority_ab.txt)

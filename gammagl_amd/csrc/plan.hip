@@ -64,6 +64,7 @@ Options &options() {
     t.hub_pipe = env_i64("GGL_HUB_PIPE", t.hub_pipe);
     t.hub_priority = env_i64("GGL_HUB_PRIORITY", t.hub_priority);
     t.hop_fused_scans = env_i64("GGL_HOP_FUSED_SCANS", t.hop_fused_scans);
+    t.hop_small_scans = env_i64("GGL_HOP_SMALL_SCANS", t.hop_small_scans);
     t.maxbwd_arg32 = env_i64("GGL_MAXBWD_ARG32", t.maxbwd_arg32);
     t.maxbwd_mask = env_i64("GGL_MAXBWD_MASK", t.maxbwd_mask);
     t.maxbwd_mask_kmax = env_i64("GGL_MAXBWD_MASK_KMAX", t.maxbwd_mask_kmax);
@@ -319,6 +320,7 @@ extern "C" int ggl_set_option(const char *name, int64_t value) {
   else if (!strcmp(name, "hub_pipe")) o.hub_pipe = value;
   else if (!strcmp(name, "hub_priority")) o.hub_priority = value;
   else if (!strcmp(name, "hop_fused_scans")) o.hop_fused_scans = value;
+  else if (!strcmp(name, "hop_small_scans")) o.hop_small_scans = value;
   else if (!strcmp(name, "maxbwd_arg32")) o.maxbwd_arg32 = value;
   else if (!strcmp(name, "maxbwd_mask")) o.maxbwd_mask = value;
   else if (!strcmp(name, "maxbwd_mask_kmax")) o.maxbwd_mask_kmax = value;
@@ -356,6 +358,7 @@ extern "C" int64_t ggl_get_option(const char *name) {
   if (!strcmp(name, "hub_pipe")) return o.hub_pipe;
   if (!strcmp(name, "hub_priority")) return o.hub_priority;
   if (!strcmp(name, "hop_fused_scans")) return o.hop_fused_scans;
+  if (!strcmp(name, "hop_small_scans")) return o.hop_small_scans;
   if (!strcmp(name, "maxbwd_arg32")) return o.maxbwd_arg32;
   if (!strcmp(name, "maxbwd_mask")) return o.maxbwd_mask;
   if (!strcmp(name, "maxbwd_mask_kmax")) return o.maxbwd_mask_kmax;

@@ -705,6 +705,57 @@ __global__ __launch_bounds__(kBlock) void hop_flag_scan_kernel(const int64_t *__
 }
 #endif
 
+#ifndef GGL_EMULATE
+// ---- small hops: scan + clamp (+ clamp_last), and the flag scan, as ONE single-workgroup launch each (round 6) -----------------------
+// A replayed mini-batch step is bound by the number of its dependent ~5-us launches.  The hop's first scan runs over B_cap + 1 <= 2^16
+// values — rocprim's [init] + [scan] + [clamp] + [clamp_last] = four launches, 20 us, for 150 KB of work that one workgroup of 1024
+// threads finishes in one launch: no inter-workgroup state, no look-back chain (what made round 5's multi-block fused scans as slow as
+// the launches they replaced).  The VALUES stay with their parallel kernels (hop_count / hop_flag): computed inside the single
+// workgroup they cost 2-50 dependent random reads per thread on ONE CU (measured: the step 0.62 -> 0.76 ms).  The second scan (flags
+// over B_cap + E_cap + 1 positions) takes the same form only while it is small: one CU streams ~130 GB/s, rocprim's two launches take 10 us.
+constexpr int kSmallThreads = 1024, kSmallWaves = kSmallThreads / 64;
+constexpr int64_t kSmallScanMax = 65536;       // values the first scan's single launch covers
+constexpr int64_t kSmallFlagMax = 32768;       // ... and the flag scan's
+// out[i] = min(cap, sum of in[0 .. i)) for i in [0, n); over_flag (or NULL) = the unclamped total exceeds cap (cap < 0: no clamp).
+// = exclusive scan + hop_clamp_kernel + hop_clamp_last_kernel.  Wavefront w owns the contiguous slice [w C, (w + 1) C) and walks it in
+// COALESCED 64-element steps (a lane per element, a shuffle scan per step, the running prefix carried in a register): pass 1 the slices'
+// totals, one barrier, pass 2 the prefixes.  (A thread-contiguous split reads 64 different lines per load instruction: measured slower
+// than the four launches it replaces.)
+__global__ __launch_bounds__(kSmallThreads) void scan_clamp_small_kernel(const int64_t *__restrict__ in, int64_t n, int64_t cap,
+                                                                        int64_t *__restrict__ out, int64_t *__restrict__ over_flag) {
+  __shared__ uint64_t wsum[kSmallWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t C = ((n + kSmallWaves - 1) / kSmallWaves + 63) / 64 * 64;     // slice length: a multiple of the step
+  const int64_t lo = (int64_t)wave * C, hi = lo + C < n ? lo + C : n;
+  uint64_t tot = 0;
+  for (int64_t i = lo + lane; i < hi; i += 64) tot += (uint64_t)in[i];
+#pragma unroll
+  for (int dlt = 32; dlt > 0; dlt >>= 1) tot += __shfl_xor(tot, dlt, 64);
+  if (lane == 0) wsum[wave] = tot;
+  __syncthreads();
+  uint64_t run = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < kSmallWaves; ++q) {
+    if (q < wave) run += wsum[q];
+    total += wsum[q];
+  }
+  for (int64_t base = lo; base < hi; base += 64) {
+    const int64_t i = base + lane;
+    const uint64_t v = i < hi ? (uint64_t)in[i] : 0ull;      // (read before out[i] is written: in and out may be the same array)
+    uint64_t incl = v;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint64_t y = __shfl_up(incl, dlt, 64);
+      if (lane >= dlt) incl += y;
+    }
+    const uint64_t p = run + incl - v;
+    if (i < hi) out[i] = (cap >= 0 && (int64_t)p > cap) ? cap : (int64_t)p;
+    run += __shfl(incl, 63, 64);
+  }
+  if (over_flag && threadIdx.x == 0) *over_flag = (cap >= 0 && (int64_t)total > cap) ? 1 : 0;
+}
+#endif
+
 // ---- static-shape hop -------------------------------------------------------------------------------
 extern "C" size_t ggl_sample_hop_workspace_bytes(int64_t B_cap, int64_t E_cap) {
   if (B_cap < 0 || E_cap < 0) return 0;
@@ -757,7 +808,21 @@ extern "C" int ggl_sample_hop_ex(const int64_t *rowptr, const int64_t *col, cons
 #else
   const bool fused_scans = false;
 #endif
-  if (fused_scans) {
+#ifndef GGL_EMULATE
+  const bool small1 = options().hop_small_scans != 0 && B_cap + 1 <= kSmallScanMax;
+  const bool small2 = options().hop_small_scans != 0 && T <= kSmallFlagMax;
+#else
+  const bool small1 = false, small2 = false;
+#endif
+  if (small1) {
+#ifndef GGL_EMULATE
+    GGL_LAUNCH((hop_count_kernel), grid_for(B_cap + 1), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap, num_nodes, fanout, cnt);
+    GGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_clamp_small_kernel, dim3(1), dim3(kSmallThreads), 0, s, (const int64_t *)cnt, B_cap + 1, E_cap, out_rowptr,
+                       out_counts + 2);
+    GGL_LAUNCH_CHECK();
+#endif
+  } else if (fused_scans) {
 #ifndef GGL_EMULATE
     GGL_LAUNCH((hop_count_scan_kernel), ceil_div(B_cap + 1, (int64_t)kScanTile), kBlock, s, rowptr, seeds, n_seeds_dev, B_cap,
                num_nodes, fanout, E_cap, (const int64_t *)rng_state, slots1, out_rowptr, out_counts);
@@ -785,7 +850,16 @@ extern "C" int ggl_sample_hop_ex(const int64_t *rowptr, const int64_t *col, cons
   GGL_LAUNCH((hop_mark_kernel), grid_for(B_cap + E_cap), kBlock, s, seeds, n_seeds_dev, B_cap, (const int64_t *)nbr,
              (const int64_t *)out_rowptr, num_nodes, fp);
   GGL_LAUNCH_CHECK();
-  if (fused_scans) {
+  if (small2) {
+#ifndef GGL_EMULATE
+    GGL_LAUNCH((hop_flag_kernel), grid_for(T), kBlock, s, n_seeds_dev, B_cap, E_cap, (const int64_t *)nbr,
+               (const int64_t *)out_rowptr, (const long long *)fp, flag);
+    GGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_clamp_small_kernel, dim3(1), dim3(kSmallThreads), 0, s, (const int64_t *)flag, T, (int64_t)-1, new_id,
+                       (int64_t *)nullptr);
+    GGL_LAUNCH_CHECK();
+#endif
+  } else if (fused_scans) {
 #ifndef GGL_EMULATE
     GGL_LAUNCH((hop_flag_scan_kernel), ceil_div(T, (int64_t)kScanTile), kBlock, s, n_seeds_dev, B_cap, E_cap, (const int64_t *)nbr,
                (const int64_t *)out_rowptr, (const long long *)fp, (const int64_t *)rng_state, slots2, flag, new_id);

@@ -782,6 +782,9 @@ def test_static_shape_block_sampler(eng, dev, oracle):
     # default: same blocks, bit for bit — the checks compare against the dynamic sampler and the oracle)
     with pc.option(eng, "hop_fused_scans", 1):
         pc.check_block_sampler(eng, dev, oracle)
+    # round 6 (an A/B knob too, off: no faster): the scans of small hops as ONE single-workgroup launch each
+    with pc.option(eng, "hop_small_scans", 1):
+        pc.check_block_sampler(eng, dev, oracle)
 
 
 def test_minibatch_step_captures_into_one_hipgraph(eng, dev):
