@@ -5,9 +5,10 @@ Same names, argument meaning and return types as the reference module
 (read by MessagePassing.message_aggregate, layers/conv/message_passing.py:99) and ``torch`` (which
 leaks through the star-import and is used at message_passing.py:101).  Differences, on purpose:
 
-* the work runs in hand-written HIP kernels on MI355X, reached through the dispatcher ops
-  ``torch.ops.gammagl_amd.*`` (gammagl_amd/torch_ops.py); CPU tensors dispatch to the host build of the same
-  kernel sources, as the reference dispatches on ``x.is_cpu()`` (BASELINE config 1: ``--gpu -1``);
+* the work runs in hand-written HIP kernels on MI355X, reached through the dispatcher ops ``torch.ops.ggl.*`` registered from
+  C++ (csrc/torch/ggl_torch.cpp; ``torch.ops.gammagl_amd.*``, the same schemas over the ctypes engine, for engines injected by the
+  test-suite); CPU tensors dispatch to the host build of the same kernel sources, as the reference dispatches on ``x.is_cpu()``
+  (BASELINE config 1: ``--gpu -1``);
 * native errors are NOT swallowed: the reference's segment wrappers catch every exception and
   silently re-run a pure-torch fallback (torch.py:83-86,139-142,199-202) that disagrees with the
   C++ extension on empty max segments and integer dtypes (SURVEY.md §8c); here an error is an error;
@@ -20,8 +21,24 @@ import torch  # noqa: F401  (re-exported on purpose, see above)
 from . import engine as _engine
 from . import torch_ops as _torch_ops  # registers torch.ops.gammagl_amd.* (CUDA = HIP kernels, CPU = host build)
 
-_ops = _torch_ops.ops
+_py_ops = _torch_ops.ops
 use_ext = True
+
+
+def _ops_for(x):
+    """The operator namespace that serves `x`: ``torch.ops.ggl`` — the seven operators registered from C++ (libggl_torch.so: plan
+    cache, launch policy and autograd in C++; what compat/_torch_ext.py binds and, since round 6, what bench.py's one-GPU step runs)
+    — whenever the engine for x's device is the shipped library; the Python-registered ``torch.ops.gammagl_amd`` (same schemas over
+    the ctypes engine) for an engine injected on another build of the kernel sources (host-emulation / ASan tests) or with
+    GGL_CPP_OPS=0."""
+    eng = _engine(x)
+    eng._dev(x)
+    if getattr(eng, "is_product", False):
+        from . import cpp_ops
+
+        if cpp_ops.enabled():
+            return cpp_ops.load()
+    return _py_ops
 
 __all__ = ["unsorted_segment_sum", "unsorted_segment_mean", "unsorted_segment_max", "segment_sum",
            "segment_mean", "segment_max", "gspmm", "bspmm", "use_ext", "torch"]
@@ -47,24 +64,21 @@ def unsorted_segment_sum(x, segment_ids, num_segments=None):
     """out[s] = sum of x[e] over e with segment_ids[e] == s (torch.py:43-86)."""
     assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
     n = _num_segments(segment_ids, num_segments)
-    _engine(x)._dev(x)
-    return _ops.segment_sum(x, _ids(segment_ids, x), n)
+    return _ops_for(x).segment_sum(x, _ids(segment_ids, x), n)
 
 
 def unsorted_segment_mean(x, segment_ids, num_segments=None):
     """Mean along segments; empty segments give 0 (torch.py:99-142)."""
     assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
     n = _num_segments(segment_ids, num_segments)
-    _engine(x)._dev(x)
-    return _ops.segment_mean(x, _ids(segment_ids, x), n)
+    return _ops_for(x).segment_mean(x, _ids(segment_ids, x), n)
 
 
 def unsorted_segment_max(x, segment_ids, num_segments=None):
     """Max along segments (torch.py:159-202); empty segments hold lowest() as in the C++ extension."""
     n = _num_segments(segment_ids, num_segments)
     assert x.shape[0] == segment_ids.shape[0], "the length of segment_ids should be equal to data.shape[0]."
-    _engine(x)._dev(x)
-    return _ops.segment_max(x, _ids(segment_ids, x), n)[0]
+    return _ops_for(x).segment_max(x, _ids(segment_ids, x), n)[0]
 
 
 def segment_max(x, segment_ids, num_segments=None):
@@ -82,6 +96,7 @@ def segment_sum(x, segment_ids, num_segments=None):
 def gspmm(index, weight=None, x=None, reduce='sum'):
     """Generalized SpMM: out[dst] = reduce_e weight[e] * x[src] (torch.py:302-351)."""
     _engine(x)._dev(index, weight, x)
+    _ops = _ops_for(x)
     # weight=None: torch.py:332-333 builds ones([E]) f32; w * x == x exactly, so the kernels simply skip
     # the multiply when no weight pointer is passed
     if reduce == 'sum':
@@ -102,6 +117,6 @@ def bspmm(index, weight=None, x=None, reduce='sum'):
         weight = torch.ones((index.shape[1], x.shape[1]), dtype=torch.float32, device=x.device)
     if reduce == 'sum':
         _engine(x)._dev(index, weight, x)
-        return _ops.bspmm_sum(index, weight, x)
+        return _ops_for(x).bspmm_sum(index, weight, x)
     else:
         raise Exception("Unsupported reduce type, please choose from ['sum'].")

@@ -449,3 +449,32 @@ def test_reseed_reaches_the_cpp_route_dropout_stream(cpp):
     assert runs[0][0] == runs[1][0], runs
     for a, b in zip(runs[0][1], runs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_mpops_surface_runs_on_the_cpp_operators(cpp):
+    """gammagl_amd.mpops — the module GammaGL's `from gammagl.mpops import *` is replaced with (INTEGRATION.md option A) — reaches the
+    kernels through torch.ops.ggl (C++ plan cache + autograd) when the engine is the shipped library (round 6: one host
+    implementation behind every drop-in route), and through the Python-registered ops only for an injected engine."""
+    import gammagl_amd
+    from gammagl_amd import mpops
+
+    prev = gammagl_amd._engine
+    gammagl_amd._engine = None           # no injected engine: CPU tensors -> host_engine() (a product engine)
+    try:
+        assert mpops._ops_for(torch.zeros(1)) is cpp.ops
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(500, 12, generator=g, requires_grad=True)
+        ids = torch.randint(0, 40, (500,), generator=g)
+        before = list(cpp.ops.plan_stats())
+        y = mpops.unsorted_segment_sum(x, ids, 40)
+        assert list(cpp.ops.plan_stats()) != before, "the call did not reach the C++ operator library's plan cache"
+        y.sum().backward()
+        want = torch.zeros(40, 12).index_add_(0, ids, x.detach())
+        assert torch.allclose(y.detach(), want, atol=1e-5) and torch.equal(x.grad, torch.ones_like(x))
+        ei = torch.randint(0, 60, (2, 700), generator=g)
+        xs = torch.randn(60, 8, generator=g)
+        w = torch.rand(700, generator=g)
+        for red in ("sum", "mean", "max"):
+            assert torch.equal(mpops.gspmm(ei, w, xs, red), getattr(cpp.ops, "spmm_" + red)(ei, w, xs))
+    finally:
+        gammagl_amd._engine = prev
