@@ -594,7 +594,7 @@ def committed_traffic(args, launches, E):
     if not (args.workload == "products" and args.hidden == 256 and args.order == "src" and args.relabel == "random"
             and args.seed == 0):
         return None, None
-    for name in ("r3_pmc_products_k256.json", "r2_pmc_products_k256.json"):
+    for name in ("r6_pmc_products_k256.json", "r2_pmc_products_k256.json"):
         try:
             rec = json.load(open(os.path.join(REPO, "profiles", name)))
             if int(rec.get("graph_edges", -1)) == E and int(rec.get("launches_per_aggregate", 1)) == launches:
